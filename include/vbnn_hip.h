@@ -1,0 +1,214 @@
+/*
+ * vbnn_hip.h -- C ABI of the MI355X-native VBLinear hot path (libvbnn_hip.so).
+ *
+ * The reference (louissmit/VBNN) has no FFI of its own: its hot path is Lua calling
+ * Torch7 tensor ops. Each entry point below therefore cites the Lua call site it
+ * replaces (file:line under the reference tree). The host side that binds this ABI is
+ *   - vbnn_amd/nn.py      (ctypes; same class/method names as VBLinear.lua / mlp.lua)
+ *   - lua/VBLinear.lua    (LuaJIT FFI shim)
+ *
+ * Conventions
+ *   - every function returns an int status (0 = VBNN_OK); the message of the last
+ *     failure on the calling thread is vbnn_last_error(). No C++ exception crosses.
+ *   - all tensor pointers are DEVICE pointers (hipMalloc'ed by anyone: this library's
+ *     vbnn_buf_alloc, PyTorch-ROCm, ...). The library never retains them.
+ *   - calls are asynchronous on the context's HIP stream; vbnn_sync / vbnn_buf_download
+ *     are the only blocking calls.
+ *   - matrices are dense row-major. "packed operands" are the GEMM-ready copies made by
+ *     vbnn_pack: element type f32 or bf16 (dtype), leading dimension padded to a
+ *     multiple of VBNN_KPAD elements with ZERO fill (allocate them zeroed).
+ *   - O = outputSize, I = inputSize, N = minibatch rows (local rows on this rank).
+ */
+#ifndef VBNN_HIP_H
+#define VBNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
+#endif
+
+#define VBNN_ABI_VERSION 1
+#define VBNN_KPAD 64            /* packed leading dimensions are multiples of this */
+
+enum { VBNN_OK = 0, VBNN_ERR_INVALID = 1, VBNN_ERR_HIP = 2, VBNN_ERR_NOMEM = 3, VBNN_ERR_UNSUPPORTED = 4 };
+enum { VBNN_F32 = 0, VBNN_BF16 = 1 };                       /* dtype of packed operands */
+enum { VBNN_PACK_COPY = 0, VBNN_PACK_EXP = 1, VBNN_PACK_SQUARE = 2, VBNN_PACK_MUL = 3,
+       VBNN_PACK_RELU = 4, VBNN_PACK_RELU_SQUARE = 5 };
+
+typedef struct vbnn_ctx vbnn_ctx;
+
+int vbnn_abi_version(void);
+const char* vbnn_last_error(void);
+
+/* context = (device, stream). stream == NULL: the library creates its own. */
+int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);
+int vbnn_ctx_destroy(vbnn_ctx* ctx);
+int vbnn_ctx_set_stream(vbnn_ctx* ctx, void* hip_stream);
+int vbnn_sync(vbnn_ctx* ctx);
+
+/* device-buffer helpers for hosts without a tensor library on the device (the Lua shim;
+ * replaces the cutorch :cuda() copies at VBLinear.lua:40-44,56-58 and main.lua:22-25). */
+int vbnn_buf_alloc(vbnn_ctx* ctx, size_t bytes, void** dptr);   /* zero-initialised */
+int vbnn_buf_free(vbnn_ctx* ctx, void* dptr);
+int vbnn_buf_zero(vbnn_ctx* ctx, void* dptr, size_t bytes);
+int vbnn_buf_upload(vbnn_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int vbnn_buf_download(vbnn_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);  /* blocks */
+
+/* rows x cols standard normals (include/vbnn_philox.h contract):
+ * out[r][c] = lane c&3 of vbnn_normal4(seed, stream, layer, draw, row0 + r, c >> 2), times `scale`.
+ * Replaces randomkit.normal at VBLinear.lua:26-28 (means init) and mlp.lua:53 (He init);
+ * also the synthetic-input generator of bench.py. */
+int vbnn_fill_normal(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int64_t ld,
+                     uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
+                     float scale);
+
+/* VBLinear:compute_prior (VBLinear.lua:77-88). One fused sweep over means/lvars:
+ *   stats[0] = sum(exp(lvars) + means^2)   (so var_hat = stats[0] / W, :86)
+ *   stats[1] = sum(lvars)
+ *   stats[2] = var_hat (as double)  -- read by later kernels on the device, no host sync
+ * Optional caches (NULL to skip), exactly the reference's: vars (:78), stdv (:79), mu_sqe (:82).
+ * `stats` is a device array of 4 doubles. */
+int vbnn_compute_prior(vbnn_ctx* ctx, const float* means, const float* lvars, int64_t W,
+                       float* vars, float* stdv, float* mu_sqe, double* stats);
+
+/* VBLinear:sample (VBLinear.lua:49-64): weight = means + stdv (.) e, e ~ N(0,1) of shape O x I
+ * regenerated from the Philox counter (stream EPS). e_out may be NULL (the reference keeps
+ * self.e; the kernels never need it stored). stdv == NULL: use exp(lvars/2) of `lvars`. */
+int vbnn_wn_sample(vbnn_ctx* ctx, const float* means, const float* stdv, const float* lvars,
+                   float* weight, float* e_out, int64_t O, int64_t I,
+                   uint64_t seed, uint32_t layer, uint32_t draw);
+
+/* Generic packer: dst[r][c] = T(f(src[r][c])) for r < rows, c < cols, with
+ *   f = COPY | EXP | SQUARE | MUL (src * src2) | RELU | RELU_SQUARE;
+ * dst is rows x ld_dst, dstT (optional) is the transpose, cols x ld_dstT. Pads are not
+ * written (keep them zero). Produces every GEMM operand of the module-level path:
+ * mu/sigma^2 shadows, x and x.x, g and g.r. */
+int vbnn_pack(vbnn_ctx* ctx, int dtype, int func, const float* src, const float* src2, int64_t ld_src,
+              int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* dstT, int64_t ld_dstT);
+
+/* ---- the three GEMM families of the layer (MFMA kernels, fused epilogues) ------------------- */
+
+typedef struct vbnn_fwd_args {
+    /* operands (packed, dtype): A = weights-side O x ld_w, B = input-side N x ld_x */
+    const void* w;      /* mu shadow (LRT) or sampled-weight shadow (WN / MAP)            */
+    const void* w2;     /* sigma^2 shadow, LRT only (NULL: single GEMM)                    */
+    const void* x;      /* input                                                           */
+    const void* x2;     /* input squared, LRT only                                         */
+    int64_t ld_w, ld_x;
+    int64_t N, I, O;
+    const float* bias;  /* O, may be NULL                                                  */
+    /* LRT noise: z[n][o] from (seed, ZETA, layer, draw, row0 + n, o >> 2); ignored if w2 == NULL */
+    uint64_t seed; uint32_t layer; uint32_t draw; int64_t row0;
+    /* outputs, each optional */
+    float* y;  int64_t ld_y;        /* pre-activation output (the module's `output`), N x O     */
+    float* r;  int64_t ld_r;        /* z / (2 sqrt(v)), saved for backward (LRT), N x O f32      */
+    int relu;                       /* apply ReLU before writing the packed outputs below        */
+    void* h;  void* h2;  int64_t ld_h;     /* next layer's packed input and its square, N x ld_h  */
+    void* hT; void* h2T; int64_t ld_hT;    /* their transposes, O x ld_hT                         */
+} vbnn_fwd_args;
+
+/* updateOutput. WN/MAP: y = x w^T + b  (inherited nn.Linear:updateOutput, VBLinear.lua:7).
+ * LRT: m = x mu^T + b, v = (x.x)(sigma^2)^T, y = m + sqrt(v) . z   (north_star). */
+int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a);
+
+typedef struct vbnn_dx_args {
+    /* A = transposed weights-side I x ld_wT, B = gradient-side N x ld_g */
+    const void* wT;     /* mu^T shadow (LRT) or sampled-weight^T shadow (WN)               */
+    const void* w2T;    /* (sigma^2)^T shadow, LRT only                                     */
+    const void* g;      /* dL/dy packed                                                     */
+    const void* gv;     /* dL/dv = g . r packed, LRT only                                   */
+    int64_t ld_wT, ld_g;
+    int64_t N, I, O;
+    const void* x; int64_t ld_x;    /* this layer's packed input (LRT term 2 x . (gv sigma^2);  */
+                                    /* also the ReLU mask of the previous module)               */
+    float* gx; int64_t ld_gx;       /* gradInput N x I f32, optional                            */
+    /* optional fused hand-off to the previous VB layer: g_prev = gx . [x > 0], gv_prev = g_prev . r_prev */
+    int relu_mask;
+    const float* r_prev; int64_t ld_r_prev;
+    void* g_prev; void* gv_prev; int64_t ld_gp;      /* N x ld_gp   */
+    void* gT_prev; void* gvT_prev; int64_t ld_gpT;   /* I x ld_gpT  */
+} vbnn_dx_args;
+
+/* updateGradInput. WN: gradInput = g w (inherited, VBLinear.lua:109-110).
+ * LRT: gradInput = g mu + 2 x . (gv sigma^2). */
+int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a);
+
+typedef struct vbnn_dw_args {
+    /* A = input-side transposed I x ld_n, B = gradient-side transposed O x ld_n (K = N rows) */
+    const void* xT;     /* x^T                                                              */
+    const void* x2T;    /* (x.x)^T, LRT only                                                */
+    const void* gT;     /* g^T                                                              */
+    const void* gvT;    /* gv^T, LRT only                                                   */
+    int64_t ld_n;
+    int64_t N, I, O;
+    float scale;        /* accGradParameters' scale (applied to gradWeight only, as the reference) */
+    int accumulate;     /* 1: += (Torch semantics); 0: overwrite (first draw after resetAcc)  */
+    float* gradWeight;  /* O x I, += scale * g^T x                      (VBLinear.lua:113)     */
+    float* gradSum;     /* O x I. WN:  += (g^T x) . e                    (VBLinear.lua:114-115) */
+                        /*        LRT: += 2 (gv^T x.x) . stdv   (same units)    */
+    /* WN: e regenerated from (seed, EPS, layer, draw). LRT: stdv = exp(lvars / 2). */
+    uint64_t seed; uint32_t layer; uint32_t draw;
+    const float* lvars;
+    /* optional fused total-gradient outputs (likelihood/S + kl_scale * KL gradient),
+     * VBLinear.lua:90-98 folded into the epilogue; NULL to skip. Needs means, lvars, stats. */
+    float* grad_mu; float* grad_lv;
+    const float* means; const double* stats; float B; float S; float kl_scale;
+} vbnn_dw_args;
+
+/* accGradParameters (VBLinear.lua:112-118), one GEMM instead of the reference's two. */
+int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
+
+/* gradBias += scale * sum_n g[n][o]  (the parent call at VBLinear.lua:113). g is N x O f32. */
+int vbnn_acc_grad_bias(vbnn_ctx* ctx, const float* g, int64_t ld_g, int64_t N, int64_t O,
+                       float scale, int accumulate, float* gradBias);
+
+/* ---- KL ("LC") terms ------------------------------------------------------------------------ */
+
+/* VBLinear:compute_mugrads (VBLinear.lua:90-93): gradWeight /= S in place; lcg = means / (B var_hat).
+ * VBLinear:compute_vargrads (:95-98): gradSum = gradSum / (2S) . stdv in place;
+ *                                      lcg = ((-1/vars + 1/var_hat) / (2B)) . vars.
+ * var_hat is read from stats[2] on the device. vars/stdv NULL: derived from lvars. */
+int vbnn_compute_mugrads(vbnn_ctx* ctx, const float* means, const double* stats, float B, float S,
+                         float* gradWeight, float* lcg, int64_t W);
+int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, const float* stdv,
+                          const double* stats, float B, float S, float* gradSum, float* lcg, int64_t W);
+
+/* VBLinear:calc_lc (VBLinear.lua:99-103) with the :sum() of mlp.lua:112 fused:
+ * lc_sum_dev[0] = sum_w [log sqrt(var_hat) - log sqrt(vars) + (mu_sqe + vars - var_hat) / (2 var_hat)] / B.
+ * lc_elem (optional) receives the per-weight tensor the Lua method returns.
+ * vars / mu_sqe: the caches of the last compute_prior (the reference reads exactly those, so its
+ * LC is one optimiser step stale, main.lua:174-177); NULL: derive from means / lvars. */
+int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const float* vars, const float* mu_sqe,
+                 const double* stats, float B, float* lc_elem, double* lc_sum_dev, int64_t W);
+
+/* ---- glue modules on the measured path (mlp.lua:12-32) --------------------------------------- */
+int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);
+int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx, int64_t n);
+/* nn.LogSoftMax + nn.ClassNLLCriterion (sizeAverage) fused, forward and backward in one pass:
+ *   out = logsoftmax(logits); loss_sum_dev[0] += -sum_n out[n][t_n] * inv_n;
+ *   correct_dev[0] += #rows whose arg-max equals the target (utils.lua:11-27);
+ *   g_logits = (exp(out) - onehot) * inv_n     (= LogSoftMax:backward(ClassNLL:backward)).
+ * inv_n = 1 / (global minibatch rows). Targets are 0-based int32. */
+int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const int32_t* target,
+                        int64_t N, int64_t C, float inv_n, float* out, float* g_logits,
+                        double* loss_sum_dev, int32_t* correct_dev);
+
+/* The same criterion as separate modules, for the module-level call order of mlp.lua:77-80:
+ * nn.LogSoftMax:updateOutput is vbnn_logsoftmax_nll with g_logits = loss = correct = NULL. */
+int vbnn_nll_forward(vbnn_ctx* ctx, const float* out, int64_t ld, const int32_t* target, int64_t N, int64_t C,
+                     float inv_n, double* loss_sum_dev, int32_t* correct_dev);          /* criterion:forward  */
+int vbnn_nll_backward(vbnn_ctx* ctx, const int32_t* target, int64_t N, int64_t C, float inv_n, float* g); /* :backward */
+int vbnn_logsoftmax_backward(vbnn_ctx* ctx, const float* out, const float* g, float* gx, int64_t N, int64_t C);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBNN_HIP_H */

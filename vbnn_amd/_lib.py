@@ -1,0 +1,121 @@
+"""ctypes binding of the C ABI in include/vbnn_hip.h (vbnn_amd/lib/libvbnn_hip.so).
+
+There is NO fallback: if the shared library is missing, or a call returns a non-zero status,
+this module raises. The product path never routes through oracle/ or through PyTorch math.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvbnn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+OK = 0
+F32, BF16 = 0, 1
+PACK_COPY, PACK_EXP, PACK_SQUARE, PACK_MUL, PACK_RELU, PACK_RELU_SQUARE = range(6)
+KPAD = 64
+STREAM_EPS, STREAM_ZETA, STREAM_INIT, STREAM_DATA, STREAM_HEINIT = 1, 2, 3, 4, 5
+
+_vp, _i64, _u64, _u32, _f, _i = C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_float, C.c_int
+
+
+class VbnnError(RuntimeError):
+    pass
+
+
+class FwdArgs(C.Structure):
+    _fields_ = [("w", _vp), ("w2", _vp), ("x", _vp), ("x2", _vp), ("ld_w", _i64), ("ld_x", _i64),
+                ("N", _i64), ("I", _i64), ("O", _i64), ("bias", _vp),
+                ("seed", _u64), ("layer", _u32), ("draw", _u32), ("row0", _i64),
+                ("y", _vp), ("ld_y", _i64), ("r", _vp), ("ld_r", _i64), ("relu", _i),
+                ("h", _vp), ("h2", _vp), ("ld_h", _i64), ("hT", _vp), ("h2T", _vp), ("ld_hT", _i64)]
+
+
+class DxArgs(C.Structure):
+    _fields_ = [("wT", _vp), ("w2T", _vp), ("g", _vp), ("gv", _vp), ("ld_wT", _i64), ("ld_g", _i64),
+                ("N", _i64), ("I", _i64), ("O", _i64), ("x", _vp), ("ld_x", _i64),
+                ("gx", _vp), ("ld_gx", _i64), ("relu_mask", _i), ("r_prev", _vp), ("ld_r_prev", _i64),
+                ("g_prev", _vp), ("gv_prev", _vp), ("ld_gp", _i64),
+                ("gT_prev", _vp), ("gvT_prev", _vp), ("ld_gpT", _i64)]
+
+
+class DwArgs(C.Structure):
+    _fields_ = [("xT", _vp), ("x2T", _vp), ("gT", _vp), ("gvT", _vp), ("ld_n", _i64),
+                ("N", _i64), ("I", _i64), ("O", _i64), ("scale", _f), ("accumulate", _i),
+                ("gradWeight", _vp), ("gradSum", _vp), ("seed", _u64), ("layer", _u32), ("draw", _u32),
+                ("lvars", _vp), ("grad_mu", _vp), ("grad_lv", _vp), ("means", _vp), ("stats", _vp),
+                ("B", _f), ("S", _f), ("kl_scale", _f)]
+
+
+_SIGS = {
+    "vbnn_abi_version": ([], _i),
+    "vbnn_last_error": ([], C.c_char_p),
+    "vbnn_ctx_create": ([_i, _vp, C.POINTER(_vp)], _i),
+    "vbnn_ctx_destroy": ([_vp], _i),
+    "vbnn_ctx_set_stream": ([_vp, _vp], _i),
+    "vbnn_sync": ([_vp], _i),
+    "vbnn_buf_alloc": ([_vp, C.c_size_t, C.POINTER(_vp)], _i),
+    "vbnn_buf_free": ([_vp, _vp], _i),
+    "vbnn_buf_zero": ([_vp, _vp, C.c_size_t], _i),
+    "vbnn_buf_upload": ([_vp, _vp, _vp, C.c_size_t], _i),
+    "vbnn_buf_download": ([_vp, _vp, _vp, C.c_size_t], _i),
+    "vbnn_fill_normal": ([_vp, _vp, _i64, _i64, _i64, _u64, _u32, _u32, _u32, _i64, _f], _i),
+    "vbnn_compute_prior": ([_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
+    "vbnn_wn_sample": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _u64, _u32, _u32], _i),
+    "vbnn_pack": ([_vp, _i, _i, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64], _i),
+    "vbnn_forward": ([_vp, _i, C.POINTER(FwdArgs)], _i),
+    "vbnn_grad_input": ([_vp, _i, C.POINTER(DxArgs)], _i),
+    "vbnn_acc_grad_parameters": ([_vp, _i, C.POINTER(DwArgs)], _i),
+    "vbnn_acc_grad_bias": ([_vp, _vp, _i64, _i64, _i64, _f, _i, _vp], _i),
+    "vbnn_compute_mugrads": ([_vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),
+    "vbnn_compute_vargrads": ([_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),
+    "vbnn_calc_lc": ([_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64], _i),
+    "vbnn_relu_forward": ([_vp, _vp, _vp, _i64], _i),
+    "vbnn_relu_backward": ([_vp, _vp, _vp, _vp, _i64], _i),
+    "vbnn_logsoftmax_nll": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp], _i),
+    "vbnn_nll_forward": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp], _i),
+    "vbnn_nll_backward": ([_vp, _vp, _i64, _i64, _f, _vp], _i),
+    "vbnn_logsoftmax_backward": ([_vp, _vp, _vp, _vp, _i64, _i64], _i),
+}
+
+
+def exported_symbols():
+    """Every symbol include/vbnn_hip.h declares (kept in step by tests/test_abi.py)."""
+    return sorted(_SIGS)
+
+
+def build(verbose=False):
+    """Compile libvbnn_hip.so for gfx950 with hipcc (vbnn_amd/csrc/Makefile)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VbnnError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)       # AttributeError if the library does not export it
+            fn.argtypes = args
+            fn.restype = res
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        msg = lib().vbnn_last_error()
+        raise VbnnError(f"libvbnn_hip status {status}: {msg.decode() if msg else '?'}")
+
+
+def pad_ld(k):
+    return (int(k) + KPAD - 1) // KPAD * KPAD

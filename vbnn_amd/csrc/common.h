@@ -1,0 +1,96 @@
+// common.h -- shared definitions of the gfx950 VBLinear library (device + host glue).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/vbnn_hip.h"
+#include "../../include/vbnn_philox.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct vbnn_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    double* scratch;       // device scratch for block partial sums (prior / KL reductions)
+    size_t scratch_doubles;
+};
+
+void vbnn_set_error(const char* fmt, ...);
+
+#define VBNN_CHECK_HIP(expr)                                                             \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            vbnn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return VBNN_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+#define VBNN_REQUIRE(cond, msg)                                                          \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            vbnn_set_error("invalid argument: %s (%s) (%s:%d)", msg, #cond, __FILE__, __LINE__); \
+            return VBNN_ERR_INVALID;                                                     \
+        }                                                                                \
+    } while (0)
+
+#define VBNN_API_BEGIN try {
+#define VBNN_API_END                                                                     \
+    } catch (const std::exception& ex) {                                                 \
+        vbnn_set_error("C++ exception: %s", ex.what());                                  \
+        return VBNN_ERR_INVALID;                                                         \
+    } catch (...) {                                                                      \
+        vbnn_set_error("unknown C++ exception");                                         \
+        return VBNN_ERR_INVALID;                                                         \
+    }
+
+static inline int vbnn_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vbnn_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return VBNN_ERR_HIP;
+    }
+    return VBNN_OK;
+}
+
+// ---- element-type helpers ------------------------------------------------------------------
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+    static __device__ __forceinline__ float to(float v) { return v; }
+    static __device__ __forceinline__ float from(float v) { return v; }
+};
+template <> struct Elt<bf16_t> {
+    static __device__ __forceinline__ bf16_t to(float v) { return (bf16_t)v; }   // v_cvt_pk_bf16_f32, RNE, NaN-safe
+    static __device__ __forceinline__ float from(bf16_t v) { return (float)v; }
+};
+
+// store 4 consecutive elements (p 4-element aligned when `vec` is true)
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float a, float b, float c, float d, int valid, bool vec);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d, int valid, bool vec) {
+    if (vec && valid == 4) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+    } else {
+        if (valid > 0) p[0] = a;
+        if (valid > 1) p[1] = b;
+        if (valid > 2) p[2] = c;
+        if (valid > 3) p[3] = d;
+    }
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d, int valid, bool vec) {
+    if (vec && valid == 4) {
+        *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    } else {
+        if (valid > 0) p[0] = (bf16_t)a;
+        if (valid > 1) p[1] = (bf16_t)b;
+        if (valid > 2) p[2] = (bf16_t)c;
+        if (valid > 3) p[3] = (bf16_t)d;
+    }
+}

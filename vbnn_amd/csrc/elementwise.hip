@@ -1,0 +1,495 @@
+// elementwise.hip -- the HBM-bound pieces of the VBLinear path: noise fills, weight sampling,
+// operand packing (with transpose), the prior / KL sweeps, KL gradients and the glue modules.
+// All of them are streaming kernels: coalesced 16-byte accesses, grid capped at 2048 blocks
+// with grid-stride loops (cdna_hip_programming.md Guideline 11), reductions as per-block
+// partials in double + a deterministic single-block finish (no float atomics).
+#include "common.h"
+
+static inline int grid_for(int64_t work_items, int per_block) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------- fill_normal
+__global__ __launch_bounds__(256) void k_fill_normal(float* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
+                                                     uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0, float scale) {
+    const int64_t quads = (cols + 3) >> 2;
+    const int64_t total = rows * quads;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t r = t / quads, q = t - r * quads;
+        const vbnn_f32x4 z = vbnn_normal4(seed, stream, layer, draw, (uint32_t)(row0 + r), (uint32_t)q);
+        float* p = out + r * ld + q * 4;
+        const int valid = (int)min((int64_t)4, cols - q * 4);
+        const bool vec = ((ld & 3) == 0) && (((uintptr_t)out & 15u) == 0);
+        store4<float>(p, z.v[0] * scale, z.v[1] * scale, z.v[2] * scale, z.v[3] * scale, valid, vec);
+    }
+}
+
+extern "C" int vbnn_fill_normal(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
+                                uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0, float scale) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && out, "null ctx/out");
+    VBNN_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "shape");
+    VBNN_REQUIRE(stream < 256 && layer < (1u << 24), "stream/layer id range");
+    hipLaunchKernelGGL(k_fill_normal, dim3(grid_for(rows * ((cols + 3) / 4), 256)), dim3(256), 0, ctx->stream, out, rows,
+                       cols, ld, seed, stream, layer, draw, row0, scale);
+    return vbnn_check_launch("k_fill_normal");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- block reduce
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+// sums `v` over the 256 threads of a block; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sh /* >= 4 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---------------------------------------------------------------------------------- compute_prior
+// VBLinear.lua:77-88, one sweep: 8 B read per weight (+ 12 B written when the caches are asked for).
+__global__ __launch_bounds__(256) void k_prior_partial(const float* __restrict__ means, const float* __restrict__ lvars,
+                                                       int64_t W, float* vars, float* stdv, float* mu_sqe,
+                                                       double* partial /* [gridDim.x][2] */) {
+    __shared__ double sh[4];
+    double s1 = 0.0, s2 = 0.0;
+    const int64_t W4 = W >> 2;
+    const bool vec = ((((uintptr_t)means | (uintptr_t)lvars | (uintptr_t)vars | (uintptr_t)stdv | (uintptr_t)mu_sqe) & 15u) == 0);
+    if (vec) {
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < W4; t += (int64_t)gridDim.x * 256) {
+            const f32x4 m = reinterpret_cast<const f32x4*>(means)[t];
+            const f32x4 l = reinterpret_cast<const f32x4*>(lvars)[t];
+            f32x4 v, sd, q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = expf(l[j]); sd[j] = sqrtf(v[j]); q[j] = m[j] * m[j];
+                s1 += (double)(v[j] + q[j]); s2 += (double)l[j];
+            }
+            if (vars) reinterpret_cast<f32x4*>(vars)[t] = v;
+            if (stdv) reinterpret_cast<f32x4*>(stdv)[t] = sd;
+            if (mu_sqe) reinterpret_cast<f32x4*>(mu_sqe)[t] = q;
+        }
+    }
+    const int64_t tail0 = vec ? (W4 << 2) : 0;
+    for (int64_t t = tail0 + (int64_t)blockIdx.x * 256 + threadIdx.x; t < W; t += (int64_t)gridDim.x * 256) {
+        const float v = expf(lvars[t]), sd = sqrtf(v), q = means[t] * means[t];
+        s1 += (double)(v + q); s2 += (double)lvars[t];
+        if (vars) vars[t] = v;
+        if (stdv) stdv[t] = sd;
+        if (mu_sqe) mu_sqe[t] = q;
+    }
+    const double r1 = block_sum(s1, sh);
+    const double r2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = r1; partial[blockIdx.x * 2 + 1] = r2; }
+}
+__global__ __launch_bounds__(256) void k_prior_finish(const double* partial, int nblocks, int64_t W, double* stats) {
+    __shared__ double sh[4];
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) { s1 += partial[b * 2]; s2 += partial[b * 2 + 1]; }
+    const double r1 = block_sum(s1, sh);
+    const double r2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { stats[0] = r1; stats[1] = r2; stats[2] = (1.0 / (double)W) * r1; stats[3] = (double)W; }
+}
+
+extern "C" int vbnn_compute_prior(vbnn_ctx* ctx, const float* means, const float* lvars, int64_t W, float* vars,
+                                  float* stdv, float* mu_sqe, double* stats) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && means && lvars && stats, "null argument");
+    VBNN_REQUIRE(W > 0, "W");
+    const int nb = grid_for(W / 4 + 1, 256);
+    VBNN_REQUIRE((size_t)nb * 2 <= ctx->scratch_doubles, "scratch");
+    hipLaunchKernelGGL(k_prior_partial, dim3(nb), dim3(256), 0, ctx->stream, means, lvars, W, vars, stdv, mu_sqe, ctx->scratch);
+    hipLaunchKernelGGL(k_prior_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->scratch, nb, W, stats);
+    return vbnn_check_launch("k_prior");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- wn_sample
+// VBLinear.lua:49-64: w = means + stdv (.) e
+__global__ __launch_bounds__(256) void k_wn_sample(const float* __restrict__ means, const float* __restrict__ stdv,
+                                                   const float* __restrict__ lvars, float* weight, float* e_out,
+                                                   int64_t O, int64_t I, uint64_t seed, uint32_t layer, uint32_t draw) {
+    const int64_t quads = (I + 3) >> 2;
+    const int64_t total = O * quads;
+    const bool vec = ((I & 3) == 0) &&
+                     ((((uintptr_t)means | (uintptr_t)stdv | (uintptr_t)lvars | (uintptr_t)weight | (uintptr_t)e_out) & 15u) == 0);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t o = t / quads, q = t - o * quads;
+        const vbnn_f32x4 z = vbnn_normal4(seed, VBNN_STREAM_EPS, layer, draw, (uint32_t)o, (uint32_t)q);
+        const int64_t base = o * I + q * 4;
+        const int valid = (int)min((int64_t)4, I - q * 4);
+        float w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < valid) {
+                const float sd = stdv ? stdv[base + j] : sqrtf(expf(lvars[base + j]));
+                const float tmp = sd * z.v[j];            // torch.cmul(stdv, e): a rounded temporary (:59)
+                w[j] = means[base + j] + tmp;
+            } else w[j] = 0.f;
+        }
+        store4<float>(weight + base, w[0], w[1], w[2], w[3], valid, vec);
+        if (e_out) store4<float>(e_out + base, z.v[0], z.v[1], z.v[2], z.v[3], valid, vec);
+    }
+}
+
+extern "C" int vbnn_wn_sample(vbnn_ctx* ctx, const float* means, const float* stdv, const float* lvars, float* weight,
+                              float* e_out, int64_t O, int64_t I, uint64_t seed, uint32_t layer, uint32_t draw) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && means && weight, "null argument");
+    VBNN_REQUIRE(stdv || lvars, "need stdv or lvars");
+    VBNN_REQUIRE(O > 0 && I > 0, "shape");
+    hipLaunchKernelGGL(k_wn_sample, dim3(grid_for(O * ((I + 3) / 4), 256)), dim3(256), 0, ctx->stream, means, stdv, lvars,
+                       weight, e_out, O, I, seed, layer, draw);
+    return vbnn_check_launch("k_wn_sample");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- pack (+ transpose)
+__device__ __forceinline__ float pack_func(int func, float a, float b) {
+    switch (func) {
+        case VBNN_PACK_EXP: return expf(a);
+        case VBNN_PACK_SQUARE: return a * a;
+        case VBNN_PACK_MUL: return a * b;
+        case VBNN_PACK_RELU: return fmaxf(a, 0.f);
+        case VBNN_PACK_RELU_SQUARE: { const float h = fmaxf(a, 0.f); return h * h; }
+        default: return a;
+    }
+}
+// 64 x 64 tile per block; src read row-wise (coalesced), dst written row-wise, dstT written
+// row-wise after a transpose through LDS (65-float pitch: conflict-free column reads).
+// SQUARE-type functions square the value AFTER rounding to T, so that x2 == T(x)^2 exactly as
+// the GEMM epilogues produce it.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack(int func, const float* __restrict__ src, const float* __restrict__ src2,
+                                              int64_t ld_src, int64_t rows, int64_t cols, T* dst, int64_t ld_dst, T* dstT,
+                                              int64_t ld_dstT) {
+    __shared__ float tile[64][65];
+    const int64_t tiles_c = (cols + 63) / 64;
+    const int64_t tiles_r = (rows + 63) / 64;
+    const int64_t ntiles = tiles_c * tiles_r;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // ty in 0..3
+    for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
+        const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
+#pragma unroll 4
+        for (int rr = ty; rr < 64; rr += 4) {
+            const int64_t r = r0 + rr, c = c0 + tx;
+            float v = 0.f;
+            if (r < rows && c < cols) {
+                const float a = src[r * ld_src + c];
+                const float b = src2 ? src2[r * ld_src + c] : 0.f;
+                if (func == VBNN_PACK_SQUARE || func == VBNN_PACK_RELU_SQUARE) {
+                    const float h = (func == VBNN_PACK_RELU_SQUARE) ? fmaxf(a, 0.f) : a;
+                    const float hr = Elt<T>::from(Elt<T>::to(h));
+                    v = hr * hr;
+                } else {
+                    v = pack_func(func, a, b);
+                }
+                if (dst) dst[r * ld_dst + c] = Elt<T>::to(v);
+            }
+            tile[rr][tx] = v;
+        }
+        if (dstT) {
+            __syncthreads();
+#pragma unroll 4
+            for (int cc = ty; cc < 64; cc += 4) {
+                const int64_t c = c0 + cc, r = r0 + tx;
+                if (c < cols && r < rows) dstT[c * ld_dstT + r] = Elt<T>::to(tile[tx][cc]);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int vbnn_pack(vbnn_ctx* ctx, int dtype, int func, const float* src, const float* src2, int64_t ld_src,
+                         int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* dstT, int64_t ld_dstT) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && src, "null argument");
+    VBNN_REQUIRE(dst || dstT, "need dst or dstT");
+    VBNN_REQUIRE(rows > 0 && cols > 0 && ld_src >= cols, "shape");
+    VBNN_REQUIRE(!dst || ld_dst >= cols, "ld_dst");
+    VBNN_REQUIRE(!dstT || ld_dstT >= rows, "ld_dstT");
+    VBNN_REQUIRE(func >= 0 && func <= VBNN_PACK_RELU_SQUARE, "func");
+    VBNN_REQUIRE(func != VBNN_PACK_MUL || src2, "MUL needs src2");
+    const int64_t ntiles = ((rows + 63) / 64) * ((cols + 63) / 64);
+    const int nb = (int)(ntiles < 4096 ? ntiles : 4096);
+    if (dtype == VBNN_F32)
+        hipLaunchKernelGGL(k_pack<float>, dim3(nb), dim3(256), 0, ctx->stream, func, src, src2, ld_src, rows, cols,
+                           (float*)dst, ld_dst, (float*)dstT, ld_dstT);
+    else if (dtype == VBNN_BF16)
+        hipLaunchKernelGGL(k_pack<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, func, src, src2, ld_src, rows, cols,
+                           (bf16_t*)dst, ld_dst, (bf16_t*)dstT, ld_dstT);
+    else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
+    return vbnn_check_launch("k_pack");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- KL gradients
+// VBLinear.lua:90-93
+__global__ __launch_bounds__(256) void k_mugrads(const float* __restrict__ means, const double* __restrict__ stats, float B,
+                                                 float S, float* gradWeight, float* lcg, int64_t W) {
+    const float den = (float)((double)B * stats[2]);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < W; t += (int64_t)gridDim.x * 256) {
+        if (lcg) lcg[t] = (means[t] - 0.0f) / den;
+        if (gradWeight) gradWeight[t] = gradWeight[t] / S;
+    }
+}
+// VBLinear.lua:95-98
+__global__ __launch_bounds__(256) void k_vargrads(const float* __restrict__ lvars, const float* __restrict__ vars,
+                                                  const float* __restrict__ stdv, const double* __restrict__ stats, float B,
+                                                  float S, float* gradSum, float* lcg, int64_t W) {
+    const float inv_vh = (float)(1.0 / stats[2]);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < W; t += (int64_t)gridDim.x * 256) {
+        const float v = vars ? vars[t] : expf(lvars[t]);
+        const float sd = stdv ? stdv[t] : sqrtf(v);
+        if (lcg) { const float a = -(1.0f / v) + inv_vh; lcg[t] = (a / (2.0f * B)) * v; }
+        if (gradSum) gradSum[t] = (gradSum[t] / (2.0f * S)) * sd;
+    }
+}
+
+extern "C" int vbnn_compute_mugrads(vbnn_ctx* ctx, const float* means, const double* stats, float B, float S,
+                                    float* gradWeight, float* lcg, int64_t W) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && means && stats, "null argument");
+    VBNN_REQUIRE(W > 0 && B > 0 && S > 0, "W, B, S");
+    hipLaunchKernelGGL(k_mugrads, dim3(grid_for(W, 256)), dim3(256), 0, ctx->stream, means, stats, B, S, gradWeight, lcg, W);
+    return vbnn_check_launch("k_mugrads");
+    VBNN_API_END
+}
+extern "C" int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, const float* stdv,
+                                     const double* stats, float B, float S, float* gradSum, float* lcg, int64_t W) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && stats, "null argument");
+    VBNN_REQUIRE(lvars || (vars && stdv), "need lvars or vars+stdv");
+    VBNN_REQUIRE(W > 0 && B > 0 && S > 0, "W, B, S");
+    hipLaunchKernelGGL(k_vargrads, dim3(grid_for(W, 256)), dim3(256), 0, ctx->stream, lvars, vars, stdv, stats, B, S, gradSum,
+                       lcg, W);
+    return vbnn_check_launch("k_vargrads");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- calc_lc
+// VBLinear.lua:99-103 + mlp.lua:112 (:sum()).
+__global__ __launch_bounds__(256) void k_lc_partial(const float* __restrict__ means, const float* __restrict__ lvars,
+                                                    const float* __restrict__ vars, const float* __restrict__ mu_sqe,
+                                                    const double* __restrict__ stats, float B, float* lc_elem, int64_t W,
+                                                    double* partial) {
+    __shared__ double sh[4];
+    const double var_hat = stats[2];
+    const float lvh = (float)log(sqrt(var_hat));
+    const float vh = (float)var_hat;
+    const float invB = 1.0f / B;
+    double s = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < W; t += (int64_t)gridDim.x * 256) {
+        const float v = vars ? vars[t] : expf(lvars[t]);
+        const float q = mu_sqe ? mu_sqe[t] : means[t] * means[t];
+        const float first = -logf(sqrtf(v)) + lvh;
+        const float second = (q + (v - vh)) / (2.0f * vh);
+        const float lc = (first + second) * invB;
+        if (lc_elem) lc_elem[t] = lc;
+        s += (double)lc;
+    }
+    const double r = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void k_sum_finish(const double* partial, int nblocks, double* out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[b];
+    const double r = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
+extern "C" int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const float* vars, const float* mu_sqe,
+                            const double* stats, float B, float* lc_elem, double* lc_sum_dev, int64_t W) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && stats && lc_sum_dev, "null argument");
+    VBNN_REQUIRE((means && lvars) || (vars && mu_sqe), "need means+lvars or the cached vars+mu_sqe");
+    VBNN_REQUIRE(W > 0 && B > 0, "W, B");
+    const int nb = grid_for(W, 1024);
+    VBNN_REQUIRE((size_t)nb <= ctx->scratch_doubles, "scratch");
+    hipLaunchKernelGGL(k_lc_partial, dim3(nb), dim3(256), 0, ctx->stream, means, lvars, vars, mu_sqe, stats, B, lc_elem, W, ctx->scratch);
+    hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->scratch, nb, lc_sum_dev);
+    return vbnn_check_launch("k_lc");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- gradBias
+// gradBias[o] (+)= scale * sum_n g[n][o]: a block owns 64 columns, its 4 waves stride the rows.
+__global__ __launch_bounds__(256) void k_col_sum(const float* __restrict__ g, int64_t ld, int64_t N, int64_t O, float scale,
+                                                 int accumulate, float* gradBias) {
+    __shared__ float sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t o = (int64_t)blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (o < O)
+        for (int64_t n = ty; n < N; n += 4) s += g[n * ld + o];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && o < O) {
+        const float tot = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+        const float old = accumulate ? gradBias[o] : 0.f;
+        gradBias[o] = fmaf(scale, tot, old);
+    }
+}
+extern "C" int vbnn_acc_grad_bias(vbnn_ctx* ctx, const float* g, int64_t ld_g, int64_t N, int64_t O, float scale,
+                                  int accumulate, float* gradBias) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && g && gradBias, "null argument");
+    VBNN_REQUIRE(N > 0 && O > 0 && ld_g >= O, "shape");
+    hipLaunchKernelGGL(k_col_sum, dim3((unsigned)((O + 63) / 64)), dim3(256), 0, ctx->stream, g, ld_g, N, O, scale, accumulate,
+                       gradBias);
+    return vbnn_check_launch("k_col_sum");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- ReLU
+__global__ __launch_bounds__(256) void k_relu_fwd(const float* __restrict__ x, float* y, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) y[t] = x[t] > 0.f ? x[t] : 0.f;
+}
+__global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ x, const float* __restrict__ g, float* gx, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) gx[t] = x[t] > 0.f ? g[t] : 0.f;
+}
+extern "C" int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && x && y && n > 0, "argument");
+    hipLaunchKernelGGL(k_relu_fwd, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, x, y, n);
+    return vbnn_check_launch("k_relu_fwd");
+    VBNN_API_END
+}
+extern "C" int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx, int64_t n) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && x && g && gx && n > 0, "argument");
+    hipLaunchKernelGGL(k_relu_bwd, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, x, g, gx, n);
+    return vbnn_check_launch("k_relu_bwd");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- LogSoftMax + ClassNLL
+// one wave per row; C <= 64 * 16.
+__global__ __launch_bounds__(256) void k_logsoftmax_nll(const float* __restrict__ logits, int64_t ld,
+                                                        const int32_t* __restrict__ target, int64_t N, int64_t C, float inv_n,
+                                                        float* out, float* g_logits, double* loss_sum, int32_t* correct) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    double loss_acc = 0.0;
+    int corr_acc = 0;
+    for (int64_t n = wave_global; n < N; n += nwaves) {
+        const float* row = logits + n * ld;
+        float mx = -INFINITY; int arg = 0;
+        for (int64_t c = lane; c < C; c += 64) { const float v = row[c]; if (v > mx) { mx = v; arg = (int)c; } }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float om = __shfl_xor(mx, off, 64);
+            const int oa = __shfl_xor(arg, off, 64);
+            if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }   // first maximum wins (Tensor:max)
+        }
+        double s = 0.0;
+        for (int64_t c = lane; c < C; c += 64) s += exp((double)(row[c] - mx));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float lse = mx + (float)log(s);
+        const int32_t t = min(max(target[n], 0), (int32_t)C - 1);   // clamp: never index out of the row
+        for (int64_t c = lane; c < C; c += 64) {
+            const float o = row[c] - lse;
+            if (out) out[n * C + c] = o;
+            if (g_logits) g_logits[n * C + c] = (expf(o) - (c == t ? 1.0f : 0.0f)) * inv_n;
+        }
+        if (lane == 0) {
+            loss_acc -= (double)(row[t] - lse) * (double)inv_n;
+            corr_acc += (arg == t) ? 1 : 0;
+        }
+    }
+    if (lane == 0) {
+        if (loss_sum && loss_acc != 0.0) atomicAdd(loss_sum, loss_acc);
+        if (correct && corr_acc) atomicAdd(correct, corr_acc);
+    }
+}
+extern "C" int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const int32_t* target, int64_t N,
+                                   int64_t C, float inv_n, float* out, float* g_logits, double* loss_sum_dev,
+                                   int32_t* correct_dev) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && logits && target, "null argument");
+    VBNN_REQUIRE(N > 0 && C > 0 && ld >= C, "shape");
+    hipLaunchKernelGGL(k_logsoftmax_nll, dim3(grid_for(N, 4)), dim3(256), 0, ctx->stream, logits, ld, target, N, C, inv_n, out,
+                       g_logits, loss_sum_dev, correct_dev);
+    return vbnn_check_launch("k_logsoftmax_nll");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- separate criterion modules
+// nn.ClassNLLCriterion (sizeAverage): forward value, backward gradient; nn.LogSoftMax:updateGradInput.
+// Used by the module-level path (mlp.lua:78-80 call order); the fused kernel above is the fast path.
+__global__ __launch_bounds__(256) void k_nll_forward(const float* __restrict__ out, int64_t ld, const int32_t* __restrict__ target,
+                                                     int64_t N, int64_t C, float inv_n, double* loss_sum, int32_t* correct) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    int corr = 0;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+        const float* row = out + n * ld;
+        const int32_t t = min(max(target[n], 0), (int32_t)C - 1);
+        acc -= (double)row[t] * (double)inv_n;
+        if (correct) {
+            int best = 0;
+            for (int c = 1; c < (int)C; ++c) if (row[c] > row[best]) best = c;
+            corr += (best == t) ? 1 : 0;
+        }
+    }
+    const double r = block_sum(acc, sh);
+    if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, r);
+    if (correct && corr) atomicAdd(correct, corr);
+}
+__global__ __launch_bounds__(256) void k_nll_backward(const int32_t* __restrict__ target, int64_t N, int64_t C, float inv_n, float* g) {
+    const int64_t total = N * C;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t n = t / C, c = t - n * C;
+        g[t] = (c == (int64_t)target[n]) ? -inv_n : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void k_logsoftmax_backward(const float* __restrict__ out, const float* __restrict__ g, float* gx,
+                                                             int64_t N, int64_t C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t n = wave_global; n < N; n += (int64_t)gridDim.x * 4) {
+        double s = 0.0;
+        for (int64_t c = lane; c < C; c += 64) s += (double)g[n * C + c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        for (int64_t c = lane; c < C; c += 64) gx[n * C + c] = g[n * C + c] - expf(out[n * C + c]) * (float)s;
+    }
+}
+extern "C" int vbnn_nll_forward(vbnn_ctx* ctx, const float* out, int64_t ld, const int32_t* target, int64_t N, int64_t C,
+                                float inv_n, double* loss_sum_dev, int32_t* correct_dev) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && out && target, "null argument");
+    VBNN_REQUIRE(N > 0 && C > 0 && ld >= C, "shape");
+    hipLaunchKernelGGL(k_nll_forward, dim3(grid_for(N, 256)), dim3(256), 0, ctx->stream, out, ld, target, N, C, inv_n,
+                       loss_sum_dev, correct_dev);
+    return vbnn_check_launch("k_nll_forward");
+    VBNN_API_END
+}
+extern "C" int vbnn_nll_backward(vbnn_ctx* ctx, const int32_t* target, int64_t N, int64_t C, float inv_n, float* g) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && target && g, "null argument");
+    VBNN_REQUIRE(N > 0 && C > 0, "shape");
+    hipLaunchKernelGGL(k_nll_backward, dim3(grid_for(N * C, 256)), dim3(256), 0, ctx->stream, target, N, C, inv_n, g);
+    return vbnn_check_launch("k_nll_backward");
+    VBNN_API_END
+}
+extern "C" int vbnn_logsoftmax_backward(vbnn_ctx* ctx, const float* out, const float* g, float* gx, int64_t N, int64_t C) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && out && g && gx, "null argument");
+    VBNN_REQUIRE(N > 0 && C > 0, "shape");
+    hipLaunchKernelGGL(k_logsoftmax_backward, dim3(grid_for(N, 4)), dim3(256), 0, ctx->stream, out, g, gx, N, C);
+    return vbnn_check_launch("k_logsoftmax_backward");
+    VBNN_API_END
+}

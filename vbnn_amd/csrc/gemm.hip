@@ -1,0 +1,123 @@
+// gemm.hip -- C-ABI entry points of the three VBLinear GEMM families.
+#include "common.h"
+#include "epilogues.h"
+#include "gemm_v1.h"
+#include "gemm_v2.h"
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <typename T, bool DUAL, class Epi>
+static int launch_gemm(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda, const void* B, const void* B2,
+                       int64_t ldb, int64_t M, int64_t N, int64_t K, const Epi& epi) {
+    if (gemm_v2_eligible<T>(M, N, K, lda, ldb))
+        return launch_gemm_v2<T, DUAL, Epi>(ctx->stream, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
+                                            (int)M, (int)N, (int)K, epi);
+    return launch_gemm_v1<T, DUAL, Epi>(ctx->stream, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
+                                        (int)M, (int)N, (int)K, epi);
+}
+
+template <typename T>
+static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
+    EpiFwd<T> e;
+    e.bias = a->bias;
+    e.noise = a->w2 != nullptr;
+    e.seed = a->seed; e.layer = a->layer; e.draw = a->draw; e.row0 = a->row0;
+    e.y = a->y; e.ld_y = a->ld_y; e.y_vec = a->y && aligned16(a->y) && (a->ld_y % 4 == 0);
+    e.r = a->r; e.ld_r = a->ld_r; e.r_vec = a->r && aligned16(a->r) && (a->ld_r % 4 == 0);
+    e.relu = a->relu;
+    e.h = (T*)a->h; e.h2 = (T*)a->h2; e.ld_h = a->ld_h;
+    e.hT = (T*)a->hT; e.h2T = (T*)a->h2T; e.ld_hT = a->ld_hT;
+    e.O = (int)a->O; e.N = (int)a->N;
+    if (a->w2) return launch_gemm<T, true>(ctx, a->w, a->w2, a->ld_w, a->x, a->x2, a->ld_x, a->O, a->N, a->I, e);
+    return launch_gemm<T, false>(ctx, a->w, nullptr, a->ld_w, a->x, nullptr, a->ld_x, a->O, a->N, a->I, e);
+}
+
+template <typename T>
+static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
+    EpiDx<T> e;
+    e.dual = a->w2T != nullptr;
+    e.x = (const T*)a->x; e.ld_x = a->ld_x;
+    e.gx = a->gx; e.ld_gx = a->ld_gx; e.gx_vec = a->gx && aligned16(a->gx) && (a->ld_gx % 4 == 0);
+    e.relu_mask = a->relu_mask;
+    e.r_prev = a->r_prev; e.ld_r_prev = a->ld_r_prev;
+    e.g_prev = (T*)a->g_prev; e.gv_prev = (T*)a->gv_prev; e.ld_gp = a->ld_gp;
+    e.gT_prev = (T*)a->gT_prev; e.gvT_prev = (T*)a->gvT_prev; e.ld_gpT = a->ld_gpT;
+    e.I = (int)a->I; e.N = (int)a->N;
+    if (a->w2T) return launch_gemm<T, true>(ctx, a->wT, a->w2T, a->ld_wT, a->g, a->gv, a->ld_g, a->I, a->N, a->O, e);
+    return launch_gemm<T, false>(ctx, a->wT, nullptr, a->ld_wT, a->g, nullptr, a->ld_g, a->I, a->N, a->O, e);
+}
+
+template <typename T>
+static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
+    EpiDw e;
+    e.lrt = a->x2T != nullptr;
+    e.scale = a->scale; e.accumulate = a->accumulate;
+    e.gradWeight = a->gradWeight; e.gradSum = a->gradSum;
+    e.vec = (a->I % 4 == 0) && (!a->gradWeight || aligned16(a->gradWeight)) && (!a->gradSum || aligned16(a->gradSum)) &&
+            (!a->grad_mu || aligned16(a->grad_mu)) && (!a->grad_lv || aligned16(a->grad_lv));
+    e.seed = a->seed; e.layer = a->layer; e.draw = a->draw;
+    e.lvars = a->lvars;
+    e.grad_mu = a->grad_mu; e.grad_lv = a->grad_lv;
+    e.means = a->means; e.stats = a->stats; e.B = a->B; e.S = a->S; e.kl_scale = a->kl_scale;
+    e.I = (int)a->I; e.O = (int)a->O;
+    if (a->x2T) return launch_gemm<T, true>(ctx, a->xT, a->x2T, a->ld_n, a->gT, a->gvT, a->ld_n, a->I, a->O, a->N, e);
+    return launch_gemm<T, false>(ctx, a->xT, nullptr, a->ld_n, a->gT, nullptr, a->ld_n, a->I, a->O, a->N, e);
+}
+
+extern "C" int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && a, "null ctx/args");
+    VBNN_REQUIRE(a->w && a->x, "w and x are required");
+    VBNN_REQUIRE((a->w2 == nullptr) == (a->x2 == nullptr), "w2 and x2 go together (LRT pair)");
+    VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
+    VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
+    VBNN_REQUIRE(!a->h2 || a->h, "h2 needs h");
+    VBNN_REQUIRE(!a->h2T || a->hT, "h2T needs hT");
+    VBNN_REQUIRE(!a->h || (a->ld_h >= a->O && a->ld_h % 4 == 0), "ld_h");
+    VBNN_REQUIRE(!a->hT || a->ld_hT >= a->N, "ld_hT");
+    VBNN_REQUIRE(!a->y || a->ld_y >= a->O, "ld_y");
+    VBNN_REQUIRE(!a->r || a->ld_r >= a->O, "ld_r");
+    if (dtype == VBNN_F32) return forward_t<float>(ctx, a);
+    if (dtype == VBNN_BF16) return forward_t<bf16_t>(ctx, a);
+    vbnn_set_error("unsupported dtype %d", dtype);
+    return VBNN_ERR_UNSUPPORTED;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && a, "null ctx/args");
+    VBNN_REQUIRE(a->wT && a->g, "wT and g are required");
+    VBNN_REQUIRE((a->w2T == nullptr) == (a->gv == nullptr), "w2T and gv go together (LRT pair)");
+    VBNN_REQUIRE(!a->w2T || a->x, "LRT gradInput needs the layer input x");
+    VBNN_REQUIRE(!a->relu_mask || a->x, "relu_mask needs the layer input x");
+    VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
+    VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
+    VBNN_REQUIRE(!a->x || a->ld_x >= a->I, "ld_x");
+    VBNN_REQUIRE(!a->gx || a->ld_gx >= a->I, "ld_gx");
+    VBNN_REQUIRE(!a->gv_prev || a->g_prev, "gv_prev needs g_prev");
+    VBNN_REQUIRE(!a->g_prev || (a->ld_gp >= a->I && a->ld_gp % 4 == 0), "ld_gp");
+    VBNN_REQUIRE(!a->gT_prev || a->ld_gpT >= a->N, "ld_gpT");
+    if (dtype == VBNN_F32) return grad_input_t<float>(ctx, a);
+    if (dtype == VBNN_BF16) return grad_input_t<bf16_t>(ctx, a);
+    vbnn_set_error("unsupported dtype %d", dtype);
+    return VBNN_ERR_UNSUPPORTED;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && a, "null ctx/args");
+    VBNN_REQUIRE(a->xT && a->gT, "xT and gT are required");
+    VBNN_REQUIRE((a->x2T == nullptr) == (a->gvT == nullptr), "x2T and gvT go together (LRT pair)");
+    VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
+    VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
+    VBNN_REQUIRE(!(a->x2T && (a->gradSum || a->grad_lv)) || a->lvars, "LRT gradSum/grad_lv need lvars");
+    VBNN_REQUIRE(!(a->grad_mu || a->grad_lv) || (a->means && a->lvars && a->stats && a->B > 0 && a->S > 0),
+                 "fused total gradients need means, lvars, stats, B, S");
+    if (dtype == VBNN_F32) return acc_grad_t<float>(ctx, a);
+    if (dtype == VBNN_BF16) return acc_grad_t<bf16_t>(ctx, a);
+    vbnn_set_error("unsupported dtype %d", dtype);
+    return VBNN_ERR_UNSUPPORTED;
+    VBNN_API_END
+}

@@ -1,0 +1,154 @@
+// gemm_v1.h -- register-staged, LDS-tiled MFMA GEMM  C[m][n] = sum_k A[m][k] * Bt[n][k]
+// (optionally a second accumulator from A2 / Bt2 sharing the tile) with a fused epilogue.
+//
+// This is the general kernel: any M, N (row-clamped loads, masked epilogue), element type
+// f32 (v_mfma_f32_16x16x4_f32, exact fp32 products and sums) or bf16
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate). It is THE kernel of the fp32 parity
+// configuration and the fallback of the bf16 path for shapes the pipelined kernel
+// (gemm_v2.h) does not take.
+//
+// Geometry: 256 threads = 4 waves (2 x 2), block tile (32*WR) x (32*WR), WR = 2 or 4 MFMA
+// tiles per wave per dimension, K step = 64 bytes of K per row (16 f32 / 32 bf16).
+// Operands are "packed": K contiguous, leading dimension padded to VBNN_KPAD elements with
+// zeros, so the K loop needs no tail handling.
+#pragma once
+#include "common.h"
+
+template <typename T> struct Frag;
+template <> struct Frag<float> { typedef f32x4 type; };
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma_step(const typename Frag<T>::type& a, const typename Frag<T>::type& b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma_step<float>(const f32x4& a, const f32x4& b, f32x4 c) {
+    // lane (i = l&15, q = l>>4) holds k = 4q..4q+3 of its row; MFMA step j contracts the four
+    // k values {4q + j}: a permutation of k inside the 16-wide K step, identical for A and B.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+template <>
+__device__ __forceinline__ f32x4 mfma_step<bf16_t>(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+constexpr int V1_ROW_BYTES = 80;   // 64 B of K + 16 B pad: conflict-free ds_read_b128 down a column
+
+template <typename T, bool DUAL, int WR, class Epi>
+__global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const T* __restrict__ A2, int64_t lda,
+                                                  const T* __restrict__ B, const T* __restrict__ B2, int64_t ldb,
+                                                  int M, int N, int Kp, Epi epi) {
+    constexpr int BT = 32 * WR;                 // block tile rows (M and N)
+    constexpr int KE = 64 / (int)sizeof(T);     // K elements per step
+    constexpr int CE = 16 / (int)sizeof(T);     // elements per 16-byte chunk
+    constexpr int CHUNKS = BT * 4;              // 16-byte chunks per operand tile
+    constexpr int CPT = CHUNKS / 256;           // chunks per thread per operand tile (1 or 2)
+    constexpr int NOP = DUAL ? 4 : 2;
+    typedef typename Frag<T>::type frag_t;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NOP * BT * V1_ROW_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BT, n0 = blockIdx.y * BT;
+
+    const T* src[4] = {A, B, A2, B2};
+    uint4 stage[NOP][CPT];
+    const T* gptr[NOP][CPT];
+    int lds_off[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int chunk = tid + c * 256;
+        const int row = chunk >> 2, kc = chunk & 3;
+        lds_off[c] = row * V1_ROW_BYTES + kc * 16;
+#pragma unroll
+        for (int op = 0; op < NOP; ++op) {
+            const bool isA = (op & 1) == 0;
+            const int grow = isA ? min(m0 + row, M - 1) : min(n0 + row, N - 1);
+            gptr[op][c] = src[op] + (int64_t)grow * (isA ? lda : ldb) + kc * CE;
+        }
+    }
+
+    f32x4 acc1[WR][WR], acc2[WR][WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WR; ++j) { acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nk = Kp / KE;
+#pragma unroll
+    for (int op = 0; op < NOP; ++op)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) stage[op][c] = *reinterpret_cast<const uint4*>(gptr[op][c]);
+
+    const int a_row = (wm * WR * 16 + (lane & 15)) * V1_ROW_BYTES + (lane >> 4) * 16;
+    const int b_row = (wn * WR * 16 + (lane & 15)) * V1_ROW_BYTES + (lane >> 4) * 16;
+
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int op = 0; op < NOP; ++op)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                *reinterpret_cast<uint4*>(lds + op * BT * V1_ROW_BYTES + lds_off[c]) = stage[op][c];
+        __syncthreads();
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int op = 0; op < NOP; ++op)
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+                    stage[op][c] = *reinterpret_cast<const uint4*>(gptr[op][c] + (int64_t)(kt + 1) * KE);
+        }
+        frag_t af[WR], bf[WR];
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            af[i] = *reinterpret_cast<const frag_t*>(lds + 0 * BT * V1_ROW_BYTES + a_row + i * 16 * V1_ROW_BYTES);
+            bf[i] = *reinterpret_cast<const frag_t*>(lds + 1 * BT * V1_ROW_BYTES + b_row + i * 16 * V1_ROW_BYTES);
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+            for (int j = 0; j < WR; ++j) acc1[i][j] = mfma_step<T>(af[i], bf[j], acc1[i][j]);
+        if (DUAL) {
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                af[i] = *reinterpret_cast<const frag_t*>(lds + 2 * BT * V1_ROW_BYTES + a_row + i * 16 * V1_ROW_BYTES);
+                bf[i] = *reinterpret_cast<const frag_t*>(lds + 3 * BT * V1_ROW_BYTES + b_row + i * 16 * V1_ROW_BYTES);
+            }
+#pragma unroll
+            for (int i = 0; i < WR; ++i)
+#pragma unroll
+                for (int j = 0; j < WR; ++j) acc2[i][j] = mfma_step<T>(af[i], bf[j], acc2[i][j]);
+        }
+        __syncthreads();
+    }
+
+    const int em = m0 + wm * WR * 16 + (lane >> 4) * 4;
+    const int en = n0 + wn * WR * 16 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < WR; ++j) epi(em + i * 16, en + j * 16, acc1[i][j], acc2[i][j]);
+}
+
+template <typename T, bool DUAL, class Epi>
+static int launch_gemm_v1(hipStream_t stream, const T* A, const T* A2, int64_t lda, const T* B, const T* B2,
+                          int64_t ldb, int M, int N, int K, const Epi& epi) {
+    const int KE = 64 / (int)sizeof(T);
+    const int Kp = (K + KE - 1) / KE * KE;
+    if (lda < Kp || ldb < Kp) {
+        vbnn_set_error("packed leading dimension too small: lda=%lld ldb=%lld need >= %d", (long long)lda, (long long)ldb, Kp);
+        return VBNN_ERR_INVALID;
+    }
+    const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (blocks128 >= 128) {
+        dim3 grid((M + 127) / 128, (N + 127) / 128);
+        hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 4, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+    } else {
+        dim3 grid((M + 63) / 64, (N + 63) / 64);
+        hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 2, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+    }
+    return vbnn_check_launch("gemm_nt_v1");
+}
