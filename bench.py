@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- VBLinear fwd+bwd samples/sec on MI355X (BASELINE.json's metric).
+
+A step = one pass of the hot path over one synthetic minibatch, exactly main.lua:28-37 with S = 1:
+    resetGradients -> (compute_prior + operand packing) -> sample -> run (forward of every VB layer,
+    final Linear, LogSoftMax + ClassNLL, backward with accGradParameters incl. the KL-gradient
+    epilogue) -> all-reduce of the gradient arena when N > 1.
+The optimiser update is excluded. Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config wide|small]
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[2]/[3]: the config the metric is quoted on
+    "wide": dict(input_size=784, hidden=[4096, 4096], n_classes=10, batch=4096, dtype="bf16",
+                 name="784-4096-4096-10 VBLinear MLP, batch 4096 per GPU, LRT, S=1"),
+    # BASELINE.json configs[1]: the fp32 numerics configuration (launch-bound)
+    "small": dict(input_size=784, hidden=[400, 400], n_classes=10, batch=256, dtype="f32",
+                  name="784-400-400-10 VBLinear MLP, batch 256 per GPU, LRT, S=1"),
+}
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def algorithmic_flops_per_sample(sizes, n_classes):
+    """per VB layer 4IO fwd + 4IO param grads + 4IO input grads (none for layer 1);
+    final Linear 6IO. Elementwise / RNG / KL flops are not counted."""
+    f = 0
+    for li in range(len(sizes) - 1):
+        io = sizes[li] * sizes[li + 1]
+        f += 8 * io if li == 0 else 12 * io
+    f += 6 * sizes[-1] * n_classes
+    return f
+
+
+def time_kernel(fn, reps, torch):
+    """Average duration (ms) of `fn`'s launches, HIP events on the stream the kernels run on."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def dominant_kernel_roofline(eng, N, torch):
+    """Time the three dual-GEMM families of the widest VB layer in isolation and report the slowest
+    one against the MFMA roofline. Algorithmic flops per launch: 2 GEMMs x 2*N*I*O."""
+    import ctypes as C
+    from vbnn_amd import _lib as L
+    lib, ctx, code = L.lib(), eng.ctx.h, eng.code
+    li = max(range(len(eng.vb)), key=lambda k: eng.vb[k].I * eng.vb[k].O)
+    v = eng.vb[li]
+    flops = 2 * 2.0 * N * v.I * v.O
+
+    def fwd():
+        a = eng._fwd_args(li, N, 0)
+        L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
+
+    def dw():
+        d = eng._dw_args(li, N, 0)
+        L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+
+    kernels = {"forward(dual GEMM + LRT epilogue)": fwd, "accGradParameters(dual GEMM + KL epilogue)": dw}
+    if li > 0:
+        def dx():
+            a = eng._dx_args(li, N)
+            L.check(lib.vbnn_grad_input(ctx, code, C.byref(a)))
+        kernels["updateGradInput(dual GEMM + ReLU/dv epilogue)"] = dx
+    res = {k: time_kernel(fn, 10, torch) for k, fn in kernels.items()}
+    name = max(res, key=res.get)
+    return name, res[name], flops, {k: round(v_, 4) for k, v_ in res.items()}
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """The reference's op sequence on the host cores (oracle/ref_numpy.py), bounded sample."""
+    import numpy as np
+    from oracle.ref_numpy import ReferenceCpuMLP, blas_threads
+    N = cfg["batch"]
+    net = ReferenceCpuMLP(cfg["input_size"], cfg["hidden"], cfg["n_classes"])
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((N, cfg["input_size"])).astype(np.float32)
+    t = rs.randint(0, cfg["n_classes"], N)
+    net.step(x, t)                                   # warm-up (BLAS thread pool, page faults)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        net.step(x, t)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s * 0.6 or steps >= 50:
+            break
+    return dict(value=round(N * steps / el, 1), unit="samples/s", cores=blas_threads(), kind="port",
+                sample=f"{steps} full steps (batch {N}) of the same MLP, weight-noise op sequence of VBLinear.lua "
+                       f"on NumPy/OpenBLAS sgemm + MT19937 Gaussian fill, {el:.1f} s; Torch7 itself cannot run here")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="wide", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="lrt", choices=["lrt", "wn"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vbnn_amd import _lib as L
+    from vbnn_amd.engine import FusedMLP
+    from vbnn_amd.nn import fill_normal
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (WORLD_SIZE={world})",
+              file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X: no HIP device is visible and there is no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+    L.lib()                                               # fail loudly if the HIP extension is missing
+
+    cfg = CONFIGS[args.config]
+    N = cfg["batch"]
+    opt = dict(var_init=1e-3, B=1e6, S=1, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
+               hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True)
+    eng = FusedMLP(opt, world_size=world, rank=rank)
+    # synthetic minibatch, resident in HBM: x ~ N(0,1) addressed by GLOBAL row, targets uniform in 0..9
+    x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
+    fill_normal(x, 3, L.STREAM_DATA, 0, 0, row0=rank * N)
+    t = ((torch.arange(N, device="cuda", dtype=torch.int64) + rank * N) * 2654435761 % 10).to(torch.int32)
+
+    def step():
+        eng.resetGradients()
+        eng.prepare()
+        eng.sample()
+        eng.run(x, t)
+        eng.finish()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    loss, correct = eng.loss_and_accuracy()
+
+    if rank == 0:
+        sizes = [cfg["input_size"]] + cfg["hidden"]
+        fps = algorithmic_flops_per_sample(sizes, cfg["n_classes"])
+        ms = el / args.steps * 1e3
+        peak = PEAK_TFLOPS[cfg["dtype"]]
+        kname, kms, kflops, kall = dominant_kernel_roofline(eng, N, torch)
+        achieved = kflops / (kms * 1e-3) / 1e12
+        out = {
+            "metric": "VBLinear fwd+bwd samples/sec", "value": round(N * world * args.steps / el, 1),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["name"], "mode": args.mode, "global_batch": N * world,
+                       "parallelism": f"dp{world}", "flop_per_sample": fps,
+                       "step_tflops": round(fps * N / (ms * 1e-3) / 1e12, 2),
+                       "step_frac_of_mfma_peak": round(fps * N / (ms * 1e-3) / 1e12 / peak, 4),
+                       "loss": round(loss, 5)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None, "kernel": kname,
+                         "kernel_ms": round(kms, 4), "flop_per_launch": kflops, "all_kernels_ms": kall},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

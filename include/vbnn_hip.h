@@ -45,7 +45,8 @@ typedef struct vbnn_ctx vbnn_ctx;
 int vbnn_abi_version(void);
 const char* vbnn_last_error(void);
 
-/* context = (device, stream). stream == NULL: the library creates its own. */
+/* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
+ * (which is also what PyTorch-ROCm's default stream is, so the two stay ordered). */
 int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);
 int vbnn_ctx_destroy(vbnn_ctx* ctx);
 int vbnn_ctx_set_stream(vbnn_ctx* ctx, void* hip_stream);
@@ -163,9 +164,17 @@ typedef struct vbnn_dw_args {
 /* accGradParameters (VBLinear.lua:112-118), one GEMM instead of the reference's two. */
 int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
 
-/* gradBias += scale * sum_n g[n][o]  (the parent call at VBLinear.lua:113). g is N x O f32. */
-int vbnn_acc_grad_bias(vbnn_ctx* ctx, const float* g, int64_t ld_g, int64_t N, int64_t O,
+/* gradBias += scale * sum_n g[n][o]  (the parent call at VBLinear.lua:113). g is N x ld_g of
+ * `dtype` (F32: the module's gradOutput; BF16: a packed operand of the fused path). */
+int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O,
                        float scale, int accumulate, float* gradBias);
+
+/* Per-step parameter sweep of the fused path: one read of means/lvars writes the packed GEMM
+ * shadows mu_s, var_s = exp(lvars) (O x ld_w) and, if asked, their transposes (I x ld_wT), and the
+ * statistics of VBLinear:compute_prior (VBLinear.lua:77-88) into stats[0..3] as vbnn_compute_prior. */
+int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, const float* lvars, int64_t O, int64_t I,
+                    void* mu_s, void* var_s, int64_t ld_w, void* muT_s, void* varT_s, int64_t ld_wT,
+                    double* stats);
 
 /* ---- KL ("LC") terms ------------------------------------------------------------------------ */
 

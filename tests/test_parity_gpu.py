@@ -1,0 +1,373 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs. Tolerances are stated per test. fp32 GEMM outputs: |d| <= 2e-6 * sum_k|a_k b_k| + 1e-7
+(fp32 MFMA is an exact fma chain; the K order inside a 16-wide step is permuted).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+SEED = 3
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+def gemm_tol(absprod, rel=2e-6, abs_=1e-7):
+    return rel * absprod + abs_
+
+
+def assert_close(got, want, tol, what):
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    bad = err > tol
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} off, max err {err.max():.3e} (tol at worst {np.max(tol):.3e})"
+
+
+@pytest.fixture(scope="module")
+def nnmod():
+    from vbnn_amd import nn
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return nn
+
+
+def opt_for(mode, dtype="f32", **kw):
+    o = dict(var_init=1e-3, mu_init=1, B=1e6, S=1, mode=mode, dtype=dtype, seed=SEED, keep_e=True,
+             input_size=784, hidden=[400, 400], n_classes=10, type="vb", testSamples=2)
+    o.update(kw)
+    return o
+
+
+# ------------------------------------------------------------------------------------------- RNG
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 7), (5, 64), (33, 130)])
+def test_fill_normal_bit_exact(nnmod, oracle, rows, cols):
+    """device Philox4x32-10 + Box-Muller == oracle, bit for bit (include/vbnn_philox.h)."""
+    from vbnn_amd import _lib as L
+    for stream, layer, draw, row0 in [(L.STREAM_EPS, 0, 1, 0), (L.STREAM_ZETA, 2, 7, 1000)]:
+        t = torch.empty(rows, cols, dtype=torch.float32, device="cuda")
+        nnmod.fill_normal(t, SEED, stream, layer, draw, row0=row0)
+        want = oracle.fill_normal(rows, cols, SEED, stream, layer, draw, row0)
+        got = host(t)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------- prior / KL
+@pytest.mark.parametrize("O,I", [(5, 7), (48, 64), (400, 784)])
+def test_compute_prior_and_kl(nnmod, oracle, O, I):
+    opt = opt_for("wn")
+    m = nnmod.VBLinear(I, O, opt)
+    rng = np.random.default_rng(0)
+    means = rng.normal(0, 0.05, (O, I)).astype(np.float32)
+    lvars = rng.normal(np.log(1e-3), 0.5, (O, I)).astype(np.float32)
+    m.means.copy_(dev(means)); m.lvars.copy_(dev(lvars))
+    _, var_hat = m.compute_prior()
+    vars_, stdv, mu_sqe, vh = oracle.compute_prior(means, lvars)
+    assert abs(var_hat - vh) <= 1e-6 * vh
+    np.testing.assert_allclose(host(m.vars), vars_, rtol=1e-5, atol=0)
+    np.testing.assert_allclose(host(m.stdv), stdv, rtol=1e-5, atol=0)
+    np.testing.assert_allclose(host(m.mu_sqe), mu_sqe, rtol=1e-6, atol=0)
+    # calc_lc (VBLinear.lua:99-103) on the cached statistics
+    lc, lc_elem = m.calc_lc(opt, elementwise=True)
+    want_sum, want_elem = oracle.calc_lc(vars_, mu_sqe, vh, opt["B"], want_elem=True)
+    np.testing.assert_allclose(host(lc_elem), want_elem, rtol=2e-4, atol=1e-11)
+    assert abs(float(lc.item()) - want_sum) <= 2e-4 * abs(want_sum) + 1e-9
+    # compute_mugrads / compute_vargrads (VBLinear.lua:90-98), in-place semantics included
+    gw = rng.normal(0, 1, (O, I)).astype(np.float32)
+    gs = rng.normal(0, 1, (O, I)).astype(np.float32)
+    m.gradWeight.copy_(dev(gw)); m.gradSum.copy_(dev(gs))
+    o2 = dict(opt, S=30)
+    mle, mlc = m.compute_mugrads(o2)
+    vle, vlc = m.compute_vargrads(o2)
+    w_mle, w_mlc = oracle.compute_mugrads(means, vh, o2["B"], o2["S"], gw.copy())
+    w_vle, w_vlc = oracle.compute_vargrads(vars_, stdv, vh, o2["B"], o2["S"], gs.copy())
+    np.testing.assert_allclose(host(mle), w_mle, rtol=1e-6, atol=0)
+    np.testing.assert_allclose(host(mlc), w_mlc, rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(host(vle), w_vle, rtol=1e-5, atol=0)
+    np.testing.assert_allclose(host(vlc), w_vlc, rtol=1e-4, atol=1e-11)
+    assert mle.data_ptr() == m.gradWeight.data_ptr() and vle.data_ptr() == m.gradSum.data_ptr()
+
+
+def test_fresh_layer_known_answers(nnmod):
+    """SURVEY 8c KAT 1-2: mu_init = 0 => var_hat == var_init, LC == 0, KL grads == 0; msr_init => 2/I."""
+    opt = opt_for("wn", mu_init=0)
+    m = nnmod.VBLinear(64, 48, opt)
+    assert abs(m.var_hat - 1e-3) <= 1e-9
+    lc = float(m.calc_lc(opt).item())
+    assert abs(lc) < 1e-9
+    _, mlc = m.compute_mugrads(opt)
+    _, vlc = m.compute_vargrads(opt)
+    assert float(mlc.abs().max()) == 0.0
+    assert float(vlc.abs().max()) < 1e-12
+    m2 = nnmod.VBLinear(50, 20, opt_for("wn", mu_init=0, msr_init=True))
+    assert abs(m2.var_init - 2.0 / 50) < 1e-12
+    np.testing.assert_allclose(host(m2.lvars), np.full((20, 50), np.log(2.0 / 50), np.float32), rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- single layer
+def _layer_pair(nnmod, oracle, mode, I, O, dtype="f32"):
+    opt = opt_for(mode, dtype)
+    m = nnmod.VBLinear(I, O, opt)
+    om = oracle.OracleVBLinear(I, O, opt, layer_id=0)
+    rng = np.random.default_rng(1)
+    means = rng.normal(0, np.sqrt(2.0 / I), (O, I)).astype(np.float32)
+    lvars = rng.normal(np.log(1e-3), 0.3, (O, I)).astype(np.float32)
+    bias = rng.normal(0, 0.1, O).astype(np.float32)
+    m.means.copy_(dev(means)); m.lvars.copy_(dev(lvars)); m.bias.copy_(dev(bias))
+    om.means[:] = means; om.lvars[:] = lvars; om.bias[:] = bias
+    m.compute_prior(); om.compute_prior()
+    return opt, m, om
+
+
+@pytest.mark.parametrize("N,I,O", [(1, 4, 4), (3, 7, 5), (32, 64, 48), (100, 130, 70), (256, 784, 400)])
+@pytest.mark.parametrize("mode", ["wn", "lrt"])
+def test_layer_forward_backward_f32(nnmod, oracle, mode, N, I, O):
+    """T1 (wn) / T2 (lrt): output, gradInput, gradWeight, gradSum, gradBias sample-exact vs the oracle."""
+    opt, m, om = _layer_pair(nnmod, oracle, mode, I, O)
+    rng = np.random.default_rng(2)
+    x = rng.normal(0, 1, (N, I)).astype(np.float32)
+    x[0, :] = 0.0 if N > 1 else x[0, :]          # a zero row: v == 0 -> r must be 0, not NaN
+    g = rng.normal(0, 1.0 / N, (N, O)).astype(np.float32)
+    for draw in range(2):                         # two draws: accumulation across draws (main.lua:32-37)
+        m.sample(); om.sample()
+        if mode == "wn":
+            np.testing.assert_allclose(host(m.weight), om.weight, rtol=0, atol=2e-7 * np.abs(om.weight).max())
+            assert np.array_equal(host(m.e).view(np.uint32), om.e.view(np.uint32))
+        y = m.updateOutput(dev(x))
+        want_y = om.updateOutput(x)
+        w_eff = np.abs(om.weight) if mode == "wn" else np.abs(om.means)
+        absprod = np.abs(x) @ w_eff.T + np.abs(om.bias)
+        if mode == "lrt":
+            absprod = absprod + np.abs(np.sqrt(om.v) * oracle.fill_normal(N, O, SEED, 2, 0, om.draw, 0))
+        assert_close(host(y), want_y, gemm_tol(absprod, 4e-6), f"output draw {draw}")
+        if mode == "lrt":
+            assert np.isfinite(host(m.r)).all()
+            np.testing.assert_allclose(host(m.r), om.r, rtol=2e-5, atol=1e-6)
+        gx = m.backward(dev(x), dev(g), 0.5)
+        want_gx = om.backward(x, g, 0.5)
+        if mode == "wn":
+            absg = np.abs(g) @ np.abs(om.weight)
+        else:
+            absg = np.abs(g) @ np.abs(om.means) + 2 * np.abs(x) * (np.abs(g * om.r) @ om.vars)
+        assert_close(host(gx), want_gx, gemm_tol(absg, 1e-5, 1e-7), f"gradInput draw {draw}")
+    absw = np.abs(g).T @ np.abs(x)
+    assert_close(host(m.gradWeight), om.gradWeight, 2 * gemm_tol(absw, 4e-6), "gradWeight")
+    np.testing.assert_allclose(host(m.gradBias), om.gradBias, rtol=1e-5, atol=1e-6)
+    if mode == "wn":
+        asum = 2 * (absw * 5.0)
+    else:
+        asum = 2 * 2 * (np.abs(g * om.r).T @ (x * x)) * om.stdv
+    assert_close(host(m.gradSum), om.gradSum, gemm_tol(asum, 2e-5, 1e-6), "gradSum")
+
+
+def test_map_forward_equals_plain_linear(nnmod, oracle):
+    """SURVEY 8c KAT 3: clamp_to_map then forward == Linear with weight = means (both modes)."""
+    for mode in ("wn", "lrt"):
+        opt, m, om = _layer_pair(nnmod, oracle, mode, 64, 48)
+        x = np.random.default_rng(3).normal(0, 1, (16, 64)).astype(np.float32)
+        m.clamp_to_map()
+        y = host(m.updateOutput(dev(x)))
+        want = oracle.linear_forward(x, om.means, om.bias)
+        assert_close(y, want, gemm_tol(np.abs(x) @ np.abs(om.means).T + 1.0, 4e-6), "MAP output")
+
+
+def test_lrt_forward_moments(nnmod, oracle):
+    """SURVEY 8c KAT 8 (statistical, fixed seeds): over draws, LRT y has mean x mu^T + b and variance
+    (x.x)(sigma^2)^T. 400 draws of a 64 x 32 output block: the mean of z is within 5 sigma / sqrt(n)."""
+    opt, m, om = _layer_pair(nnmod, oracle, "lrt", 64, 32)
+    x = np.random.default_rng(4).normal(0, 1, (64, 64)).astype(np.float32)
+    mean_want = oracle.linear_forward(x, om.means, om.bias)
+    var_want = (x * x) @ om.vars.T
+    zs = []
+    for _ in range(400):
+        m.sample()
+        zs.append((host(m.updateOutput(dev(x))) - mean_want) / np.sqrt(var_want))
+    zs = np.stack(zs)
+    assert abs(zs.mean()) < 5.0 / np.sqrt(zs.size)
+    assert abs(zs.var() - 1.0) < 5.0 * np.sqrt(2.0 / zs.size)
+    assert np.abs(zs.mean(axis=0)).max() < 6.0 / np.sqrt(400)
+
+
+def test_lrt_rows_independent_of_sharding(nnmod, oracle):
+    """Data-parallel invariance: rows [r0, r0+n) computed with row0 = r0 equal the same rows of the full batch."""
+    opt, m, om = _layer_pair(nnmod, oracle, "lrt", 64, 48)
+    x = np.random.default_rng(5).normal(0, 1, (32, 64)).astype(np.float32)
+    m.sample()
+    full = host(m.updateOutput(dev(x))).copy()
+    m.row0 = 16
+    part = host(m.updateOutput(dev(x[16:]))).copy()
+    m.row0 = 0
+    assert np.array_equal(full[16:], part)
+
+
+# ------------------------------------------------------------------------------------------- whole MLP
+@pytest.mark.parametrize("mode", ["wn", "lrt"])
+def test_mlp_step_matches_oracle_f32(nnmod, oracle, mode):
+    """BASELINE config 2: 784-400-400-10, batch 256, fp32, fixed RNG counter. mlp.lua call order:
+    resetGradients, S x (sample, run), then the KL readout."""
+    from vbnn_amd import mlp
+    opt = opt_for(mode, S=2)
+    net = mlp.buildModel(opt)
+    onet = oracle.OracleMLP(opt)
+    # identical parameters: take the oracle's (Philox-initialised) ones; means <- He weights so the net is not degenerate
+    for k, i in enumerate(net.vb_indices):
+        mod, om = net.model.get(i), onet.vb[k]
+        np.testing.assert_array_equal(host(mod.weight).view(np.uint32), om.weight.view(np.uint32))
+        om.means[:] = om.weight
+        mod.means.copy_(mod.weight)
+        mod.compute_prior(); om.compute_prior()
+    last = net.model.get(2 * (len(opt["hidden"]) + 1))
+    np.testing.assert_array_equal(host(last.weight).view(np.uint32), onet.last.weight.view(np.uint32))
+    N = 256
+    x = oracle.fill_normal(N, 784, SEED, 4, 0, 0)
+    t = (np.arange(N) * 7 % 10).astype(np.int32)
+    net.resetGradients(); onet.resetGradients()
+    for s in range(opt["S"]):
+        net.sample(); onet.sample()
+        err, acc = net.run(dev(x.reshape(N, 1, 28, 28)), dev(t))
+        werr, wacc = onet.run(x.reshape(N, 1, 28, 28), t)
+        assert abs(err - werr) <= 2e-5 * abs(werr) + 1e-6, (err, werr)
+        assert abs(acc - wacc) <= 100.0 * 2 / N
+        np.testing.assert_allclose(host(net.model.output), onet.outputs, rtol=0, atol=5e-5)
+    for k, i in enumerate(net.vb_indices):
+        mod, om = net.model.get(i), onet.vb[k]
+        scale = np.abs(om.gradWeight).max()
+        np.testing.assert_allclose(host(mod.gradWeight), om.gradWeight, rtol=0, atol=2e-5 * scale + 1e-9)
+        np.testing.assert_allclose(host(mod.gradBias), om.gradBias, rtol=0, atol=2e-5 * np.abs(om.gradBias).max() + 1e-9)
+        sscale = np.abs(om.gradSum).max()
+        np.testing.assert_allclose(host(mod.gradSum), om.gradSum, rtol=0, atol=1e-4 * sscale + 1e-9)
+    np.testing.assert_allclose(host(last.gradWeight), onet.last.gradWeight, rtol=0,
+                               atol=2e-5 * np.abs(onet.last.gradWeight).max())
+    lc, wlc = net.calc_lc(), onet.calc_lc()
+    assert abs(lc - wlc) <= 2e-4 * abs(wlc) + 1e-9
+
+
+# ------------------------------------------------------------------------------------------- fused engine
+def _engine_pair(oracle, mode, dtype, hidden, I0, fuse_kl, S=2):
+    from vbnn_amd.engine import FusedMLP
+    opt = opt_for(mode, dtype, input_size=I0, hidden=hidden, S=S, fuse_kl=fuse_kl)
+    eng = FusedMLP(opt)
+    onet = oracle.OracleMLP(opt)
+    rng = np.random.default_rng(7)
+    for k, v in enumerate(eng.vb):
+        om = onet.vb[k]
+        np.testing.assert_array_equal(host(v.means).view(np.uint32), om.weight.view(np.uint32))   # same He stream
+        lv = rng.normal(np.log(1e-3), 0.3, om.lvars.shape).astype(np.float32)
+        b = rng.normal(0, 0.05, om.bias.shape).astype(np.float32)
+        om.means[:] = om.weight; om.lvars[:] = lv; om.bias[:] = b
+        v.lvars.copy_(dev(lv)); v.bias.copy_(dev(b))
+        om.compute_prior()
+    np.testing.assert_array_equal(host(eng.weight3).view(np.uint32), onet.last.weight.view(np.uint32))
+    return opt, eng, onet
+
+
+def _run_pair(opt, eng, onet, oracle, N, I0):
+    x = oracle.fill_normal(N, I0, SEED, 4, 0, 0)
+    t = (np.arange(N) * 7 % 10).astype(np.int32)
+    eng.resetGradients(); eng.prepare(); onet.resetGradients()
+    werr = 0.0
+    for _ in range(int(opt["S"])):
+        eng.sample(); onet.sample()
+        eng.run(dev(x), dev(t))
+        e, _ = onet.run(x, t)
+        werr += e
+    loss, correct = eng.loss_and_accuracy()
+    return loss, werr
+
+
+@pytest.mark.parametrize("mode", ["lrt", "wn"])
+@pytest.mark.parametrize("fuse_kl", [False, True])
+def test_engine_matches_oracle_f32(oracle, nnmod, mode, fuse_kl):
+    """The fused whole-step engine (epilogue-fused ReLU / packing / dv hand-off / KL gradients) computes
+    what the module-by-module reference sequence computes. Shapes deliberately ragged (not multiples of
+    the tile or of 4) plus BASELINE config 2."""
+    for hidden, I0, N in ([[50, 34], 70, 37], [[400, 400], 784, 256]):
+        opt, eng, onet = _engine_pair(oracle, mode, "f32", hidden, I0, fuse_kl)
+        loss, werr = _run_pair(opt, eng, onet, oracle, N, I0)
+        assert abs(loss - werr) <= 3e-5 * abs(werr) + 1e-6, (loss, werr)
+        for k, v in enumerate(eng.vb):
+            om = onet.vb[k]
+            if fuse_kl:
+                mle, mlc = om.compute_mugrads(opt)      # VBLinear.lua:131-134: mugrad = mleg + mlcg, vgrad = vleg + vlcg
+                vle, vlc = om.compute_vargrads(opt)
+                want_mu, want_lv = mle + mlc, vle + vlc
+            else:
+                want_mu, want_lv = om.gradWeight, om.gradSum
+            np.testing.assert_allclose(host(v.gradWeight), want_mu, rtol=0, atol=3e-5 * np.abs(want_mu).max() + 1e-10)
+            np.testing.assert_allclose(host(v.gradSum), want_lv, rtol=0, atol=2e-4 * np.abs(want_lv).max() + 1e-10)
+            np.testing.assert_allclose(host(v.gradBias), om.gradBias, rtol=0, atol=3e-5 * np.abs(om.gradBias).max() + 1e-10)
+        np.testing.assert_allclose(host(eng.gradWeight3), onet.last.gradWeight, rtol=0,
+                                   atol=3e-5 * np.abs(onet.last.gradWeight).max())
+        np.testing.assert_allclose(host(eng.gradBias3), onet.last.gradBias, rtol=0,
+                                   atol=3e-5 * np.abs(onet.last.gradBias).max() + 1e-9)
+        assert abs(eng.calc_lc() - onet.calc_lc()) <= 2e-4 * abs(onet.calc_lc()) + 1e-9
+
+
+@pytest.mark.parametrize("mode", ["lrt", "wn"])
+def test_engine_bf16_close_to_f32_oracle(oracle, nnmod, mode):
+    """bf16 operands / fp32 accumulate against the fp32 oracle: normalised max error <= 3e-2 on the
+    gradients, 2e-2 on the loss (bf16 rtol 2e-2, atol 1e-3 * max)."""
+    opt, eng, onet = _engine_pair(oracle, mode, "bf16", [400, 400], 784, False, S=1)
+    loss, werr = _run_pair(opt, eng, onet, oracle, 256, 784)
+    assert abs(loss - werr) <= 2e-2 * abs(werr), (loss, werr)
+    # End to end through two ReLUs a bf16 rounding can flip a unit on/off for one row, which moves single
+    # gradient entries by one row's contribution: bound the bulk (Frobenius) tightly and the worst
+    # entry loosely. The per-layer test below has no such flips and is tight.
+    for k, v in enumerate(eng.vb):
+        om = onet.vb[k]
+        for got, want, what in ((v.gradWeight, om.gradWeight, "gradWeight"), (v.gradSum, om.gradSum, "gradSum"),
+                                (v.gradBias, om.gradBias, "gradBias")):
+            rel_fro = np.linalg.norm(host(got) - want) / np.linalg.norm(want)
+            assert rel_fro <= 3e-2, f"layer {k} {what}: relative Frobenius error {rel_fro:.3e}"
+            err = np.abs(host(got) - want).max() / np.abs(want).max()
+            assert err <= 0.25, f"layer {k} {what}: normalised max error {err:.3e}"
+
+
+@pytest.mark.parametrize("N,I,O", [(3, 7, 5), (100, 130, 70), (256, 784, 400)])
+def test_layer_bf16_against_rounded_operands(nnmod, oracle, N, I, O):
+    """bf16 MFMA path of one VBLinear (LRT) against float64 math on the SAME bf16-rounded operands
+    (oracle/ref_numpy.py): only the fp32 accumulation order differs. atol 1e-3 * max|.|, as SURVEY 8c T2."""
+    from oracle.ref_numpy import bf16_round as rb
+    opt, m, om = _layer_pair(nnmod, oracle, "lrt", I, O, dtype="bf16")
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 1, (N, I)).astype(np.float32)
+    g = rng.normal(0, 1.0 / N, (N, O)).astype(np.float32)
+    m.sample()
+    y = host(m.updateOutput(dev(x))).astype(np.float64)
+    zeta = oracle.fill_normal(N, O, SEED, 2, 0, m.draw, 0).astype(np.float64)
+    xr, mur = rb(x).astype(np.float64), rb(om.means).astype(np.float64)
+    x2r = rb(rb(x) * rb(x)).astype(np.float64)
+    varr = rb(np.exp(om.lvars)).astype(np.float64)
+    v = x2r @ varr.T
+    want_y = xr @ mur.T + om.bias + np.sqrt(v) * zeta
+    assert np.abs(y - want_y).max() <= 1e-3 * np.abs(want_y).max()
+    r = zeta / (2 * np.sqrt(v))
+    np.testing.assert_allclose(host(m.r), r, rtol=1e-3, atol=1e-6)
+    gx = host(m.backward(dev(x), dev(g), 1.0)).astype(np.float64)
+    r32 = host(m.r)
+    gr = rb(g).astype(np.float64)
+    gvr = rb(g * r32).astype(np.float64)
+    want_gx = gr @ mur + 2 * xr * (gvr @ varr)
+    assert np.abs(gx - want_gx).max() <= 1e-3 * np.abs(want_gx).max()
+    want_gw = gr.T @ xr
+    assert np.abs(host(m.gradWeight) - want_gw).max() <= 1e-3 * np.abs(want_gw).max()
+    want_gs = 2 * (gvr.T @ x2r) * np.sqrt(np.exp(om.lvars.astype(np.float64)))
+    assert np.abs(host(m.gradSum) - want_gs).max() <= 1e-3 * np.abs(want_gs).max()
+
+
+# ------------------------------------------------------------------------------------------- errors
+def test_error_convention(nnmod):
+    """Non-zero status + message instead of a crash (SURVEY 8b error convention)."""
+    from vbnn_amd import _lib as L
+    m = nnmod.Linear(8, 4)
+    with pytest.raises(ValueError):
+        m.updateOutput(torch.zeros(8, device="cuda"))          # 1-D input: the reference fails too (VBLinear.lua:114)
+    ctx = nnmod.Context.get()
+    st = L.lib().vbnn_pack(ctx.h, 7, 0, None, None, 0, 0, 0, None, 0, None, 0)
+    assert st != 0 and len(L.lib().vbnn_last_error()) > 0

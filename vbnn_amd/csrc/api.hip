@@ -30,12 +30,8 @@ extern "C" int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out) {
     }
     vbnn_ctx* c = new vbnn_ctx();
     c->device = device;
-    c->own_stream = (hip_stream == nullptr);
-    c->stream = (hipStream_t)hip_stream;
-    if (c->own_stream) {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete c; vbnn_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
-    }
+    c->own_stream = false;
+    c->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
     c->scratch_doubles = 8192;
     hipError_t e = hipMalloc((void**)&c->scratch, c->scratch_doubles * sizeof(double));
     if (e != hipSuccess) { delete c; vbnn_set_error("hipMalloc(scratch): %s", hipGetErrorString(e)); return VBNN_ERR_NOMEM; }

@@ -324,14 +324,15 @@ extern "C" int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvar
 
 // ---------------------------------------------------------------------------------- gradBias
 // gradBias[o] (+)= scale * sum_n g[n][o]: a block owns 64 columns, its 4 waves stride the rows.
-__global__ __launch_bounds__(256) void k_col_sum(const float* __restrict__ g, int64_t ld, int64_t N, int64_t O, float scale,
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_sum(const T* __restrict__ g, int64_t ld, int64_t N, int64_t O, float scale,
                                                  int accumulate, float* gradBias) {
     __shared__ float sh[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t o = (int64_t)blockIdx.x * 64 + tx;
     float s = 0.f;
     if (o < O)
-        for (int64_t n = ty; n < N; n += 4) s += g[n * ld + o];
+        for (int64_t n = ty; n < N; n += 4) s += Elt<T>::from(g[n * ld + o]);
     sh[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && o < O) {
@@ -340,13 +341,18 @@ __global__ __launch_bounds__(256) void k_col_sum(const float* __restrict__ g, in
         gradBias[o] = fmaf(scale, tot, old);
     }
 }
-extern "C" int vbnn_acc_grad_bias(vbnn_ctx* ctx, const float* g, int64_t ld_g, int64_t N, int64_t O, float scale,
+extern "C" int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O, float scale,
                                   int accumulate, float* gradBias) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && g && gradBias, "null argument");
     VBNN_REQUIRE(N > 0 && O > 0 && ld_g >= O, "shape");
-    hipLaunchKernelGGL(k_col_sum, dim3((unsigned)((O + 63) / 64)), dim3(256), 0, ctx->stream, g, ld_g, N, O, scale, accumulate,
-                       gradBias);
+    if (dtype == VBNN_F32)
+        hipLaunchKernelGGL(k_col_sum<float>, dim3((unsigned)((O + 63) / 64)), dim3(256), 0, ctx->stream, (const float*)g, ld_g,
+                           N, O, scale, accumulate, gradBias);
+    else if (dtype == VBNN_BF16)
+        hipLaunchKernelGGL(k_col_sum<bf16_t>, dim3((unsigned)((O + 63) / 64)), dim3(256), 0, ctx->stream, (const bf16_t*)g,
+                           ld_g, N, O, scale, accumulate, gradBias);
+    else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
     return vbnn_check_launch("k_col_sum");
     VBNN_API_END
 }
@@ -491,5 +497,77 @@ extern "C" int vbnn_logsoftmax_backward(vbnn_ctx* ctx, const float* out, const f
     VBNN_REQUIRE(N > 0 && C > 0, "shape");
     hipLaunchKernelGGL(k_logsoftmax_backward, dim3(grid_for(N, 4)), dim3(256), 0, ctx->stream, out, g, gx, N, C);
     return vbnn_check_launch("k_logsoftmax_backward");
+    VBNN_API_END
+}
+
+
+// ---------------------------------------------------------------------------------- prep_layer
+// The per-step parameter sweep of the fused path: ONE read of means/lvars (8 B per weight) produces
+//   - the GEMM shadows mu, sigma^2 = exp(lvars) (and their transposes for the gradInput GEMM),
+//   - the prior statistics of VBLinear:compute_prior (VBLinear.lua:77-88) as block partials.
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_layer(const float* __restrict__ means, const float* __restrict__ lvars,
+                                                    int64_t O, int64_t I, T* mu_s, T* var_s, int64_t ld_w, T* muT_s, T* varT_s,
+                                                    int64_t ld_wT, double* partial) {
+    __shared__ float tm[64][65];
+    __shared__ float tv[64][65];
+    __shared__ double sh[4];
+    const int64_t tiles_c = (I + 63) / 64, tiles_r = (O + 63) / 64;
+    const int64_t ntiles = tiles_c * tiles_r;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
+        const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
+#pragma unroll 4
+        for (int rr = ty; rr < 64; rr += 4) {
+            const int64_t r = r0 + rr, c = c0 + tx;
+            float m = 0.f, v = 0.f;
+            if (r < O && c < I) {
+                m = means[r * I + c];
+                const float l = lvars[r * I + c];
+                v = expf(l);
+                s1 += (double)(v + m * m); s2 += (double)l;
+                mu_s[r * ld_w + c] = Elt<T>::to(m);
+                var_s[r * ld_w + c] = Elt<T>::to(v);
+            }
+            tm[rr][tx] = m; tv[rr][tx] = v;
+        }
+        if (muT_s) {
+            __syncthreads();
+#pragma unroll 4
+            for (int cc = ty; cc < 64; cc += 4) {
+                const int64_t c = c0 + cc, r = r0 + tx;
+                if (c < I && r < O) {
+                    muT_s[c * ld_wT + r] = Elt<T>::to(tm[tx][cc]);
+                    varT_s[c * ld_wT + r] = Elt<T>::to(tv[tx][cc]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const double r1 = block_sum(s1, sh);
+    const double r2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = r1; partial[blockIdx.x * 2 + 1] = r2; }
+}
+
+extern "C" int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, const float* lvars, int64_t O, int64_t I,
+                               void* mu_s, void* var_s, int64_t ld_w, void* muT_s, void* varT_s, int64_t ld_wT,
+                               double* stats) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && means && lvars && mu_s && var_s && stats, "null argument");
+    VBNN_REQUIRE((muT_s == nullptr) == (varT_s == nullptr), "muT_s and varT_s go together");
+    VBNN_REQUIRE(O > 0 && I > 0 && ld_w >= I && (!muT_s || ld_wT >= O), "shape");
+    const int64_t ntiles = ((O + 63) / 64) * ((I + 63) / 64);
+    const int nb = (int)(ntiles < 2048 ? ntiles : 2048);
+    VBNN_REQUIRE((size_t)nb * 2 <= ctx->scratch_doubles, "scratch");
+    if (dtype == VBNN_F32)
+        hipLaunchKernelGGL(k_prep_layer<float>, dim3(nb), dim3(256), 0, ctx->stream, means, lvars, O, I, (float*)mu_s,
+                           (float*)var_s, ld_w, (float*)muT_s, (float*)varT_s, ld_wT, ctx->scratch);
+    else if (dtype == VBNN_BF16)
+        hipLaunchKernelGGL(k_prep_layer<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, means, lvars, O, I, (bf16_t*)mu_s,
+                           (bf16_t*)var_s, ld_w, (bf16_t*)muT_s, (bf16_t*)varT_s, ld_wT, ctx->scratch);
+    else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_prior_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->scratch, nb, O * I, stats);
+    return vbnn_check_launch("k_prep_layer");
     VBNN_API_END
 }

@@ -1,0 +1,290 @@
+"""Fused whole-step engine: mlp.lua's protocol (resetGradients / sample / run / calc_lc) with the
+elementwise modules folded into the GEMM epilogues, activations and packed operands resident in
+HBM, one process per GPU and an RCCL all-reduce of the gradient arena after accGradParameters.
+
+Per minibatch (main.lua:28-40):   resetGradients(); prepare(); S x { sample(); run(x, t) }
+One `run` = forward of every VB layer (dual MFMA GEMM, Philox noise + ReLU + operand packing in the
+epilogue), final Linear + LogSoftMax + ClassNLL, backward (gradInput GEMMs with the ReLU mask and the
+dL/dv hand-off in the epilogue, accGradParameters GEMMs with the gradSum / KL-gradient epilogue).
+
+Everything here is argument plumbing around include/vbnn_hip.h; torch is device memory, the
+stream and torch.distributed.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from .nn import Context, _DT, _Packed, _p, fill_normal
+
+
+class _VB:
+    pass
+
+
+class FusedMLP:
+    def __init__(self, opt, device=None, world_size=1, rank=0, process_group=None):
+        self.opt = opt
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.ctx = Context.get(self.device)
+        self.dtype = opt.get("dtype", "bf16")
+        self.code, self.tdt = _DT[self.dtype]
+        self.mode = opt.get("mode", "lrt")
+        assert self.mode in ("wn", "lrt")
+        self.seed = int(opt.get("seed", 3))
+        self.world, self.rank, self.pg = world_size, rank, process_group
+        self.fuse_kl = bool(opt.get("fuse_kl", True))
+        self.B, self.S = float(opt.get("B", 1e6)), float(opt.get("S", 1))
+        hidden = list(opt["hidden"])
+        sizes = [opt["input_size"]] + hidden
+        self.n_classes = opt["n_classes"]
+        self.sizes = sizes
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        # ---- gradient arena: [gradWeight | gradSum | gradBias] per VB layer, then the final Linear
+        n_g = sum(2 * sizes[i] * sizes[i + 1] + sizes[i + 1] for i in range(len(hidden)))
+        n_g += sizes[-1] * self.n_classes + self.n_classes
+        self.grads = torch.zeros(n_g, **f32)
+        off = 0
+
+        def take(n, shape):
+            nonlocal off
+            v = self.grads[off:off + n].view(*shape)
+            off += n
+            return v
+
+        var_init = opt["var_init"] if not opt.get("msr_init") else None
+        self.vb = []
+        for li in range(len(hidden)):
+            I, O = sizes[li], sizes[li + 1]
+            v = _VB()
+            v.I, v.O, v.layer_id = I, O, li
+            v.var_init = var_init if var_init is not None else 2.0 / I           # VBLinear.lua:12-16
+            v.means = torch.zeros(O, I, **f32)                                     # :22-23
+            v.lvars = torch.full((O, I), math.log(v.var_init), **f32)              # :18
+            v.bias = torch.zeros(O, **f32)                                         # :13
+            v.weight = torch.zeros(O, I, **f32) if self.mode == "wn" else None
+            start = off
+            # with fuse_kl the first two blocks hold the TOTAL gradients d/dmeans, d/dlvars
+            # (likelihood / S + KL, VBLinear.lua:90-98); otherwise the reference's gradWeight / gradSum
+            v.gradWeight = take(O * I, (O, I))
+            v.gradSum = take(O * I, (O, I))
+            v.gradBias = take(O, (O,))
+            v.bucket = self.grads[start:off]
+            v.stats = torch.zeros(4, dtype=torch.float64, device=dev)
+            v.mu_s, v.var_s = _Packed(O, I, self.tdt, dev), _Packed(O, I, self.tdt, dev)
+            if li > 0:
+                v.muT_s, v.varT_s = _Packed(I, O, self.tdt, dev), _Packed(I, O, self.tdt, dev)
+            else:
+                v.muT_s = v.varT_s = None
+            self.vb.append(v)
+        H = sizes[-1]
+        self.weight3 = torch.zeros(self.n_classes, H, **f32)
+        self.bias3 = torch.zeros(self.n_classes, **f32)
+        start = off
+        self.gradWeight3 = take(self.n_classes * H, (self.n_classes, H))
+        self.gradBias3 = take(self.n_classes, (self.n_classes,))
+        self.bucket3 = self.grads[start:off]
+        self.w3_s = _Packed(self.n_classes, H, self.tdt, dev)
+        self.w3T_s = _Packed(H, self.n_classes, self.tdt, dev)
+        self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        self._corr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._lc = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.draw = 0
+        self._first = True
+        self._N = None
+        self._works = []
+        self.init_parameters()
+
+    # mlp.lua:47-55 (He rule for every weight, bias zero) + the bench's non-degenerate means
+    # (means ~ N(0, sqrt(2/I)); the shipped mu_init = 0 gives an all-zero net).
+    def init_parameters(self):
+        for v in self.vb:
+            fill_normal(v.means, self.seed, L.STREAM_HEINIT, v.layer_id, 0, scale=math.sqrt(2.0 / v.I))
+            v.bias.zero_()
+        fill_normal(self.weight3, self.seed, L.STREAM_HEINIT, len(self.vb), 0, scale=math.sqrt(2.0 / self.sizes[-1]))
+        self.bias3.zero_()
+
+    # ---- buffers that depend on the local batch size
+    def _alloc_batch(self, N):
+        if self._N == N:
+            return
+        self._N = N
+        dev, tdt = self.device, self.tdt
+        for v in self.vb:
+            v.x_s, v.x2_s = _Packed(N, v.I, tdt, dev), _Packed(N, v.I, tdt, dev)
+            v.xT_s, v.x2T_s = _Packed(v.I, N, tdt, dev), _Packed(v.I, N, tdt, dev)
+            v.g_s, v.gv_s = _Packed(N, v.O, tdt, dev), _Packed(N, v.O, tdt, dev)
+            v.gT_s, v.gvT_s = _Packed(v.O, N, tdt, dev), _Packed(v.O, N, tdt, dev)
+            v.r = torch.zeros(N, v.O, dtype=torch.float32, device=dev)
+        H = self.sizes[-1]
+        self.h_s = _Packed(N, H, tdt, dev)            # input of the final Linear
+        self.hT_s = _Packed(H, N, tdt, dev)
+        self.logits = torch.zeros(N, self.n_classes, dtype=torch.float32, device=dev)
+        self.g_logits = torch.zeros(N, self.n_classes, dtype=torch.float32, device=dev)
+        self.out = torch.zeros(N, self.n_classes, dtype=torch.float32, device=dev)
+        self.g3_s = _Packed(N, self.n_classes, tdt, dev)
+        self.g3T_s = _Packed(self.n_classes, N, tdt, dev)
+
+    # ---- mlp.lua:62-67. Nothing is zeroed: the first accGradParameters of the minibatch overwrites.
+    def resetGradients(self):
+        self._first = True
+        L.check(L.lib().vbnn_buf_zero(self.ctx.h, _p(self._acc), 16))
+        L.check(L.lib().vbnn_buf_zero(self.ctx.h, _p(self._corr), 4))
+
+    # ---- once per minibatch, after the parameters changed: VBLinear:compute_prior (VBLinear.lua:77-88)
+    # fused with the packing of the GEMM shadows.
+    def prepare(self):
+        lib = L.lib()
+        for v in self.vb:
+            if self.mode == "lrt":
+                L.check(lib.vbnn_prep_layer(self.ctx.h, self.code, _p(v.means), _p(v.lvars), v.O, v.I, v.mu_s.ptr,
+                                            v.var_s.ptr, v.mu_s.ld, v.muT_s.ptr if v.muT_s else None,
+                                            v.varT_s.ptr if v.varT_s else None, v.muT_s.ld if v.muT_s else 0,
+                                            _p(v.stats)))
+            else:
+                L.check(lib.vbnn_compute_prior(self.ctx.h, _p(v.means), _p(v.lvars), v.O * v.I, None, None, None,
+                                               _p(v.stats)))
+        L.check(lib.vbnn_pack(self.ctx.h, self.code, L.PACK_COPY, _p(self.weight3), None, self.sizes[-1],
+                              self.n_classes, self.sizes[-1], self.w3_s.ptr, self.w3_s.ld, self.w3T_s.ptr, self.w3T_s.ld))
+
+    # ---- mlp.lua:69-74
+    def sample(self):
+        self.draw += 1
+        if self.mode == "wn":
+            lib = L.lib()
+            for v in self.vb:
+                L.check(lib.vbnn_wn_sample(self.ctx.h, _p(v.means), None, _p(v.lvars), _p(v.weight), None, v.O, v.I,
+                                           self.seed, v.layer_id, self.draw))
+                L.check(lib.vbnn_pack(self.ctx.h, self.code, L.PACK_COPY, _p(v.weight), None, v.I, v.O, v.I,
+                                      v.mu_s.ptr, v.mu_s.ld, v.muT_s.ptr if v.muT_s else None,
+                                      v.muT_s.ld if v.muT_s else 0))
+
+    # ---- argument blocks of the three GEMM families for VB layer `li` (also used by bench.py to time
+    # exactly the launches of the step in isolation)
+    def _fwd_args(self, li, N, row0):
+        v, lrt = self.vb[li], self.mode == "lrt"
+        last = li == len(self.vb) - 1
+        nxt = None if last else self.vb[li + 1]
+        return L.FwdArgs(w=v.mu_s.ptr, w2=v.var_s.ptr if lrt else None, x=v.x_s.ptr, x2=v.x2_s.ptr if lrt else None,
+                         ld_w=v.mu_s.ld, ld_x=v.x_s.ld, N=N, I=v.I, O=v.O, bias=_p(v.bias), seed=self.seed,
+                         layer=v.layer_id, draw=self.draw, row0=row0, y=None, ld_y=0,
+                         r=_p(v.r) if lrt else None, ld_r=v.O, relu=1,
+                         h=self.h_s.ptr if last else nxt.x_s.ptr,
+                         h2=None if (last or not lrt) else nxt.x2_s.ptr,
+                         ld_h=self.h_s.ld if last else nxt.x_s.ld,
+                         hT=self.hT_s.ptr if last else nxt.xT_s.ptr,
+                         h2T=None if (last or not lrt) else nxt.x2T_s.ptr,
+                         ld_hT=self.hT_s.ld if last else nxt.xT_s.ld)
+
+    def _dw_args(self, li, N, accumulate):
+        v, lrt = self.vb[li], self.mode == "lrt"
+        d = L.DwArgs(xT=v.xT_s.ptr, x2T=v.x2T_s.ptr if lrt else None, gT=v.gT_s.ptr,
+                     gvT=v.gvT_s.ptr if lrt else None, ld_n=v.xT_s.ld, N=N, I=v.I, O=v.O, scale=1.0,
+                     accumulate=accumulate, seed=self.seed, layer=v.layer_id, draw=self.draw, lvars=_p(v.lvars))
+        if self.fuse_kl:
+            d.gradWeight, d.gradSum = None, None
+            d.grad_mu, d.grad_lv = _p(v.gradWeight), _p(v.gradSum)
+            d.means, d.stats = _p(v.means), _p(v.stats)
+            d.B, d.S, d.kl_scale = self.B, self.S, 1.0 / self.world
+        else:
+            d.gradWeight, d.gradSum = _p(v.gradWeight), _p(v.gradSum)
+        return d
+
+    def _dx_args(self, li, N):
+        v, p, lrt = self.vb[li], self.vb[li - 1], self.mode == "lrt"
+        return L.DxArgs(wT=v.muT_s.ptr, w2T=v.varT_s.ptr if lrt else None, g=v.g_s.ptr,
+                        gv=v.gv_s.ptr if lrt else None, ld_wT=v.muT_s.ld, ld_g=v.g_s.ld, N=N, I=v.I, O=v.O,
+                        x=v.x_s.ptr, ld_x=v.x_s.ld, gx=None, ld_gx=0, relu_mask=1,
+                        r_prev=_p(p.r) if lrt else None, ld_r_prev=p.O, g_prev=p.g_s.ptr,
+                        gv_prev=p.gv_s.ptr if lrt else None, ld_gp=p.g_s.ld, gT_prev=p.gT_s.ptr,
+                        gvT_prev=p.gvT_s.ptr if lrt else None, ld_gpT=p.gT_s.ld)
+
+    # ---- mlp.lua:76-84, fused
+    def run(self, inputs, targets, row0=None):
+        lib, ctx, code = L.lib(), self.ctx.h, self.code
+        x = inputs.reshape(inputs.shape[0], -1)                         # nn.Reshape (mlp.lua:12)
+        N = x.shape[0]
+        assert x.shape[1] == self.sizes[0] and x.dtype == torch.float32 and x.is_cuda
+        self._alloc_batch(N)
+        if row0 is None:
+            row0 = self.rank * N
+        lrt = self.mode == "lrt"
+        accumulate = 0 if self._first else 1
+        inv_n = 1.0 / (N * self.world)
+        v0 = self.vb[0]
+        L.check(lib.vbnn_pack(ctx, code, L.PACK_COPY, _p(x), None, x.stride(0), N, v0.I, v0.x_s.ptr, v0.x_s.ld,
+                              v0.xT_s.ptr, v0.xT_s.ld))
+        if lrt:
+            L.check(lib.vbnn_pack(ctx, code, L.PACK_SQUARE, _p(x), None, x.stride(0), N, v0.I, v0.x2_s.ptr, v0.x2_s.ld,
+                                  v0.x2T_s.ptr, v0.x2T_s.ld))
+        nl = len(self.vb)
+        # ---------------- forward
+        for li in range(nl):
+            a = self._fwd_args(li, N, row0)
+            L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
+        H, Cn = self.sizes[-1], self.n_classes
+        a = L.FwdArgs(w=self.w3_s.ptr, w2=None, x=self.h_s.ptr, x2=None, ld_w=self.w3_s.ld, ld_x=self.h_s.ld,
+                      N=N, I=H, O=Cn, bias=_p(self.bias3), y=_p(self.logits), ld_y=Cn)
+        L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
+        # ---------------- criterion (LogSoftMax + ClassNLL forward/backward, accuracy)
+        L.check(lib.vbnn_logsoftmax_nll(ctx, _p(self.logits), Cn, _p(targets), N, Cn, inv_n, _p(self.out),
+                                        _p(self.g_logits), _p(self._acc), _p(self._corr)))
+        # ---------------- backward: final Linear
+        L.check(lib.vbnn_pack(ctx, code, L.PACK_COPY, _p(self.g_logits), None, Cn, N, Cn, self.g3_s.ptr, self.g3_s.ld,
+                              self.g3T_s.ptr, self.g3T_s.ld))
+        d = L.DwArgs(xT=self.hT_s.ptr, x2T=None, gT=self.g3T_s.ptr, gvT=None, ld_n=self.hT_s.ld, N=N, I=H, O=Cn,
+                     scale=1.0, accumulate=accumulate, gradWeight=_p(self.gradWeight3), gradSum=None)
+        L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+        L.check(lib.vbnn_acc_grad_bias(ctx, L.F32, _p(self.g_logits), Cn, N, Cn, 1.0, accumulate, _p(self.gradBias3)))
+        self._reduce(self.bucket3)
+        vl = self.vb[-1]
+        dx = L.DxArgs(wT=self.w3T_s.ptr, w2T=None, g=self.g3_s.ptr, gv=None, ld_wT=self.w3T_s.ld, ld_g=self.g3_s.ld,
+                      N=N, I=H, O=Cn, x=self.h_s.ptr, ld_x=self.h_s.ld, gx=None, ld_gx=0, relu_mask=1,
+                      r_prev=_p(vl.r) if lrt else None, ld_r_prev=vl.O, g_prev=vl.g_s.ptr,
+                      gv_prev=vl.gv_s.ptr if lrt else None, ld_gp=vl.g_s.ld, gT_prev=vl.gT_s.ptr,
+                      gvT_prev=vl.gvT_s.ptr if lrt else None, ld_gpT=vl.gT_s.ld)
+        L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
+        # ---------------- backward: VB layers, last to first
+        for li in range(nl - 1, -1, -1):
+            v = self.vb[li]
+            d = self._dw_args(li, N, accumulate)
+            L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+            L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
+            self._reduce(v.bucket)
+            if li > 0:
+                dx = self._dx_args(li, N)
+                L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
+        self._first = False
+
+    # ---- data-parallel exchange: sum all-reduce of one layer's gradient bucket over RCCL/xGMI, issued
+    # right after that layer's accGradParameters so it overlaps the rest of backward. The criterion
+    # already divides by the GLOBAL batch and the KL gradient carries 1/world, so the sum is the result.
+    def _reduce(self, bucket):
+        if self.world > 1:
+            import torch.distributed as dist
+            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        """Wait for the outstanding all-reduces (end of the step)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    # ---- reporting (each of these synchronises)
+    def loss_and_accuracy(self):
+        self.finish()
+        torch.cuda.synchronize(self.device)
+        loss = float(self._acc[0].item())
+        correct = int(self._corr[0].item())
+        return loss, correct
+
+    def calc_lc(self, opt=None):                                         # mlp.lua:109-115, fresh statistics
+        lc = 0.0
+        B = float((opt or self.opt).get("B", self.B))
+        for v in self.vb:
+            L.check(L.lib().vbnn_calc_lc(self.ctx.h, _p(v.means), _p(v.lvars), None, None, _p(v.stats), B, None,
+                                         _p(self._lc), v.O * v.I))
+            lc += float(self._lc[0].item())
+        return lc

@@ -341,7 +341,7 @@ class Linear(Module):
 
     def _acc_bias(self, g, scale):
         N, O = g.shape
-        L.check(L.lib().vbnn_acc_grad_bias(self.ctx.h, _p(g), g.stride(0), N, O, float(scale), 1, _p(self.gradBias)))
+        L.check(L.lib().vbnn_acc_grad_bias(self.ctx.h, L.F32, _p(g), g.stride(0), N, O, float(scale), 1, _p(self.gradBias)))
 
     def updateOutput(self, input):
         return self._forward_plain(self._check_input(input))
