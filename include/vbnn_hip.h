@@ -45,6 +45,11 @@ typedef struct vbnn_ctx vbnn_ctx;
 int vbnn_abi_version(void);
 const char* vbnn_last_error(void);
 
+/* test / A-B hook. VBNN_DEBUG_GEMM_KERNEL: 0 = pick by shape (default), 1 = always the general MFMA
+ * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it. */
+#define VBNN_DEBUG_GEMM_KERNEL 0
+int vbnn_debug_set(int key, int value);
+
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
  * (which is also what PyTorch-ROCm's default stream is, so the two stay ordered). */
 int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);

@@ -122,6 +122,59 @@ class ReferenceCpuMLP:
         return self.run(x, t)
 
 
+# ---- the fused LRT step with explicit rounding points -------------------------------------------------
+def emulate_lrt_step(layers, w3, b3, x, t, zetas, rnd=lambda a: a, S=1.0, B=1e6, inv_n=None):
+    """One LRT draw of the whole MLP in float64 with the engine's rounding points made explicit:
+    `rnd` is applied wherever the HIP path stores a GEMM operand (x, x.x, mu, sigma^2, relu(y), its
+    square, g, g.r and the final Linear's operands). rnd = identity gives the exact fp32-free reference
+    (cross-checks the C oracle); rnd = bf16_round gives what the bf16 MFMA path computes up to fp32
+    accumulation order. layers: list of dicts(means, lvars, bias); zetas: per-layer N x O normals.
+    Returns loss, per-layer dicts(gradWeight, gradSum, gradBias, grad_mu, grad_lv), gw3, gb3."""
+    f8 = np.float64
+    N = x.shape[0]
+    inv_n = 1.0 / N if inv_n is None else inv_n
+    xs, x2s, rs = [rnd(x).astype(f8)], [rnd(rnd(x) * rnd(x)).astype(f8)], []
+    for lay, z in zip(layers, zetas):
+        mu, var = rnd(lay["means"]).astype(f8), rnd(np.exp(lay["lvars"])).astype(f8)
+        m = xs[-1] @ mu.T + lay["bias"].astype(f8)
+        v = x2s[-1] @ var.T
+        y = (m + np.sqrt(v) * z).astype(np.float32)                 # the accumulators are fp32
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = np.where(v > 0, z / (2 * np.sqrt(v)), 0.0).astype(np.float32)
+        h = rnd(np.maximum(y, 0))
+        rs.append(r)
+        xs.append(h.astype(f8))
+        x2s.append(rnd(h * h).astype(f8))
+    logits = (xs[-1] @ rnd(w3).astype(f8).T + b3).astype(np.float32)
+    out = log_softmax(logits)
+    loss = float(-out[np.arange(N), t].sum() * inv_n)
+    onehot = np.zeros_like(out)
+    onehot[np.arange(N), t] = 1.0
+    g3 = ((np.exp(out) - onehot) * np.float32(inv_n)).astype(np.float32)
+    g3r = rnd(g3).astype(f8)
+    gw3 = g3r.T @ xs[-1]
+    gb3 = g3.astype(f8).sum(axis=0)
+    gx = g3r @ rnd(w3).astype(f8)
+    res = [None] * len(layers)
+    for k in range(len(layers) - 1, -1, -1):
+        lay = layers[k]
+        gp = np.where(xs[k + 1] > 0, gx, 0.0).astype(np.float32)      # ReLU mask on the stored activation
+        g = rnd(gp).astype(f8)
+        gv = rnd(gp * rs[k]).astype(f8)
+        var32 = np.exp(lay["lvars"])
+        gw = g.T @ xs[k]
+        gs2 = gv.T @ x2s[k]
+        stdv = np.sqrt(var32.astype(f8))
+        vh = float(np.sum(var32.astype(f8) + lay["means"].astype(f8) ** 2) / lay["means"].size)
+        res[k] = dict(gradWeight=gw, gradSum=2 * gs2 * stdv, gradBias=g.sum(axis=0),
+                      grad_mu=gw / S + lay["means"] / (B * vh),
+                      grad_lv=gs2 * var32 / S + (var32 / vh - 1.0) / (2 * B))
+        if k > 0:
+            mu, var = rnd(lay["means"]).astype(f8), rnd(var32).astype(f8)
+            gx = g @ mu + 2 * xs[k] * (gv @ var)
+    return loss, res, gw3, gb3
+
+
 # ---- BLAS-speed single-layer math for big-shape parity (operands optionally bf16-rounded) ---------
 def lrt_forward(x, means, lvars, bias, zeta, rnd=lambda a: a):
     xr = rnd(x)

@@ -1,0 +1,109 @@
+"""CPU tests of the drop-in boundary: the shared library loads, exports every symbol the header
+declares, the ctypes mirror agrees with the C struct layouts, and the Lua FFI cdef is in step with the
+header. No compute call is made (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vbnn_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(vbnn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vbnn_amd import _lib as L
+    assert os.path.exists(L.LIB_PATH), "libvbnn_hip.so must be built in-tree (python -c 'import __graft_entry__ as g; g.build()')"
+    lib = C.CDLL(L.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/vbnn_hip.h but not exported"
+    # and the ctypes table covers exactly the header
+    assert sorted(L.exported_symbols()) == names
+    L.lib()
+    assert L.lib().vbnn_abi_version() == 1
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    """On a box without a HIP device the product path must fail loudly (no CPU / oracle fallback)."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from vbnn_amd import _lib as L
+    h = C.c_void_p()
+    st = L.lib().vbnn_ctx_create(0, None, C.byref(h))
+    assert st != 0
+    assert len(L.lib().vbnn_last_error()) > 0
+    with pytest.raises(L.VbnnError):
+        L.check(st)
+
+
+def test_product_path_does_not_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vbnn_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                bad = re.findall(r"^\s*(?:from\s+\S*oracle\S*\s+import|import\s+\S*oracle|#include\s+\S*oracle)|libvbnn_oracle|vbo_",
+                                 txt, flags=re.M)
+                assert not bad, f"{f} reaches into oracle/: {bad}"
+
+
+def test_ctypes_structs_match_the_header():
+    """Compile a C program against the header that prints sizeof/offsetof of the three argument blocks."""
+    from vbnn_amd import _lib as L
+    structs = {"vbnn_fwd_args": L.FwdArgs, "vbnn_dx_args": L.DxArgs, "vbnn_dw_args": L.DwArgs}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void){"]
+    for cname, st in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(src, "w").write("\n".join(lines))
+        subprocess.check_call(["gcc", "-std=c11", "-o", exe, src])
+        out = subprocess.check_output([exe]).decode().split("\n")
+    got = dict(l.split() for l in out if l)
+    for cname, st in structs.items():
+        assert int(got[cname]) == C.sizeof(st)
+        for fname, _ in st._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(st, fname).offset, f"{cname}.{fname}"
+
+
+def test_lua_cdef_matches_header():
+    """lua/VBLinear.lua cannot be executed here (no LuaJIT); keep its ffi.cdef in step with the header:
+    every function the header declares must appear in the cdef with the same parameter count."""
+    lua = os.path.join(ROOT, "lua", "vbnn_ffi.lua")
+    if not os.path.exists(lua):
+        pytest.skip("Lua shim not written yet")
+    txt = open(lua).read()
+    cdef = txt[txt.index("ffi.cdef[["):txt.index("]]")]
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+
+    def protos(s):
+        return {m.group(1): len([p for p in m.group(2).split(",") if p.strip() and p.strip() != "void"])
+                for m in re.finditer(r"(vbnn_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", s, flags=re.S)}
+
+    ph, pl = protos(hdr), protos(cdef)
+    for name in declared_functions():
+        assert name in pl, f"{name} missing from the Lua cdef"
+        assert pl[name] == ph[name], f"{name}: {pl[name]} parameters in Lua, {ph[name]} in the header"
+
+
+def test_pad_ld():
+    from vbnn_amd import _lib as L
+    assert [L.pad_ld(k) for k in (1, 10, 64, 65, 784, 4096)] == [64, 64, 64, 128, 832, 4096]
+
+
+if __name__ == "__main__":
+    sys.exit(pytest.main([__file__, "-q"]))

@@ -310,27 +310,90 @@ def test_engine_matches_oracle_f32(oracle, nnmod, mode, fuse_kl):
 
 
 @pytest.mark.parametrize("mode", ["lrt", "wn"])
-def test_engine_bf16_close_to_f32_oracle(oracle, nnmod, mode):
+def test_engine_bf16_close_to_f32_oracle(oracle, nnmod, gemm_kernel, mode):
     """bf16 operands / fp32 accumulate against the fp32 oracle: normalised max error <= 3e-2 on the
     gradients, 2e-2 on the loss (bf16 rtol 2e-2, atol 1e-3 * max)."""
     opt, eng, onet = _engine_pair(oracle, mode, "bf16", [400, 400], 784, False, S=1)
     loss, werr = _run_pair(opt, eng, onet, oracle, 256, 784)
     assert abs(loss - werr) <= 2e-2 * abs(werr), (loss, werr)
-    # End to end through two ReLUs a bf16 rounding can flip a unit on/off for one row, which moves single
-    # gradient entries by one row's contribution: bound the bulk (Frobenius) tightly and the worst
-    # entry loosely. The per-layer test below has no such flips and is tight.
+    # End to end through two ReLUs a bf16 rounding flips ~0.3 % of the units on/off, and every flip moves a
+    # whole row's contribution in or out of a gradient sum: sqrt(0.003) ~ 5 % Frobenius is inherent to
+    # comparing against UNROUNDED math. So this bound is loose; test_engine_bf16_against_rounding_emulation
+    # below (same rounding points => same masks) is the tight one.
     for k, v in enumerate(eng.vb):
         om = onet.vb[k]
         for got, want, what in ((v.gradWeight, om.gradWeight, "gradWeight"), (v.gradSum, om.gradSum, "gradSum"),
                                 (v.gradBias, om.gradBias, "gradBias")):
             rel_fro = np.linalg.norm(host(got) - want) / np.linalg.norm(want)
-            assert rel_fro <= 3e-2, f"layer {k} {what}: relative Frobenius error {rel_fro:.3e}"
-            err = np.abs(host(got) - want).max() / np.abs(want).max()
-            assert err <= 0.25, f"layer {k} {what}: normalised max error {err:.3e}"
+            assert rel_fro <= 0.15, f"layer {k} {what}: relative Frobenius error {rel_fro:.3e}"
+
+
+@pytest.mark.parametrize("hidden,I0,N", [([50, 34], 70, 37), ([400, 400], 784, 256), ([512, 384], 320, 640)])
+@pytest.mark.parametrize("fuse_kl", [False, True])
+def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidden, I0, N, fuse_kl):
+    """The bf16 fused step against float64 math that rounds to bf16 at exactly the engine's rounding points
+    (oracle/ref_numpy.emulate_lrt_step): identical ReLU masks, so what remains is fp32 accumulation order.
+    Bounds: loss 1e-4 relative; gradients 2e-3 Frobenius, 2e-2 of the largest entry."""
+    from oracle.ref_numpy import bf16_round, emulate_lrt_step
+    opt, eng, onet = _engine_pair(oracle, "lrt", "bf16", hidden, I0, fuse_kl, S=1)
+    x = oracle.fill_normal(N, I0, SEED, 4, 0, 0)
+    t = (np.arange(N) * 7 % 10).astype(np.int32)
+    eng.resetGradients(); eng.prepare(); eng.sample()
+    eng.run(dev(x), dev(t))
+    loss, _ = eng.loss_and_accuracy()
+    layers = [dict(means=om.means, lvars=om.lvars, bias=om.bias) for om in onet.vb]
+    zetas = [oracle.fill_normal(N, om.O, SEED, 2, k, 1, 0).astype(np.float64) for k, om in enumerate(onet.vb)]
+    wloss, res, gw3, gb3 = emulate_lrt_step(layers, onet.last.weight, onet.last.bias, x, t, zetas, bf16_round,
+                                            S=1.0, B=opt["B"])
+    assert abs(loss - wloss) <= 1e-4 * abs(wloss), (loss, wloss)
+
+    def close(got, want, what):
+        got = host(got).astype(np.float64)
+        fro = np.linalg.norm(got - want) / np.linalg.norm(want)
+        mx = np.abs(got - want).max() / np.abs(want).max()
+        assert fro <= 2e-3 and mx <= 2e-2, f"{what}: Frobenius {fro:.3e}, max {mx:.3e}"
+
+    for k, v in enumerate(eng.vb):
+        close(v.gradWeight, res[k]["grad_mu" if fuse_kl else "gradWeight"], f"layer {k} d/dmeans")
+        close(v.gradSum, res[k]["grad_lv" if fuse_kl else "gradSum"], f"layer {k} d/dlvars")
+        close(v.gradBias, res[k]["gradBias"], f"layer {k} gradBias")
+    close(eng.gradWeight3, gw3, "final gradWeight")
+    close(eng.gradBias3, gb3, "final gradBias")
+
+
+@pytest.fixture(params=[1, 2], ids=["general-kernel", "pipelined-kernel"])
+def gemm_kernel(request, nnmod):
+    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h), whatever the shape heuristics say."""
+    from vbnn_amd import _lib as L
+    L.check(L.lib().vbnn_debug_set(0, request.param))
+    yield request.param
+    L.check(L.lib().vbnn_debug_set(0, 0))
+
+
+@pytest.mark.parametrize("N,I,O", [(1, 8, 8), (37, 70, 50), (300, 200, 260), (512, 448, 384), (200, 4096, 130)])
+def test_bf16_gemm_exact_on_integers(nnmod, gemm_kernel, N, I, O):
+    """Layout / race screen: small-integer operands are exact in bf16 and their sums exact in fp32, so
+    y = x W^T + b, gradInput = g W and gradWeight = g^T x must equal the integer results EXACTLY, for both
+    bf16 kernels, on ragged shapes (asymmetric operands, so a transposed or permuted tile cannot pass)."""
+    rng = np.random.default_rng(N * 1000 + I)
+    W = rng.integers(-3, 4, (O, I)).astype(np.float32)
+    b = rng.integers(-5, 6, O).astype(np.float32)
+    x = rng.integers(-3, 4, (N, I)).astype(np.float32)
+    g = rng.integers(-2, 3, (N, O)).astype(np.float32)
+    m = nnmod.Linear(I, O, dict(dtype="bf16"))
+    m.weight.copy_(dev(W)); m.bias.copy_(dev(b))
+    for _ in range(3):                                   # repeated launches: a race would not repeat exactly
+        y = host(m.updateOutput(dev(x)))
+        assert np.array_equal(y, x @ W.T + b)
+        m.gradWeight.zero_(); m.gradBias.zero_()
+        gx = host(m.backward(dev(x), dev(g), 1.0))
+        assert np.array_equal(gx, g @ W)
+        assert np.array_equal(host(m.gradWeight), g.T @ x)
+        assert np.array_equal(host(m.gradBias), g.sum(axis=0))
 
 
 @pytest.mark.parametrize("N,I,O", [(3, 7, 5), (100, 130, 70), (256, 784, 400)])
-def test_layer_bf16_against_rounded_operands(nnmod, oracle, N, I, O):
+def test_layer_bf16_against_rounded_operands(nnmod, oracle, gemm_kernel, N, I, O):
     """bf16 MFMA path of one VBLinear (LRT) against float64 math on the SAME bf16-rounded operands
     (oracle/ref_numpy.py): only the fp32 accumulation order differs. atol 1e-3 * max|.|, as SURVEY 8c T2."""
     from oracle.ref_numpy import bf16_round as rb

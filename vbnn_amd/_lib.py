@@ -51,6 +51,7 @@ class DwArgs(C.Structure):
 _SIGS = {
     "vbnn_abi_version": ([], _i),
     "vbnn_last_error": ([], C.c_char_p),
+    "vbnn_debug_set": ([_i, _i], _i),
     "vbnn_ctx_create": ([_i, _vp, C.POINTER(_vp)], _i),
     "vbnn_ctx_destroy": ([_vp], _i),
     "vbnn_ctx_set_stream": ([_vp, _vp], _i),

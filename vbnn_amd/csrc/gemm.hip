@@ -6,10 +6,21 @@
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
+// 0 = choose by shape, 1 = always the general kernel (gemm_v1.h), 2 = the pipelined bf16 kernel
+// (gemm_v2.h) whenever the operands allow it. Test / A-B hook: vbnn_debug_set(VBNN_DEBUG_GEMM_KERNEL, ..).
+static int g_force_kernel = 0;
+
+extern "C" int vbnn_debug_set(int key, int value) {
+    if (key == VBNN_DEBUG_GEMM_KERNEL && value >= 0 && value <= 2) { g_force_kernel = value; return VBNN_OK; }
+    vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
+    return VBNN_ERR_INVALID;
+}
+
 template <typename T, bool DUAL, class Epi>
 static int launch_gemm(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda, const void* B, const void* B2,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, const Epi& epi) {
-    if (gemm_v2_eligible<T>(M, N, K, lda, ldb))
+    const bool v2_ok = gemm_v2_possible<T>(lda, ldb);
+    if (v2_ok && g_force_kernel != 1 && (g_force_kernel == 2 || gemm_v2_eligible<T>(M, N, K, lda, ldb)))
         return launch_gemm_v2<T, DUAL, Epi>(ctx->stream, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
                                             (int)M, (int)N, (int)K, epi);
     return launch_gemm_v1<T, DUAL, Epi>(ctx->stream, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,

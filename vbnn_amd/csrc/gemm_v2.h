@@ -1,10 +1,224 @@
-// gemm_v2.h -- pipelined bf16 MFMA GEMM (placeholder until the kernel lands).
+// gemm_v2.h -- the pipelined bf16 MFMA GEMM of the wide configurations (gfx950 only).
+//
+//   C1[m][n] = sum_k A[m][k] Bt[n][k]      and, when DUAL,      C2[m][n] = sum_k A2[m][k] Bt2[n][k]
+//
+// Structure (cdna_hip_programming.md section 5, "What does break it"): ~1 workgroup per CU, LDS
+// filled by LDS-DMA (global_load_lds_dwordx4) that stays in flight ACROSS the barrier, counted
+// s_waitcnt vmcnt(N), raw s_barrier, all LDS in one array.
+//
+//   workgroup   512 threads = 8 waves as 4 (M) x 2 (N); wave tile 64 x 64; block tile 256 x 128
+//   K step      64 bf16 = 128 B per row; A tile 32 KiB + B tile 16 KiB = 48 KiB per stage
+//   ring        3 stages (144 KiB of the CU's 160 KiB): loads run two tiles ahead of the MFMAs
+//   tile stream DUAL alternates the pairs: (A,B,k0) -> acc1, (A2,B2,k0) -> acc2, (A,B,k0+64) ...
+//               so the register cost of the second GEMM is only its accumulator
+//   MFMA        v_mfma_f32_16x16x32_bf16, 32 per wave per tile (4 x 4 output tiles x 2 k-halves)
+//   LDS image   lane-linear as the DMA writes it (8 rows x 128 B per wave-instruction); the bank
+//               swizzle chunk' = chunk ^ ((row >> 1) & 7) is applied on the per-lane SOURCE address
+//               and again on the ds_read_b128 address (rule 21: both sides or neither). With it the
+//               16 rows x 1 chunk a lane group reads fall on 16 distinct 16-byte bank slots.
+//   per tile    s_waitcnt vmcnt(6)  -> this wave's DMAs for tile u have landed (tile u+1's 6 may fly)
+//               s_barrier           -> everybody's have; everybody is done reading tile u-1
+//               issue DMAs of tile u+2 into the buffer tile u-1 occupied
+//               16 ds_read_b128 + 32 MFMA on tile u
+//
+// Any M, N >= 1 (row-clamped sources, masked epilogue); K is padded by the packed-operand
+// convention (ld % 64 == 0, zero fill).
 #pragma once
 #include "common.h"
+#include <type_traits>
+
+constexpr int V2_BM = 256, V2_BN = 128, V2_BK = 64;
+constexpr int V2_A_BYTES = V2_BM * V2_BK * 2;           // 32768
+constexpr int V2_B_BYTES = V2_BN * V2_BK * 2;           // 16384
+constexpr int V2_STAGE = V2_A_BYTES + V2_B_BYTES;       // 49152
+constexpr int V2_STAGES = 3;
+constexpr int V2_LDS = V2_STAGE * V2_STAGES;            // 147456
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool DUAL, class Epi>
+__global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
+                                                     const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
+                                                     int M, int N, int nk, int tiles_m, int tiles_n, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block -> tile mapping. Blocks that share an XCD (bid % 8, T1) get a contiguous chunk of
+    // the tile list; inside it tiles are walked in 4 (M) x 8 (N) groups so the ~32 blocks running
+    // together on an XCD share 4 A panels and 8 B panels in its L2.
+    const int nblk = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective remap
+    }
+    int tm, tn;
+    {
+        constexpr int GM = 4, GN = 8;
+        const int groups_n = (tiles_n + GN - 1) / GN;
+        const int per_band = GM * tiles_n;                // tiles in a band of GM tile-rows
+        const int band = bid / per_band;
+        const int in_band = bid - band * per_band;
+        const int band_rows = min(GM, tiles_m - band * GM);
+        // inside a band: groups of (band_rows x GN), the last group may be narrower
+        const int full = band_rows * GN;
+        int grp = in_band / full;
+        int in_grp = in_band - grp * full;
+        if (grp >= groups_n) { grp = groups_n - 1; in_grp = in_band - grp * full; }
+        const int grp_cols = min(GN, tiles_n - grp * GN);
+        tm = band * GM + in_grp / grp_cols;
+        tn = grp * GN + in_grp % grp_cols;
+        if (tm >= tiles_m) { tm = tiles_m - 1; }          // unreachable for consistent inputs; keeps loads in range
+    }
+    const int m0 = tm * V2_BM, n0 = tn * V2_BN;
+
+    // ---- LDS-DMA source pointers. A: 32 groups of 8 rows, 4 per wave; B: 16 groups, 2 per wave.
+    // Lane l of the instruction for group g fills LDS position (row 8g + (l>>3), chunk slot l&7) with
+    // global chunk (l&7) ^ f(row), f(row) = (row >> 1) & 7.
+    const bf16_t* a_src[2][4];
+    const bf16_t* b_src[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = wave + 8 * i;
+        const int row = 8 * g + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int64_t off = (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        a_src[0][i] = A + off;
+        a_src[1][i] = DUAL ? A2 + off : A + off;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int g = wave + 8 * i;
+        const int row = 8 * g + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int64_t off = (int64_t)min(n0 + row, N - 1) * ldb + chunk * 8;
+        b_src[0][i] = B + off;
+        b_src[1][i] = DUAL ? B2 + off : B + off;
+    }
+    const int U = DUAL ? 2 * nk : nk;       // tiles in the stream
+
+    // `pair` is a compile-time constant at every call site (the loop below is unrolled by the pair
+    // period), so the pointer arrays stay in registers (runtime-indexed arrays would go to scratch).
+    auto issue = [&](int u, auto pair_c) {
+        constexpr int P = decltype(pair_c)::value;
+        const int64_t koff = (int64_t)(DUAL ? (u >> 1) : u) * V2_BK;
+        unsigned char* base = lds + (u % V2_STAGES) * V2_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][i] + koff), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][i] + koff),
+                                             (lptr_t)(base + V2_A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets (bytes inside a stage). Lane reads row r = base + (l & 15), chunk
+    // c = 4s + (l >> 4) of k-half s; swizzled chunk = c ^ ((r >> 1) & 7). Row bases are multiples of 16,
+    // so (r >> 1) & 7 == ((l & 15) >> 1) for every fragment of the lane.
+    const int rsw = (lane & 15) >> 1;
+    const int q = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int csw = ((4 * s + q) ^ rsw) * 16;
+        a_off[s] = (wm * 64 + (lane & 15)) * 128 + csw;
+        b_off[s] = V2_A_BYTES + (wn * 64 + (lane & 15)) * 128 + csw;
+    }
+
+    f32x4 acc1[4][4], acc2[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto compute = [&](const unsigned char* stage, f32x4 (&acc)[4][4]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[s] + i * 16 * 128);
+                bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[s] + i * 16 * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    std::integral_constant<int, 0> c0;
+    std::integral_constant<int, 1> c1;
+
+    // ---- prologue: two tiles in flight
+    issue(0, c0);
+    if (U > 1) { if (DUAL) issue(1, c1); else issue(1, c0); }
+
+    auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
+        if (u + 1 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (u + 2 < U) issue(u + 2, pair_c);            // tile u+2 belongs to the same pair as tile u
+        compute(lds + (u % V2_STAGES) * V2_STAGE, acc);
+    };
+    if (DUAL) {
+        for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+    } else {
+        for (int u = 0; u < U; ++u) step(u, c0, acc1);
+    }
+
+    const int em = m0 + wm * 64 + (lane >> 4) * 4;
+    const int en = n0 + wn * 64 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi(em + i * 16, en + j * 16, acc1[i][j], acc2[i][j]);
+}
+
 template <typename T>
-static inline bool gemm_v2_eligible(int64_t, int64_t, int64_t, int64_t, int64_t) { return false; }
+static inline bool gemm_v2_possible(int64_t lda, int64_t ldb) {
+    return sizeof(T) == 2 && (lda % 64) == 0 && (ldb % 64) == 0;
+}
+template <typename T>
+static inline bool gemm_v2_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+    (void)K;
+    if (!gemm_v2_possible<T>(lda, ldb)) return false;
+    // worth it only when the 256 x 128 tiling gives the chip something like one block per CU
+    const int64_t tiles = ((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN);
+    return tiles >= 96;
+}
+
 template <typename T, bool DUAL, class Epi>
-static int launch_gemm_v2(hipStream_t, const T*, const T*, int64_t, const T*, const T*, int64_t, int, int, int, const Epi&) {
-    vbnn_set_error("gemm_v2 not built");
-    return VBNN_ERR_UNSUPPORTED;
+static int launch_gemm_v2(hipStream_t stream, const T* A, const T* A2, int64_t lda, const T* B, const T* B2, int64_t ldb,
+                          int M, int N, int K, const Epi& epi) {
+    if constexpr (sizeof(T) != 2) {
+        vbnn_set_error("gemm_v2 is bf16 only");
+        return VBNN_ERR_UNSUPPORTED;
+    } else {
+        if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15u) != 0) {
+            vbnn_set_error("gemm_v2 operands must be 16-byte aligned");
+            return VBNN_ERR_INVALID;
+        }
+        const int nk = (K + V2_BK - 1) / V2_BK;
+        if (lda < (int64_t)nk * V2_BK || ldb < (int64_t)nk * V2_BK) {
+            vbnn_set_error("packed leading dimension too small for K=%d", K);
+            return VBNN_ERR_INVALID;
+        }
+        const int tiles_m = (M + V2_BM - 1) / V2_BM, tiles_n = (N + V2_BN - 1) / V2_BN;
+        auto kern = gemm_nt_v2<DUAL, Epi>;
+        static bool configured = false;                  // one flag per instantiation
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+            if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+            configured = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), V2_LDS, stream, (const bf16_t*)A, (const bf16_t*)A2, lda,
+                           (const bf16_t*)B, (const bf16_t*)B2, ldb, M, N, nk, tiles_m, tiles_n, epi);
+        return vbnn_check_launch("gemm_nt_v2");
+    }
 }
