@@ -48,6 +48,7 @@ const char* vbnn_last_error(void);
 /* test / A-B hook. VBNN_DEBUG_GEMM_KERNEL: 0 = pick by shape (default), 1 = always the general MFMA
  * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it. */
 #define VBNN_DEBUG_GEMM_KERNEL 0
+#define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel schedule 0..3, see gemm_v2.h (default 2) */
 int vbnn_debug_set(int key, int value);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
@@ -211,6 +212,21 @@ int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx,
 int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const int32_t* target,
                         int64_t N, int64_t C, float inv_n, float* out, float* g_logits,
                         double* loss_sum_dev, int32_t* correct_dev);
+
+/* mlp.lua:29-32 fused for a small class count (C <= 16): final nn.Linear + nn.LogSoftMax +
+ * nn.ClassNLLCriterion as streaming kernels over the packed N x H activation `h` (dtype) and the packed
+ * final weight `w3` (C x ld_w, dtype). Forward: logits = h w3^T + bias, out = logsoftmax, loss / accuracy
+ * accumulated as in vbnn_logsoftmax_nll, g_logits = d(loss)/d(logits) (N x C f32). `logits`, `out` optional. */
+int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
+                      const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
+                      float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev);
+/* Backward of the same head: gradWeight (C x H) / gradBias (C) of the final Linear (accumulate as in
+ * vbnn_acc_grad_parameters; NULL to skip), and its gradInput pushed through the ReLU straight into the last
+ * VB layer's packed gradient operands (same meaning as the hand-off fields of vbnn_dx_args). */
+int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
+                       const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
+                       float* gradBias, int relu_mask, const float* r_prev, int64_t ld_r_prev, void* g_prev,
+                       void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT);
 
 /* The same criterion as separate modules, for the module-level call order of mlp.lua:77-80:
  * nn.LogSoftMax:updateOutput is vbnn_logsoftmax_nll with g_logits = loss = correct = NULL. */

@@ -32,7 +32,7 @@ extern "C" int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out) {
     c->device = device;
     c->own_stream = false;
     c->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
-    c->scratch_doubles = 8192;
+    c->scratch_doubles = 1u << 20;       // 8 MiB: block partials of the reductions
     hipError_t e = hipMalloc((void**)&c->scratch, c->scratch_doubles * sizeof(double));
     if (e != hipSuccess) { delete c; vbnn_set_error("hipMalloc(scratch): %s", hipGetErrorString(e)); return VBNN_ERR_NOMEM; }
     *out = c;

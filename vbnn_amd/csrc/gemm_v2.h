@@ -34,10 +34,34 @@ constexpr int V2_STAGE = V2_A_BYTES + V2_B_BYTES;       // 49152
 constexpr int V2_STAGES = 3;
 constexpr int V2_LDS = V2_STAGE * V2_STAGES;            // 147456
 
+// Diagnostic stamps (tools/gemm_lab.hip builds with -DV2_DIAG; the library never does): per-wave cycle
+// sums of the segments of schedule 0, written to a buffer of their own, never to an output.
+#ifdef V2_DIAG
+__device__ unsigned long long* g_v2_diag = nullptr;
+#define V2_STAMP_DECL unsigned long long v2_t[5] = {0, 0, 0, 0, 0}, v2_sum[4] = {0, 0, 0, 0};
+#define V2_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v2_t[i])::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if ((i) > 0) v2_sum[(i)-1] += v2_t[i] - v2_t[(i)-1];                                          \
+    } while (0)
+#define V2_STAMP_FLUSH                                                                                \
+    if (g_v2_diag && lane == 0) {                                                                     \
+        for (int k = 0; k < 4; ++k) g_v2_diag[((size_t)blockIdx.x * 8 + wave) * 4 + k] = v2_sum[k];   \
+    }
+#else
+#define V2_STAMP_DECL
+#define V2_STAMP(i)
+#define V2_STAMP_FLUSH
+#endif
+
+static int g_v2_sched = 2;        // 0: burst DMAs after the barrier; 1: staggered wave groups; 2: DMAs interleaved with the MFMAs (default); 3: 2 + fragment prefetch (vbnn_debug_set key 1)
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <bool DUAL, class Epi>
+template <bool DUAL, int SCHED, class Epi>
 __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                      const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
                                                      int M, int N, int nk, int tiles_m, int tiles_n, Epi epi) {
@@ -103,17 +127,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
 
     // `pair` is a compile-time constant at every call site (the loop below is unrolled by the pair
     // period), so the pointer arrays stay in registers (runtime-indexed arrays would go to scratch).
-    auto issue = [&](int u, auto pair_c) {
+    auto issue_part = [&](int u, auto pair_c, auto part_c) {
         constexpr int P = decltype(pair_c)::value;
+        constexpr int PART = decltype(part_c)::value;     // 0: A groups 0-2, 1: A group 3 + both B groups, 2: all six
         const int64_t koff = (int64_t)(DUAL ? (u >> 1) : u) * V2_BK;
         unsigned char* base = lds + (u % V2_STAGES) * V2_STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][i] + koff), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+            if (PART == 2 || (PART == 0) == (i < 3))
+                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][i] + koff), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+        if (PART != 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][i] + koff),
-                                             (lptr_t)(base + V2_A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][i] + koff),
+                                                 (lptr_t)(base + V2_A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int u, auto pair_c) { issue_part(u, pair_c, std::integral_constant<int, 2>()); };
+    auto issue_one = [&](int u, auto pair_c, auto idx_c) {      // DMA number IDX (0-3: A groups, 4-5: B groups) of tile u
+        constexpr int P = decltype(pair_c)::value;
+        constexpr int IDX = decltype(idx_c)::value;
+        const int64_t koff = (int64_t)(DUAL ? (u >> 1) : u) * V2_BK;
+        unsigned char* base = lds + (u % V2_STAGES) * V2_STAGE;
+        if constexpr (IDX < 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + 8 * IDX) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][IDX - 4] + koff),
+                                             (lptr_t)(base + V2_A_BYTES + (wave + 8 * (IDX - 4)) * 1024), 16, 0, 0);
     };
 
     // ---- fragment read offsets (bytes inside a stage). Lane reads row r = base + (l & 15), chunk
@@ -154,24 +194,177 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
 
     std::integral_constant<int, 0> c0;
     std::integral_constant<int, 1> c1;
+    V2_STAMP_DECL
 
     // ---- prologue: two tiles in flight
     issue(0, c0);
     if (U > 1) { if (DUAL) issue(1, c1); else issue(1, c0); }
 
-    auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
-        if (u + 1 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (u + 2 < U) issue(u + 2, pair_c);            // tile u+2 belongs to the same pair as tile u
-        compute(lds + (u % V2_STAGES) * V2_STAGE, acc);
-    };
-    if (DUAL) {
-        for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+    if constexpr (SCHED == 0) {
+        // ---- schedule 0: one barrier per tile, every wave reads then multiplies
+        auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
+            V2_STAMP(0);
+            if (u + 1 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            V2_STAMP(1);                                     // [0->1] waiting for this wave's DMAs
+            __builtin_amdgcn_s_barrier();
+            V2_STAMP(2);                                     // [1->2] barrier
+            if (u + 2 < U) issue(u + 2, pair_c);            // tile u+2 belongs to the same pair as tile u
+            V2_STAMP(3);                                     // [2->3] issuing 6 DMAs
+            compute(lds + (u % V2_STAGES) * V2_STAGE, acc);
+            V2_STAMP(4);                                     // [3->4] 16 ds_read_b128 + 32 MFMA
+        };
+        if (DUAL) {
+            for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+        } else {
+            for (int u = 0; u < U; ++u) step(u, c0, acc1);
+        }
+    } else if constexpr (SCHED == 2) {
+        // ---- schedule 2: one barrier per tile as schedule 0, but the six DMAs of tile u+2 are spread through the
+        // MFMA stream of tile u (one after every 5-6 MFMAs) instead of bursting after the barrier: the texture path
+        // (64 B/clk/CU) then works beside the matrix pipe instead of in front of it.
+        auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
+            if (u + 1 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* stage = lds + (u % V2_STAGES) * V2_STAGE;
+            const bool more = u + 2 < U;
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                bf16x8 af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
+                    bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    if (more) {
+                        if (sidx == 0 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
+                        if (sidx == 0 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
+                        if (sidx == 0 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
+                        if (sidx == 1 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
+                        if (sidx == 1 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
+                        if (sidx == 1 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // keep each DMA behind its four MFMAs
+                }
+            }
+        };
+        if (DUAL) {
+            for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+        } else {
+            for (int u = 0; u < U; ++u) step(u, c0, acc1);
+        }
+    } else if constexpr (SCHED == 3) {
+        // ---- schedule 3 (= 2 with both k-halves' fragments read up front and s_setprio around the MFMAs): one barrier per tile as schedule 0, but the six DMAs of tile u+2 are spread through the
+        // MFMA stream of tile u (one after every 5-6 MFMAs) instead of bursting after the barrier: the texture path
+        // (64 B/clk/CU) then works beside the matrix pipe instead of in front of it.
+        auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
+            if (u + 1 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* stage = lds + (u % V2_STAGES) * V2_STAGE;
+            const bool more = u + 2 < U;
+            bf16x8 afr[2][4], bfr[2][4];
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    afr[sidx][i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
+                    bfr[sidx][i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
+                }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[sidx][i], bfr[sidx][j], acc[i][j], 0, 0, 0);
+                    if (more) {
+                        if (sidx == 0 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
+                        if (sidx == 0 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
+                        if (sidx == 0 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
+                        if (sidx == 1 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
+                        if (sidx == 1 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
+                        if (sidx == 1 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // keep each DMA behind its four MFMAs
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        if (DUAL) {
+            for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+        } else {
+            for (int u = 0; u < U; ++u) step(u, c0, acc1);
+        }
     } else {
-        for (int u = 0; u < U; ++u) step(u, c0, acc1);
+        // ---- schedule 1: the two waves of a SIMD (w and w + 4) run one barrier apart, so one reads LDS
+        // while the other owns the matrix pipe (MI355X_MICROARCH.md "Two waves per SIMD", item 9; the
+        // `if (wr == 1) s_barrier` of the 8-phase template). A tile is four slots:
+        //   READ(k-half 0) | MFMA(0) | READ(1) | MFMA(1),   16 MFMA per slot, a barrier after each.
+        // Early waves (0-3) are in slot 4u when late waves (4-7) are in slot 4u - 1.
+        // RAW: every wave waits for its DMAs of tile u+1 before the barrier that opens slot 4u+4
+        //      (early waves: their 4th barrier of tile u; late waves: their 3rd).
+        // WAR: reads are retired (lgkmcnt(0)) before the barrier that closes their slot, and tile u+2 is
+        //      issued into tile u-1's buffer at the top of tile u, after every read of tile u-1.
+        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+        auto read_half = [&](const unsigned char* stage, int sidx, bf16x8 (&af)[4], bf16x8 (&bf)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
+                bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfma_half = [&](const bf16x8 (&af)[4], const bf16x8 (&bf)[4], f32x4 (&acc)[4][4]) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto wait_next = [&](int u) {                        // DMAs of tile u+1 (tile u+2's may stay in flight)
+            if (u + 2 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        if (U > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (late) __builtin_amdgcn_s_barrier();              // the stagger
+        auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
+            const unsigned char* stage = lds + (u % V2_STAGES) * V2_STAGE;
+            bf16x8 af[4], bf[4];
+            if (u + 2 < U) issue_part(u + 2, pair_c, std::integral_constant<int, 0>());   // 3 DMAs per READ slot
+            read_half(stage, 0, af, bf);
+            __builtin_amdgcn_s_barrier();
+            mfma_half(af, bf, acc);
+            __builtin_amdgcn_s_barrier();
+            if (u + 2 < U) issue_part(u + 2, pair_c, std::integral_constant<int, 1>());
+            read_half(stage, 1, af, bf);
+            if (late) wait_next(u);
+            __builtin_amdgcn_s_barrier();
+            mfma_half(af, bf, acc);
+            if (!late) wait_next(u);
+            __builtin_amdgcn_s_barrier();
+        };
+        if (DUAL) {
+            for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+        } else {
+            for (int u = 0; u < U; ++u) step(u, c0, acc1);
+        }
+        if (!late) __builtin_amdgcn_s_barrier();             // early waves take the barrier the late ones took up front
     }
 
+    V2_STAMP_FLUSH
     const int em = m0 + wm * 64 + (lane >> 4) * 4;
     const int en = n0 + wn * 64 + (lane & 15);
 #pragma unroll
@@ -210,12 +403,12 @@ static int launch_gemm_v2(hipStream_t stream, const T* A, const T* A2, int64_t l
             return VBNN_ERR_INVALID;
         }
         const int tiles_m = (M + V2_BM - 1) / V2_BM, tiles_n = (N + V2_BN - 1) / V2_BN;
-        auto kern = gemm_nt_v2<DUAL, Epi>;
-        static bool configured = false;                  // one flag per instantiation
-        if (!configured) {
+        auto kern = (g_v2_sched == 0) ? gemm_nt_v2<DUAL, 0, Epi> : (g_v2_sched == 1) ? gemm_nt_v2<DUAL, 1, Epi> : (g_v2_sched == 2) ? gemm_nt_v2<DUAL, 2, Epi> : gemm_nt_v2<DUAL, 3, Epi>;
+        static bool configured[4] = {false, false, false, false};      // per instantiation of this launcher
+        if (!configured[g_v2_sched]) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
-            configured = true;
+            configured[g_v2_sched] = true;
         }
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), V2_LDS, stream, (const bf16_t*)A, (const bf16_t*)A2, lda,
                            (const bf16_t*)B, (const bf16_t*)B2, ldb, M, N, nk, tiles_m, tiles_n, epi);

@@ -161,6 +161,31 @@ class FusedMLP:
                                       v.mu_s.ptr, v.mu_s.ld, v.muT_s.ptr if v.muT_s else None,
                                       v.muT_s.ld if v.muT_s else 0))
 
+    # ---- final Linear + criterion through the generic GEMM kernels (class counts above 16)
+    def _generic_head(self, N, targets, inv_n, accumulate):
+        lib, ctx, code = L.lib(), self.ctx.h, self.code
+        lrt = self.mode == "lrt"
+        H, Cn = self.sizes[-1], self.n_classes
+        a = L.FwdArgs(w=self.w3_s.ptr, w2=None, x=self.h_s.ptr, x2=None, ld_w=self.w3_s.ld, ld_x=self.h_s.ld,
+                      N=N, I=H, O=Cn, bias=_p(self.bias3), y=_p(self.logits), ld_y=Cn)
+        L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
+        L.check(lib.vbnn_logsoftmax_nll(ctx, _p(self.logits), Cn, _p(targets), N, Cn, inv_n, _p(self.out),
+                                        _p(self.g_logits), _p(self._acc), _p(self._corr)))
+        L.check(lib.vbnn_pack(ctx, code, L.PACK_COPY, _p(self.g_logits), None, Cn, N, Cn, self.g3_s.ptr, self.g3_s.ld,
+                              self.g3T_s.ptr, self.g3T_s.ld))
+        d = L.DwArgs(xT=self.hT_s.ptr, x2T=None, gT=self.g3T_s.ptr, gvT=None, ld_n=self.hT_s.ld, N=N, I=H, O=Cn,
+                     scale=1.0, accumulate=accumulate, gradWeight=_p(self.gradWeight3), gradSum=None)
+        L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+        L.check(lib.vbnn_acc_grad_bias(ctx, L.F32, _p(self.g_logits), Cn, N, Cn, 1.0, accumulate, _p(self.gradBias3)))
+        self._reduce(self.bucket3)
+        vl = self.vb[-1]
+        dx = L.DxArgs(wT=self.w3T_s.ptr, w2T=None, g=self.g3_s.ptr, gv=None, ld_wT=self.w3T_s.ld, ld_g=self.g3_s.ld,
+                      N=N, I=H, O=Cn, x=self.h_s.ptr, ld_x=self.h_s.ld, gx=None, ld_gx=0, relu_mask=1,
+                      r_prev=_p(vl.r) if lrt else None, ld_r_prev=vl.O, g_prev=vl.g_s.ptr,
+                      gv_prev=vl.gv_s.ptr if lrt else None, ld_gp=vl.g_s.ld, gT_prev=vl.gT_s.ptr,
+                      gvT_prev=vl.gvT_s.ptr if lrt else None, ld_gpT=vl.gT_s.ld)
+        L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
+
     # ---- argument blocks of the three GEMM families for VB layer `li` (also used by bench.py to time
     # exactly the launches of the step in isolation)
     def _fwd_args(self, li, N, row0):
@@ -174,7 +199,7 @@ class FusedMLP:
                          h=self.h_s.ptr if last else nxt.x_s.ptr,
                          h2=None if (last or not lrt) else nxt.x2_s.ptr,
                          ld_h=self.h_s.ld if last else nxt.x_s.ld,
-                         hT=self.hT_s.ptr if last else nxt.xT_s.ptr,
+                         hT=(None if self.n_classes <= 16 else self.hT_s.ptr) if last else nxt.xT_s.ptr,
                          h2T=None if (last or not lrt) else nxt.x2T_s.ptr,
                          ld_hT=self.hT_s.ld if last else nxt.xT_s.ld)
 
@@ -225,27 +250,20 @@ class FusedMLP:
             a = self._fwd_args(li, N, row0)
             L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
         H, Cn = self.sizes[-1], self.n_classes
-        a = L.FwdArgs(w=self.w3_s.ptr, w2=None, x=self.h_s.ptr, x2=None, ld_w=self.w3_s.ld, ld_x=self.h_s.ld,
-                      N=N, I=H, O=Cn, bias=_p(self.bias3), y=_p(self.logits), ld_y=Cn)
-        L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
-        # ---------------- criterion (LogSoftMax + ClassNLL forward/backward, accuracy)
-        L.check(lib.vbnn_logsoftmax_nll(ctx, _p(self.logits), Cn, _p(targets), N, Cn, inv_n, _p(self.out),
-                                        _p(self.g_logits), _p(self._acc), _p(self._corr)))
-        # ---------------- backward: final Linear
-        L.check(lib.vbnn_pack(ctx, code, L.PACK_COPY, _p(self.g_logits), None, Cn, N, Cn, self.g3_s.ptr, self.g3_s.ld,
-                              self.g3T_s.ptr, self.g3T_s.ld))
-        d = L.DwArgs(xT=self.hT_s.ptr, x2T=None, gT=self.g3T_s.ptr, gvT=None, ld_n=self.hT_s.ld, N=N, I=H, O=Cn,
-                     scale=1.0, accumulate=accumulate, gradWeight=_p(self.gradWeight3), gradSum=None)
-        L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
-        L.check(lib.vbnn_acc_grad_bias(ctx, L.F32, _p(self.g_logits), Cn, N, Cn, 1.0, accumulate, _p(self.gradBias3)))
-        self._reduce(self.bucket3)
         vl = self.vb[-1]
-        dx = L.DxArgs(wT=self.w3T_s.ptr, w2T=None, g=self.g3_s.ptr, gv=None, ld_wT=self.w3T_s.ld, ld_g=self.g3_s.ld,
-                      N=N, I=H, O=Cn, x=self.h_s.ptr, ld_x=self.h_s.ld, gx=None, ld_gx=0, relu_mask=1,
-                      r_prev=_p(vl.r) if lrt else None, ld_r_prev=vl.O, g_prev=vl.g_s.ptr,
-                      gv_prev=vl.gv_s.ptr if lrt else None, ld_gp=vl.g_s.ld, gT_prev=vl.gT_s.ptr,
-                      gvT_prev=vl.gvT_s.ptr if lrt else None, ld_gpT=vl.gT_s.ld)
-        L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
+        if Cn <= 16:
+            # ---------------- fused classifier head (mlp.lua:29-32): streaming kernels, no 10-wide MFMA tiles
+            L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
+                                          _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
+                                          _p(self.g_logits), _p(self._acc), _p(self._corr)))
+            L.check(lib.vbnn_head_backward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
+                                           _p(self.g_logits), N, H, Cn, accumulate, _p(self.gradWeight3),
+                                           _p(self.gradBias3), 1, _p(vl.r) if lrt else None, vl.O, vl.g_s.ptr,
+                                           vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr,
+                                           vl.gvT_s.ptr if lrt else None, vl.gT_s.ld))
+            self._reduce(self.bucket3)
+        else:
+            self._generic_head(N, targets, inv_n, accumulate)
         # ---------------- backward: VB layers, last to first
         for li in range(nl - 1, -1, -1):
             v = self.vb[li]
