@@ -94,3 +94,27 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, floa
         if (valid > 3) p[3] = (bf16_t)d;
     }
 }
+
+// load 4 consecutive elements as floats (p 4-element aligned when `vec` is true); lanes past `valid` read 0
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&v)[4], int valid, bool vec);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float (&v)[4], int valid, bool vec) {
+    if (vec && valid == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (j < valid) ? p[j] : 0.f;
+    }
+}
+template <>
+__device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4], int valid, bool vec) {
+    if (vec && valid == 4) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (j < valid) ? (float)p[j] : 0.f;
+    }
+}

@@ -362,7 +362,7 @@ extern "C" int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64
     const int64_t cap = (int64_t)(ctx->scratch_doubles * 2) / O;      // partial rows that fit the scratch (floats)
     VBNN_REQUIRE(cap >= 1, "outputSize too large for the reduction scratch");
     int64_t R = (N + 31) / 32;
-    if (R > 128) R = 128;
+    if (R > 32) R = 32;
     if (R > cap) R = cap;
     const int rows_per_chunk = (int)((N + R - 1) / R);
     R = (N + rows_per_chunk - 1) / rows_per_chunk;
@@ -596,277 +596,3 @@ extern "C" int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, con
     VBNN_API_END
 }
 
-// ================================================================================== classifier head
-// mlp.lua:29-32 fused: final nn.Linear (H -> C, C <= 16) + nn.LogSoftMax + nn.ClassNLLCriterion.
-// With C = 10 these are skinny, HBM-bound passes over the N x H activation, not GEMM-shaped work:
-// they get their own streaming kernels instead of 10/64-full MFMA tiles.
-constexpr int HEAD_CMAX = 16;
-
-template <typename T> struct Chunk;                        // 16 bytes of packed operand
-template <> struct Chunk<float> { static constexpr int E = 4; typedef f32x4 vec; };
-template <> struct Chunk<bf16_t> { static constexpr int E = 8; typedef bf16x8 vec; };
-
-// ---- forward + criterion: one wave owns 4 rows; lanes stride the H dimension in 16-byte chunks, the
-// weight chunk is loaded once and used for the 4 rows; 4 x C dot products are reduced across the wave,
-// then lane r finishes row r (log-softmax, loss, arg-max, d(loss)/d(logits)).
-template <typename T>
-__global__ __launch_bounds__(256) void k_head_forward(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
-                                                      const float* __restrict__ bias, const int32_t* __restrict__ target, int64_t N,
-                                                      int64_t H, int C, float inv_n, float* out, float* g_logits, float* logits,
-                                                      double* loss_sum, int32_t* correct) {
-    constexpr int E = Chunk<T>::E;
-    typedef typename Chunk<T>::vec vec;
-    const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (row0 >= N) return;
-    float acc[4][HEAD_CMAX];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < HEAD_CMAX; ++c) acc[r][c] = 0.f;
-    const T* hp[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hp[r] = h + min(row0 + r, N - 1) * ld_h;
-    const int64_t Hp = (H + E - 1) / E * E;                 // pads are zero (packed-operand convention)
-    for (int64_t i = (int64_t)lane * E; i < Hp; i += 64 * E) {
-        vec hv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = *reinterpret_cast<const vec*>(hp[r] + i);
-#pragma unroll
-        for (int c = 0; c < HEAD_CMAX; ++c) {
-            if (c < C) {
-                const vec wv = *reinterpret_cast<const vec*>(w3 + (int64_t)c * ld_w + i);
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const float w = Elt<T>::from(wv[e]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r][c] = fmaf(Elt<T>::from(hv[r][e]), w, acc[r][c]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < HEAD_CMAX; ++c)
-            if (c < C) {
-                float v = acc[r][c];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                acc[r][c] = v;
-            }
-    // lane r finishes row r
-    double loss_acc = 0.0;
-    int corr = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (lane == r && row0 + r < N) {
-            const int64_t n = row0 + r;
-            float lg[HEAD_CMAX];
-            float mx = -INFINITY; int arg = 0;
-#pragma unroll
-            for (int c = 0; c < HEAD_CMAX; ++c)
-                if (c < C) { lg[c] = acc[r][c] + (bias ? bias[c] : 0.f); if (lg[c] > mx) { mx = lg[c]; arg = c; } }
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < HEAD_CMAX; ++c) if (c < C) s += expf(lg[c] - mx);
-            const float lse = mx + logf(s);
-            const int t = min(max(target[n], 0), C - 1);
-#pragma unroll
-            for (int c = 0; c < HEAD_CMAX; ++c)
-                if (c < C) {
-                    const float o = lg[c] - lse;
-                    if (logits) logits[n * C + c] = lg[c];
-                    if (out) out[n * C + c] = o;
-                    g_logits[n * C + c] = (expf(o) - (c == t ? 1.0f : 0.0f)) * inv_n;
-                    if (c == t) loss_acc -= (double)o * (double)inv_n;
-                }
-            corr += (arg == t) ? 1 : 0;
-        }
-    }
-    // lanes 0..3 hold the four rows' contributions
-    loss_acc += __shfl_xor(loss_acc, 1, 64); loss_acc += __shfl_xor(loss_acc, 2, 64);
-    corr += __shfl_xor(corr, 1, 64); corr += __shfl_xor(corr, 2, 64);
-    if (lane == 0) {
-        if (loss_sum) atomicAdd(loss_sum, loss_acc);
-        if (correct && corr) atomicAdd(correct, corr);
-    }
-}
-
-// ---- gradWeight3 / gradBias3, stage 1: block (column chunk of 512, row chunk): each thread owns 2 columns
-// and C accumulators each; g rows are staged in LDS and broadcast.
-template <typename T>
-__global__ __launch_bounds__(256) void k_head_dw_partial(const T* __restrict__ h, int64_t ld_h, const float* __restrict__ g,
-                                                         int64_t N, int64_t H, int C, int rows_per_chunk,
-                                                         float* __restrict__ partial /* [R][C][H] */,
-                                                         float* __restrict__ partial_b /* [R][C] */) {
-    __shared__ float gs[64][HEAD_CMAX];
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    const int64_t n0 = (int64_t)blockIdx.y * rows_per_chunk, n1 = min(N, n0 + rows_per_chunk);
-    float acc0[HEAD_CMAX], acc1[HEAD_CMAX], accb = 0.f;
-#pragma unroll
-    for (int c = 0; c < HEAD_CMAX; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
-    for (int64_t nb = n0; nb < n1; nb += 64) {
-        const int rows = (int)min((int64_t)64, n1 - nb);
-        __syncthreads();
-        for (int k = threadIdx.x; k < rows * C; k += 256) {
-            const int rr = k / C, cc = k - rr * C;
-            gs[rr][cc] = Elt<T>::from(Elt<T>::to(g[(nb + rr) * C + cc]));      // the GEMM operand rounding of the packed path
-        }
-        __syncthreads();
-        if (i < H) {
-            for (int rr = 0; rr < rows; ++rr) {
-                const T* hp = h + (nb + rr) * ld_h + i;
-                const float h0 = Elt<T>::from(hp[0]);
-                const float h1 = (i + 1 < H) ? Elt<T>::from(hp[1]) : 0.f;
-#pragma unroll
-                for (int c = 0; c < HEAD_CMAX; ++c)
-                    if (c < C) { const float gv = gs[rr][c]; acc0[c] = fmaf(gv, h0, acc0[c]); acc1[c] = fmaf(gv, h1, acc1[c]); }
-            }
-        }
-        if (blockIdx.x == 0 && threadIdx.x < C)
-            for (int rr = 0; rr < rows; ++rr) accb += g[(nb + rr) * C + threadIdx.x];
-    }
-    if (i < H) {
-#pragma unroll
-        for (int c = 0; c < HEAD_CMAX; ++c)
-            if (c < C) {
-                float* p = partial + ((int64_t)blockIdx.y * C + c) * H + i;
-                p[0] = acc0[c];
-                if (i + 1 < H) p[1] = acc1[c];
-            }
-    }
-    if (blockIdx.x == 0 && threadIdx.x < C) partial_b[(int64_t)blockIdx.y * C + threadIdx.x] = accb;
-}
-__global__ __launch_bounds__(256) void k_head_dw_finish(const float* __restrict__ partial, const float* __restrict__ partial_b, int R,
-                                                        int64_t H, int C, int accumulate, float* gradWeight, float* gradBias) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over C * H
-    if (k < (int64_t)C * H) {
-        float tot = 0.f;
-        for (int r = 0; r < R; ++r) tot += partial[(int64_t)r * C * H + k];
-        gradWeight[k] = (accumulate ? gradWeight[k] : 0.f) + tot;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < C && gradBias) {
-        float tot = 0.f;
-        for (int r = 0; r < R; ++r) tot += partial_b[r * C + threadIdx.x];
-        gradBias[threadIdx.x] = (accumulate ? gradBias[threadIdx.x] : 0.f) + tot;
-    }
-}
-
-// ---- gradInput of the final Linear through the ReLU into the last VB layer's gradient operands:
-//   gx[n][i] = sum_c g[n][c] w3[c][i];  g_prev = gx . [h > 0];  gv_prev = g_prev . r
-// 64 x 64 tile per block, transposes through LDS so all four outputs are written in full segments.
-template <typename T>
-__global__ __launch_bounds__(256) void k_head_dx(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
-                                                 const float* __restrict__ g, int64_t N, int64_t H, int C, int relu_mask,
-                                                 const float* __restrict__ r_prev, int64_t ld_r, T* g_prev, T* gv_prev, int64_t ld_gp,
-                                                 T* gT_prev, T* gvT_prev, int64_t ld_gpT) {
-    __shared__ float tg[64][65];
-    __shared__ float tv[64][65];
-    __shared__ float gs[64][HEAD_CMAX];
-    __shared__ float ws[HEAD_CMAX][64];
-    const int64_t tiles_c = (H + 63) / 64;
-    const int64_t r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int k = threadIdx.x; k < 64 * C; k += 256) {
-        const int rr = k / C, cc = k - rr * C;
-        gs[rr][cc] = (r0 + rr < N) ? Elt<T>::from(Elt<T>::to(g[(r0 + rr) * C + cc])) : 0.f;
-        const int wc = k / 64, wi = k - wc * 64;
-        ws[wc][wi] = (c0 + wi < H) ? Elt<T>::from(w3[(int64_t)wc * ld_w + c0 + wi]) : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int rr = ty; rr < 64; rr += 4) {
-        const int64_t n = r0 + rr, i = c0 + tx;
-        float gp = 0.f, gvp = 0.f;
-        if (n < N && i < H) {
-            float gx = 0.f;
-#pragma unroll
-            for (int c = 0; c < HEAD_CMAX; ++c) if (c < C) gx = fmaf(gs[rr][c], ws[c][tx], gx);
-            const float hv = Elt<T>::from(h[n * ld_h + i]);
-            gp = (relu_mask && !(hv > 0.f)) ? 0.f : gx;
-            gvp = r_prev ? gp * r_prev[n * ld_r + i] : 0.f;
-            if (g_prev) g_prev[n * ld_gp + i] = Elt<T>::to(gp);
-            if (gv_prev) gv_prev[n * ld_gp + i] = Elt<T>::to(gvp);
-        }
-        tg[rr][tx] = gp; tv[rr][tx] = gvp;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int cc = ty; cc < 64; cc += 4) {
-        const int64_t i = c0 + cc, n = r0 + tx;
-        if (i < H && n < N) {
-            if (gT_prev) gT_prev[i * ld_gpT + n] = Elt<T>::to(tg[tx][cc]);
-            if (gvT_prev) gvT_prev[i * ld_gpT + n] = Elt<T>::to(tv[tx][cc]);
-        }
-    }
-}
-
-extern "C" int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
-                                 const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
-                                 float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev) {
-    VBNN_API_BEGIN
-    VBNN_REQUIRE(ctx && h && w3 && target && g_logits, "null argument");
-    VBNN_REQUIRE(N > 0 && H > 0 && C > 0 && C <= HEAD_CMAX, "shape (C <= 16)");
-    VBNN_REQUIRE(ld_h >= H && ld_w >= H && ld_h % 8 == 0 && ld_w % 8 == 0, "packed leading dimensions");
-    VBNN_REQUIRE((((uintptr_t)h | (uintptr_t)w3) & 15u) == 0, "operands must be 16-byte aligned");
-    const unsigned nb = (unsigned)((N + 15) / 16);
-    if (dtype == VBNN_F32)
-        hipLaunchKernelGGL(k_head_forward<float>, dim3(nb), dim3(256), 0, ctx->stream, (const float*)h, ld_h, (const float*)w3,
-                           ld_w, bias, target, N, H, (int)C, inv_n, out, g_logits, logits, loss_sum_dev, correct_dev);
-    else if (dtype == VBNN_BF16)
-        hipLaunchKernelGGL(k_head_forward<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, (const bf16_t*)h, ld_h,
-                           (const bf16_t*)w3, ld_w, bias, target, N, H, (int)C, inv_n, out, g_logits, logits, loss_sum_dev,
-                           correct_dev);
-    else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
-    return vbnn_check_launch("k_head_forward");
-    VBNN_API_END
-}
-
-extern "C" int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
-                                  const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
-                                  float* gradBias, int relu_mask, const float* r_prev, int64_t ld_r_prev, void* g_prev,
-                                  void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT) {
-    VBNN_API_BEGIN
-    VBNN_REQUIRE(ctx && h && w3 && g_logits, "null argument");
-    VBNN_REQUIRE(N > 0 && H > 0 && C > 0 && C <= HEAD_CMAX, "shape (C <= 16)");
-    VBNN_REQUIRE(ld_h >= H && ld_w >= H, "leading dimensions");
-    VBNN_REQUIRE(!gv_prev || (g_prev && r_prev), "gv_prev needs g_prev and r_prev");
-    VBNN_REQUIRE(!(g_prev || gv_prev) || ld_gp >= H, "ld_gp");
-    VBNN_REQUIRE(!(gT_prev || gvT_prev) || ld_gpT >= N, "ld_gpT");
-    if (gradWeight) {
-        const int64_t cap = (int64_t)(ctx->scratch_doubles * 2) / (C * H + C);
-        VBNN_REQUIRE(cap >= 1, "hidden size too large for the reduction scratch");
-        int64_t R = (N + 127) / 128;
-        if (R > 64) R = 64;
-        if (R > cap) R = cap;
-        const int rows_per_chunk = (int)((N + R - 1) / R);
-        R = (N + rows_per_chunk - 1) / rows_per_chunk;
-        float* partial = reinterpret_cast<float*>(ctx->scratch);
-        float* partial_b = partial + R * C * H;
-        const dim3 grid((unsigned)((H + 511) / 512), (unsigned)R);
-        if (dtype == VBNN_F32)
-            hipLaunchKernelGGL(k_head_dw_partial<float>, grid, dim3(256), 0, ctx->stream, (const float*)h, ld_h, g_logits, N, H,
-                               (int)C, rows_per_chunk, partial, partial_b);
-        else if (dtype == VBNN_BF16)
-            hipLaunchKernelGGL(k_head_dw_partial<bf16_t>, grid, dim3(256), 0, ctx->stream, (const bf16_t*)h, ld_h, g_logits, N,
-                               H, (int)C, rows_per_chunk, partial, partial_b);
-        else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL(k_head_dw_finish, dim3((unsigned)((C * H + 255) / 256)), dim3(256), 0, ctx->stream, partial, partial_b,
-                           (int)R, H, (int)C, accumulate, gradWeight, gradBias);
-    }
-    if (g_prev || gT_prev) {
-        const unsigned nb = (unsigned)(((N + 63) / 64) * ((H + 63) / 64));
-        if (dtype == VBNN_F32)
-            hipLaunchKernelGGL(k_head_dx<float>, dim3(nb), dim3(256), 0, ctx->stream, (const float*)h, ld_h, (const float*)w3,
-                               ld_w, g_logits, N, H, (int)C, relu_mask, r_prev, ld_r_prev, (float*)g_prev, (float*)gv_prev,
-                               ld_gp, (float*)gT_prev, (float*)gvT_prev, ld_gpT);
-        else if (dtype == VBNN_BF16)
-            hipLaunchKernelGGL(k_head_dx<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, (const bf16_t*)h, ld_h,
-                               (const bf16_t*)w3, ld_w, g_logits, N, H, (int)C, relu_mask, r_prev, ld_r_prev, (bf16_t*)g_prev,
-                               (bf16_t*)gv_prev, ld_gp, (bf16_t*)gT_prev, (bf16_t*)gvT_prev, ld_gpT);
-        else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
-    }
-    return vbnn_check_launch("k_head_backward");
-    VBNN_API_END
-}

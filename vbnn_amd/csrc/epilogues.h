@@ -84,7 +84,7 @@ struct EpiDx {
     const T* x; int64_t ld_x;
     float* gx; int64_t ld_gx; int gx_vec;
     int relu_mask;
-    const float* r_prev; int64_t ld_r_prev;
+    const float* r_prev; int64_t ld_r_prev; int r_vec;
     T* g_prev; T* gv_prev; int64_t ld_gp;
     T* gT_prev; T* gvT_prev; int64_t ld_gpT;
     int I, N;
@@ -93,21 +93,18 @@ struct EpiDx {
         const int valid = min(4, I - m);
         if (valid <= 0 || n >= N) return;
         float xv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (x) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (j < valid) xv[j] = Elt<T>::from(x[(int64_t)n * ld_x + m + j]);
-        }
+        if (x) load4<T>(x + (int64_t)n * ld_x + m, xv, valid, (ld_x & 3) == 0);
         float gv4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) gv4[j] = dual ? fmaf(2.0f * xv[j], a2[j], a1[j]) : a1[j];
         if (gx) store4<float>(gx + (int64_t)n * ld_gx + m, gv4[0], gv4[1], gv4[2], gv4[3], valid, gx_vec);
         if (g_prev || gT_prev) {
-            float gp[4], gvp[4];
+            float gp[4], gvp[4], rp[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r_prev) load4<float>(r_prev + (int64_t)n * ld_r_prev + m, rp, valid, r_vec);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 gp[j] = (relu_mask && !(xv[j] > 0.f)) ? 0.f : gv4[j];
-                const float rp = (r_prev && j < valid) ? r_prev[(int64_t)n * ld_r_prev + m + j] : 0.f;
-                gvp[j] = gp[j] * rp;
+                gvp[j] = gp[j] * rp[j];
             }
             if (g_prev) store4<T>(g_prev + (int64_t)n * ld_gp + m, gp[0], gp[1], gp[2], gp[3], valid, true);
             if (gv_prev) store4<T>(gv_prev + (int64_t)n * ld_gp + m, gvp[0], gvp[1], gvp[2], gvp[3], valid, true);
@@ -144,40 +141,41 @@ struct EpiDw {
             for (int j = 0; j < 4; ++j) e[j] = z.v[j];
         }
         if (lvars && (gradSum || grad_lv)) {
+            float lv4[4];
+            load4<float>(lvars + base, lv4, valid, vec);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (j < valid) { var[j] = expf(lvars[base + j]); sd[j] = sqrtf(var[j]); }
+            for (int j = 0; j < 4; ++j) if (j < valid) { var[j] = expf(lv4[j]); sd[j] = sqrtf(var[j]); }
         }
         if (gradWeight) {
-            float o4[4];
+            float o4[4], old4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (accumulate) load4<float>(gradWeight + base, old4, valid, vec);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float old = (accumulate && j < valid) ? gradWeight[base + j] : 0.f;
-                o4[j] = fmaf(scale, a1[j], old);
-            }
+            for (int j = 0; j < 4; ++j) o4[j] = fmaf(scale, a1[j], old4[j]);
             store4<float>(gradWeight + base, o4[0], o4[1], o4[2], o4[3], valid, vec);
         }
         if (gradSum) {
-            float o4[4];
+            float o4[4], old4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (accumulate) load4<float>(gradSum + base, old4, valid, vec);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float old = (accumulate && j < valid) ? gradSum[base + j] : 0.f;
-                o4[j] = lrt ? fmaf(2.0f * a2[j], sd[j], old) : old + a1[j] * e[j];
-            }
+            for (int j = 0; j < 4; ++j) o4[j] = lrt ? fmaf(2.0f * a2[j], sd[j], old4[j]) : old4[j] + a1[j] * e[j];
             store4<float>(gradSum + base, o4[0], o4[1], o4[2], o4[3], valid, vec);
         }
         if (grad_mu || grad_lv) {
             // VBLinear.lua:90-98 folded in: likelihood/S (+ kl_scale * KL gradient on the first draw)
             const float var_hat = (float)stats[2];
             const float invS = 1.0f / S;
-            float gm[4], gl[4];
+            float gm[4], gl[4], mu4[4] = {0.f, 0.f, 0.f, 0.f}, om4[4] = {0.f, 0.f, 0.f, 0.f}, ol4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (means && !accumulate) load4<float>(means + base, mu4, valid, vec);
+            if (accumulate && grad_mu) load4<float>(grad_mu + base, om4, valid, vec);
+            if (accumulate && grad_lv) load4<float>(grad_lv + base, ol4, valid, vec);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float mu = (means && j < valid) ? means[base + j] : 0.f;
+                const float mu = mu4[j];
                 float lm = scale * a1[j] * invS;
                 float ll = lrt ? a2[j] * var[j] * invS : a1[j] * e[j] * sd[j] * (0.5f * invS);
                 if (accumulate) {
-                    if (grad_mu && j < valid) lm += grad_mu[base + j];
-                    if (grad_lv && j < valid) ll += grad_lv[base + j];
+                    lm += om4[j];
+                    ll += ol4[j];
                 } else {
                     lm += kl_scale * mu / (B * var_hat);
                     ll += kl_scale * (var[j] / var_hat - 1.0f) / (2.0f * B);

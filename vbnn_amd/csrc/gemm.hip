@@ -51,7 +51,7 @@ static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
     e.x = (const T*)a->x; e.ld_x = a->ld_x;
     e.gx = a->gx; e.ld_gx = a->ld_gx; e.gx_vec = a->gx && aligned16(a->gx) && (a->ld_gx % 4 == 0);
     e.relu_mask = a->relu_mask;
-    e.r_prev = a->r_prev; e.ld_r_prev = a->ld_r_prev;
+    e.r_prev = a->r_prev; e.ld_r_prev = a->ld_r_prev; e.r_vec = a->r_prev && aligned16(a->r_prev) && (a->ld_r_prev % 4 == 0);
     e.g_prev = (T*)a->g_prev; e.gv_prev = (T*)a->gv_prev; e.ld_gp = a->ld_gp;
     e.gT_prev = (T*)a->gT_prev; e.gvT_prev = (T*)a->gvT_prev; e.ld_gpT = a->ld_gpT;
     e.I = (int)a->I; e.N = (int)a->N;
@@ -65,7 +65,8 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
     e.lrt = a->x2T != nullptr;
     e.scale = a->scale; e.accumulate = a->accumulate;
     e.gradWeight = a->gradWeight; e.gradSum = a->gradSum;
-    e.vec = (a->I % 4 == 0) && (!a->gradWeight || aligned16(a->gradWeight)) && (!a->gradSum || aligned16(a->gradSum)) &&
+    e.vec = (a->I % 4 == 0) && (!a->lvars || aligned16(a->lvars)) && (!a->means || aligned16(a->means)) &&
+            (!a->gradWeight || aligned16(a->gradWeight)) && (!a->gradSum || aligned16(a->gradSum)) &&
             (!a->grad_mu || aligned16(a->grad_mu)) && (!a->grad_lv || aligned16(a->grad_lv));
     e.seed = a->seed; e.layer = a->layer; e.draw = a->draw;
     e.lvars = a->lvars;
