@@ -11,9 +11,16 @@
 void vbnn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 #include "../vbnn_amd/csrc/gemm_v2.h"
 
-struct EpiSum {          // keeps both accumulators live with one 16-byte store per 16x16 tile per lane
+struct EpiSum {          // keeps both accumulators live with one 16-byte store per four outputs
+    typedef bf16_t elem_t;
     float* out; int M, N;
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 a1, f32x4 a2) const {
+    __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
+    __device__ __forceinline__ bf16_t* t2_ptr() const { return nullptr; }
+    __device__ __forceinline__ int64_t t_ld() const { return 0; }
+    __device__ __forceinline__ int m_dim() const { return M; }
+    __device__ __forceinline__ int n_dim() const { return N; }
+    template <bool ST>
+    __device__ __forceinline__ void apply(int m, int n, f32x4 a1, f32x4 a2, float (&t1)[4], float (&t2)[4]) const {
         if (m < M && n < N) *reinterpret_cast<f32x4*>(out + (size_t)n * M + m) = a1 + a2;
     }
 };

@@ -1,14 +1,18 @@
 // epilogues.h -- fused epilogues of the three VBLinear GEMM families.
 //
 // Every GEMM kernel in this library computes C[m][n] = sum_k A[m][k] * Bt[n][k] (and, for
-// the local-reparameterisation pair, a second accumulator from A2/Bt2) on 16x16 MFMA tiles,
-// whose accumulator layout is   n = lane & 15,  m = 4 * (lane >> 4) + reg   (reg = 0..3).
-// The "weights / feature" side is always operand A, so a lane's four registers are four
-// CONSECUTIVE feature indices of one minibatch row (FWD: 4 output units of row n; DX: 4
-// input units of row n; DW: 4 input units i of output unit o). That is the contiguous
-// direction of every primary output tensor and exactly one Philox block (4 normals).
+// the local-reparameterisation pair, a second accumulator from A2/Bt2). The "weights / feature"
+// side is always operand A, so M is the CONTIGUOUS direction of every primary output tensor
+// (FWD: output units of a minibatch row; DX: input units of a row; DW: input units i of output
+// unit o). An epilogue functor is handed four consecutive m of one n:
 //
-// An epilogue is called once per lane per 16x16 tile:  epi(m, n, acc1, acc2).
+//     epi.apply<STORE_T>(m, n, acc1, acc2, t1, t2)
+//
+// and (a) computes and stores the primary outputs at [n][m .. m+3] (one 8- or 16-byte store),
+// (b) produces the four values of each TRANSPOSED output (t1, t2) -- stored by the functor itself
+// (STORE_T = true: 2-byte stores, the general kernel) or handed back to the kernel, which transposes
+// them through LDS and writes whole rows (STORE_T = false: the pipelined kernel).
+// Four consecutive m are also exactly one Philox block (4 normals) of the RNG contract.
 #pragma once
 #include "common.h"
 
@@ -17,6 +21,7 @@
 // LRT   : y = acc1 + b + sqrt(acc2) * z,  r = z / (2 sqrt(acc2))
 template <typename T>
 struct EpiFwd {
+    typedef T elem_t;
     const float* bias;
     int noise;
     uint64_t seed; uint32_t layer, draw; int64_t row0;
@@ -27,16 +32,25 @@ struct EpiFwd {
     T* hT; T* h2T; int64_t ld_hT;
     int O, N;
 
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 a1, f32x4 a2) const {
+    __device__ __forceinline__ T* t1_ptr() const { return hT; }
+    __device__ __forceinline__ T* t2_ptr() const { return h2T; }
+    __device__ __forceinline__ int64_t t_ld() const { return ld_hT; }
+    __device__ __forceinline__ int m_dim() const { return O; }
+    __device__ __forceinline__ int n_dim() const { return N; }
+
+    template <bool STORE_T>
+    __device__ __forceinline__ void apply(int m, int n, f32x4 a1, f32x4 a2, float (&t1)[4], float (&t2)[4]) const {
         const int valid = min(4, O - m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
         if (valid <= 0 || n >= N) return;
-        float yv[4], rv[4];
+        float yv[4], rv[4], bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) load4<float>(bias + m, bv, valid, (m & 3) == 0 && (((uintptr_t)bias & 15u) == 0));
         vbnn_f32x4 z;
         if (noise) z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + n), (uint32_t)(m >> 2));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float b = (bias && j < valid) ? bias[m + j] : 0.f;
-            const float mb = a1[j] + b;
+            const float mb = a1[j] + bv[j];
             if (noise) {
                 const float sd = sqrtf(a2[j]);
                 yv[j] = fmaf(sd, z.v[j], mb);
@@ -49,28 +63,30 @@ struct EpiFwd {
         if (y) store4<float>(y + (int64_t)n * ld_y + m, yv[0], yv[1], yv[2], yv[3], valid, y_vec);
         if (r) store4<float>(r + (int64_t)n * ld_r + m, rv[0], rv[1], rv[2], rv[3], valid, r_vec);
         if (h || hT) {
-            float hv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hv[j] = relu ? fmaxf(yv[j], 0.f) : yv[j];
-            if (h) {
-                store4<T>(h + (int64_t)n * ld_h + m, hv[0], hv[1], hv[2], hv[3], valid, true);
-                if (h2) {
-                    // square the value the consumer will actually read (the rounded one)
-                    float q[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { const float hr = Elt<T>::from(Elt<T>::to(hv[j])); q[j] = hr * hr; }
-                    store4<T>(h2 + (int64_t)n * ld_h + m, q[0], q[1], q[2], q[3], valid, true);
-                }
+            for (int j = 0; j < 4; ++j) {
+                t1[j] = relu ? fmaxf(yv[j], 0.f) : yv[j];
+                // square the value the consumer will actually read (the rounded one)
+                const float hr = Elt<T>::from(Elt<T>::to(t1[j]));
+                t2[j] = hr * hr;
             }
-            if (hT) {
+            if (h) {
+                store4<T>(h + (int64_t)n * ld_h + m, t1[0], t1[1], t1[2], t1[3], valid, true);
+                if (h2) store4<T>(h2 + (int64_t)n * ld_h + m, t2[0], t2[1], t2[2], t2[3], valid, true);
+            }
+            if (STORE_T && hT) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (j < valid) {
-                        hT[(int64_t)(m + j) * ld_hT + n] = Elt<T>::to(hv[j]);
-                        if (h2T) { const float hr = Elt<T>::from(Elt<T>::to(hv[j])); h2T[(int64_t)(m + j) * ld_hT + n] = Elt<T>::to(hr * hr); }
+                        hT[(int64_t)(m + j) * ld_hT + n] = Elt<T>::to(t1[j]);
+                        if (h2T) h2T[(int64_t)(m + j) * ld_hT + n] = Elt<T>::to(t2[j]);
                     }
             }
         }
+    }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 a1, f32x4 a2) const {
+        float t1[4], t2[4];
+        apply<true>(m, n, a1, a2, t1, t2);
     }
 };
 
@@ -80,6 +96,7 @@ struct EpiFwd {
 // optional hand-off to the previous VB layer through the ReLU between them (mlp.lua:19,27).
 template <typename T>
 struct EpiDx {
+    typedef T elem_t;
     int dual;
     const T* x; int64_t ld_x;
     float* gx; int64_t ld_gx; int gx_vec;
@@ -89,8 +106,17 @@ struct EpiDx {
     T* gT_prev; T* gvT_prev; int64_t ld_gpT;
     int I, N;
 
-    __device__ __forceinline__ void operator()(int m, int n, f32x4 a1, f32x4 a2) const {
+    __device__ __forceinline__ T* t1_ptr() const { return gT_prev; }
+    __device__ __forceinline__ T* t2_ptr() const { return gvT_prev; }
+    __device__ __forceinline__ int64_t t_ld() const { return ld_gpT; }
+    __device__ __forceinline__ int m_dim() const { return I; }
+    __device__ __forceinline__ int n_dim() const { return N; }
+
+    template <bool STORE_T>
+    __device__ __forceinline__ void apply(int m, int n, f32x4 a1, f32x4 a2, float (&t1)[4], float (&t2)[4]) const {
         const int valid = min(4, I - m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
         if (valid <= 0 || n >= N) return;
         float xv[4] = {0.f, 0.f, 0.f, 0.f};
         if (x) load4<T>(x + (int64_t)n * ld_x + m, xv, valid, (ld_x & 3) == 0);
@@ -99,28 +125,35 @@ struct EpiDx {
         for (int j = 0; j < 4; ++j) gv4[j] = dual ? fmaf(2.0f * xv[j], a2[j], a1[j]) : a1[j];
         if (gx) store4<float>(gx + (int64_t)n * ld_gx + m, gv4[0], gv4[1], gv4[2], gv4[3], valid, gx_vec);
         if (g_prev || gT_prev) {
-            float gp[4], gvp[4], rp[4] = {0.f, 0.f, 0.f, 0.f};
+            float rp[4] = {0.f, 0.f, 0.f, 0.f};
             if (r_prev) load4<float>(r_prev + (int64_t)n * ld_r_prev + m, rp, valid, r_vec);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                gp[j] = (relu_mask && !(xv[j] > 0.f)) ? 0.f : gv4[j];
-                gvp[j] = gp[j] * rp[j];
+                t1[j] = (relu_mask && !(xv[j] > 0.f)) ? 0.f : gv4[j];
+                t2[j] = t1[j] * rp[j];
             }
-            if (g_prev) store4<T>(g_prev + (int64_t)n * ld_gp + m, gp[0], gp[1], gp[2], gp[3], valid, true);
-            if (gv_prev) store4<T>(gv_prev + (int64_t)n * ld_gp + m, gvp[0], gvp[1], gvp[2], gvp[3], valid, true);
+            if (g_prev) store4<T>(g_prev + (int64_t)n * ld_gp + m, t1[0], t1[1], t1[2], t1[3], valid, true);
+            if (gv_prev) store4<T>(gv_prev + (int64_t)n * ld_gp + m, t2[0], t2[1], t2[2], t2[3], valid, true);
+            if (STORE_T) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < valid) {
-                    if (gT_prev) gT_prev[(int64_t)(m + j) * ld_gpT + n] = Elt<T>::to(gp[j]);
-                    if (gvT_prev) gvT_prev[(int64_t)(m + j) * ld_gpT + n] = Elt<T>::to(gvp[j]);
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (j < valid) {
+                        if (gT_prev) gT_prev[(int64_t)(m + j) * ld_gpT + n] = Elt<T>::to(t1[j]);
+                        if (gvT_prev) gvT_prev[(int64_t)(m + j) * ld_gpT + n] = Elt<T>::to(t2[j]);
+                    }
+            }
         }
+    }
+    __device__ __forceinline__ void operator()(int m, int n, f32x4 a1, f32x4 a2) const {
+        float t1[4], t2[4];
+        apply<true>(m, n, a1, a2, t1, t2);
     }
 };
 
 // ---- DW: M = input units i, N = output units o --------------------------------------------------
 // acc1 = (g^T x)[o][i], acc2 = (gv^T x.x)[o][i]          (VBLinear.lua:112-118, one GEMM not two)
 struct EpiDw {
+    typedef bf16_t elem_t;   // no transposed outputs; only the type is needed
     int lrt;                 // 1: LRT (acc2 valid), 0: WN (e regenerated)
     float scale; int accumulate;
     float* gradWeight; float* gradSum; int vec;
@@ -130,21 +163,38 @@ struct EpiDw {
     const float* means; const double* stats; float B, S, kl_scale;
     int I, O;
 
+    __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
+    __device__ __forceinline__ bf16_t* t2_ptr() const { return nullptr; }
+    __device__ __forceinline__ int64_t t_ld() const { return 0; }
+    __device__ __forceinline__ int m_dim() const { return I; }
+    __device__ __forceinline__ int n_dim() const { return O; }
+
+    template <bool STORE_T>
+    __device__ __forceinline__ void apply(int m, int n, f32x4 a1, f32x4 a2, float (&t1)[4], float (&t2)[4]) const {
+        (void)t1; (void)t2;
+        (*this)(m, n, a1, a2);
+    }
+
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a1, f32x4 a2) const {
         const int valid = min(4, I - m);
         if (valid <= 0 || n >= O) return;
         const int64_t base = (int64_t)n * I + m;
         float e[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f}, var[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!lrt && (gradSum || grad_lv)) {
+        const bool want_lv = gradSum || grad_lv;
+        if (!lrt && want_lv) {
             const vbnn_f32x4 z = vbnn_normal4(seed, VBNN_STREAM_EPS, layer, draw, (uint32_t)n, (uint32_t)(m >> 2));
 #pragma unroll
             for (int j = 0; j < 4; ++j) e[j] = z.v[j];
         }
-        if (lvars && (gradSum || grad_lv)) {
+        if (lvars && want_lv) {
             float lv4[4];
             load4<float>(lvars + base, lv4, valid, vec);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (j < valid) { var[j] = expf(lv4[j]); sd[j] = sqrtf(var[j]); }
+            for (int j = 0; j < 4; ++j) if (j < valid) var[j] = expf(lv4[j]);
+            if (gradSum || !lrt) {             // stdv is only needed by gradSum and by the weight-noise form
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sd[j] = sqrtf(var[j]);
+            }
         }
         if (gradWeight) {
             float o4[4], old4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -161,24 +211,27 @@ struct EpiDw {
             store4<float>(gradSum + base, o4[0], o4[1], o4[2], o4[3], valid, vec);
         }
         if (grad_mu || grad_lv) {
-            // VBLinear.lua:90-98 folded in: likelihood/S (+ kl_scale * KL gradient on the first draw)
+            // VBLinear.lua:90-98 folded in: likelihood/S (+ kl_scale * KL gradient on the first draw).
+            // Reciprocals are formed once per call, so the per-element work is multiply-adds only.
             const float var_hat = (float)stats[2];
             const float invS = 1.0f / S;
+            const float k_mu = kl_scale / (B * var_hat);            // d(KL/B)/dmeans  = means / (B var_hat)
+            const float k_lv = kl_scale / (2.0f * B);               // d(KL/B)/dlvars  = (vars / var_hat - 1) / (2B)
+            const float inv_vh = 1.0f / var_hat;
             float gm[4], gl[4], mu4[4] = {0.f, 0.f, 0.f, 0.f}, om4[4] = {0.f, 0.f, 0.f, 0.f}, ol4[4] = {0.f, 0.f, 0.f, 0.f};
             if (means && !accumulate) load4<float>(means + base, mu4, valid, vec);
             if (accumulate && grad_mu) load4<float>(grad_mu + base, om4, valid, vec);
             if (accumulate && grad_lv) load4<float>(grad_lv + base, ol4, valid, vec);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float mu = mu4[j];
                 float lm = scale * a1[j] * invS;
                 float ll = lrt ? a2[j] * var[j] * invS : a1[j] * e[j] * sd[j] * (0.5f * invS);
                 if (accumulate) {
                     lm += om4[j];
                     ll += ol4[j];
                 } else {
-                    lm += kl_scale * mu / (B * var_hat);
-                    ll += kl_scale * (var[j] / var_hat - 1.0f) / (2.0f * B);
+                    lm = fmaf(k_mu, mu4[j], lm);
+                    ll = fmaf(k_lv, fmaf(var[j], inv_vh, -1.0f), ll);
                 }
                 gm[j] = lm; gl[j] = ll;
             }

@@ -365,12 +365,76 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
     }
 
     V2_STAMP_FLUSH
-    const int em = m0 + wm * 64 + (lane >> 4) * 4;
-    const int en = n0 + wn * 64 + (lane & 15);
+
+    // ---- epilogue. The ring is idle now: each wave re-lays its 64 x 64 accumulator tile through a private
+    // 18 KiB LDS region from the MFMA layout (n = lane & 15, 4 m per lane-group) into rows of n, so that one
+    // wave-instruction touches 4 rows x 64 CONTIGUOUS m (256 B of fp32 / 128 B of bf16 per row) instead of 16
+    // rows x 16 m; the transposed outputs take a second trip (written [m][n], read back as rows of n).
+    typedef typename Epi::elem_t ET;
+    constexpr int SP = 68;                                    // fp32 staging pitch (floats): conflict-free b128 rows
+    constexpr int TP = 72;                                    // transposed staging pitch (elements), 16-byte multiple
+    __syncthreads();                                          // every wave is done reading the last tile
+    float* st = reinterpret_cast<float*>(lds + wave * 18432);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    f32x4 r1[16], r2[16];
+    auto relayout = [&](f32x4 (&acc)[4][4], f32x4 (&rows)[16]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) epi(em + i * 16, en + j * 16, acc1[i][j], acc2[i][j]);
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(st + (j * 16 + c16) * SP + i * 16 + q4 * 4) = acc[i][j];
+        // same-wave LDS operations complete in order: the reads below see the writes above
+#pragma unroll
+        for (int p = 0; p < 16; ++p) rows[p] = *reinterpret_cast<const f32x4*>(st + (4 * p + q4) * SP + 4 * c16);
+    };
+    relayout(acc1, r1);
+    if (DUAL) relayout(acc2, r2);
+    else {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) r2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int wm0 = m0 + wm * 64, wn0 = n0 + wn * 64;
+    ET* tp1 = epi.t1_ptr();
+    ET* tp2 = epi.t2_ptr();
+    const bool any_t = (tp1 != nullptr) || (tp2 != nullptr);
+    ET* tl1 = reinterpret_cast<ET*>(st);                      // [64 m][TP] each, reusing the staging region
+    ET* tl2 = tl1 + 64 * TP;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        float t1[4], t2[4];
+        epi.template apply<false>(wm0 + 4 * c16, wn0 + 4 * p + q4, r1[p], r2[p], t1, t2);
+        if (any_t) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tl1[(4 * c16 + j) * TP + 4 * p + q4] = Elt<ET>::to(t1[j]);
+                tl2[(4 * c16 + j) * TP + 4 * p + q4] = Elt<ET>::to(t2[j]);
+            }
+        }
+    }
+    if (any_t) {
+        // rows of the transposed outputs: lane (row = lane >> 3 (+8 per pass), 8 consecutive n = 8 (lane & 7) ..)
+        const int64_t ldt = epi.t_ld();
+        const int Md = epi.m_dim(), Nd = epi.n_dim();
+        const int nn = wn0 + 8 * (lane & 7);
+        const bool vec_ok = ((ldt & 7) == 0) && (nn + 8 <= Nd);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int ml = 8 * p + (lane >> 3);
+            const int mm = wm0 + ml;
+            if (mm < Md && nn < Nd) {
+                if (tp1) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(tl1 + ml * TP + 8 * (lane & 7));
+                    if (vec_ok) *reinterpret_cast<bf16x8*>(tp1 + (int64_t)mm * ldt + nn) = v;
+                    else for (int e = 0; e < 8; ++e) if (nn + e < Nd) tp1[(int64_t)mm * ldt + nn + e] = v[e];
+                }
+                if (tp2) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(tl2 + ml * TP + 8 * (lane & 7));
+                    if (vec_ok) *reinterpret_cast<bf16x8*>(tp2 + (int64_t)mm * ldt + nn) = v;
+                    else for (int e = 0; e < 8; ++e) if (nn + e < Nd) tp2[(int64_t)mm * ldt + nn + e] = v[e];
+                }
+            }
+        }
+    }
 }
 
 template <typename T>
