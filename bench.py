@@ -86,6 +86,21 @@ def dominant_kernel_roofline(eng, N, torch):
     return name, res[name], flops, {k: round(v_, 4) for k, v_ in res.items()}
 
 
+def measured_traffic(kernel_name, cfg_name):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE are collected
+    in their own rocprofv3 runs, never inside this timed process): profiles/*_traffic.json, newest round."""
+    if cfg_name != "wide":
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get(kernel_name, {}).get("hbm_bytes")
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, budget_s=25.0):
     """The reference's op sequence on the host cores (oracle/ref_numpy.py), bounded sample."""
     import numpy as np
@@ -195,7 +210,7 @@ def main():
                        "step_frac_of_mfma_peak": round(fps * N / (ms * 1e-3) / 1e12 / peak, 4),
                        "loss": round(loss, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None, "kernel": kname,
+                         "frac": round(achieved / peak, 4), "traffic": measured_traffic(kname, args.config), "kernel": kname,
                          "kernel_ms": round(kms, 4), "flop_per_launch": kflops, "all_kernels_ms": kall},
         }
         if world == 1 and not args.no_cpu_baseline:

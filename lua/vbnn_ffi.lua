@@ -1,0 +1,139 @@
+-- vbnn_ffi.lua -- LuaJIT FFI binding of libvbnn_hip.so (include/vbnn_hip.h).
+--
+-- GENERATED from the header by lua/gen_ffi.py: do not edit the cdef by hand. tests/test_abi.py checks
+-- that every function of the header appears here with the same parameter count.
+-- No LuaJIT / Torch7 exists in the build image, so this file has never been executed there; it is the
+-- reference-side binding a maintainer adds (INTEGRATION.md).
+local ffi = require 'ffi'
+
+ffi.cdef[[
+enum { VBNN_OK = 0, VBNN_ERR_INVALID = 1, VBNN_ERR_HIP = 2, VBNN_ERR_NOMEM = 3, VBNN_ERR_UNSUPPORTED = 4 };
+enum { VBNN_F32 = 0, VBNN_BF16 = 1 };
+enum { VBNN_PACK_COPY = 0, VBNN_PACK_EXP = 1, VBNN_PACK_SQUARE = 2, VBNN_PACK_MUL = 3,
+       VBNN_PACK_RELU = 4, VBNN_PACK_RELU_SQUARE = 5 };
+typedef struct vbnn_ctx vbnn_ctx;
+int vbnn_abi_version(void);
+const char* vbnn_last_error(void);
+int vbnn_debug_set(int key, int value);
+int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);
+int vbnn_ctx_destroy(vbnn_ctx* ctx);
+int vbnn_ctx_set_stream(vbnn_ctx* ctx, void* hip_stream);
+int vbnn_sync(vbnn_ctx* ctx);
+int vbnn_buf_alloc(vbnn_ctx* ctx, size_t bytes, void** dptr);
+int vbnn_buf_free(vbnn_ctx* ctx, void* dptr);
+int vbnn_buf_zero(vbnn_ctx* ctx, void* dptr, size_t bytes);
+int vbnn_buf_upload(vbnn_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int vbnn_buf_download(vbnn_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int vbnn_fill_normal(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int64_t ld,
+                     uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
+                     float scale);
+int vbnn_compute_prior(vbnn_ctx* ctx, const float* means, const float* lvars, int64_t W,
+                       float* vars, float* stdv, float* mu_sqe, double* stats);
+int vbnn_wn_sample(vbnn_ctx* ctx, const float* means, const float* stdv, const float* lvars,
+                   float* weight, float* e_out, int64_t O, int64_t I,
+                   uint64_t seed, uint32_t layer, uint32_t draw);
+int vbnn_pack(vbnn_ctx* ctx, int dtype, int func, const float* src, const float* src2, int64_t ld_src,
+              int64_t rows, int64_t cols, void* dst, int64_t ld_dst, void* dstT, int64_t ld_dstT);
+typedef struct vbnn_fwd_args {
+    const void* w;
+    const void* w2;
+    const void* x;
+    const void* x2;
+    int64_t ld_w, ld_x;
+    int64_t N, I, O;
+    const float* bias;
+    uint64_t seed; uint32_t layer; uint32_t draw; int64_t row0;
+    float* y;  int64_t ld_y;
+    float* r;  int64_t ld_r;
+    int relu;
+    void* h;  void* h2;  int64_t ld_h;
+    void* hT; void* h2T; int64_t ld_hT;
+} vbnn_fwd_args;
+int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a);
+typedef struct vbnn_dx_args {
+    const void* wT;
+    const void* w2T;
+    const void* g;
+    const void* gv;
+    int64_t ld_wT, ld_g;
+    int64_t N, I, O;
+    const void* x; int64_t ld_x;
+    float* gx; int64_t ld_gx;
+    int relu_mask;
+    const float* r_prev; int64_t ld_r_prev;
+    void* g_prev; void* gv_prev; int64_t ld_gp;
+    void* gT_prev; void* gvT_prev; int64_t ld_gpT;
+} vbnn_dx_args;
+int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a);
+typedef struct vbnn_dw_args {
+    const void* xT;
+    const void* x2T;
+    const void* gT;
+    const void* gvT;
+    int64_t ld_n;
+    int64_t N, I, O;
+    float scale;
+    int accumulate;
+    float* gradWeight;
+    float* gradSum;
+    uint64_t seed; uint32_t layer; uint32_t draw;
+    const float* lvars;
+    float* grad_mu; float* grad_lv;
+    const float* means; const double* stats; float B; float S; float kl_scale;
+} vbnn_dw_args;
+int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
+int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O,
+                       float scale, int accumulate, float* gradBias);
+int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, const float* lvars, int64_t O, int64_t I,
+                    void* mu_s, void* var_s, int64_t ld_w, void* muT_s, void* varT_s, int64_t ld_wT,
+                    double* stats);
+int vbnn_compute_mugrads(vbnn_ctx* ctx, const float* means, const double* stats, float B, float S,
+                         float* gradWeight, float* lcg, int64_t W);
+int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, const float* stdv,
+                          const double* stats, float B, float S, float* gradSum, float* lcg, int64_t W);
+int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const float* vars, const float* mu_sqe,
+                 const double* stats, float B, float* lc_elem, double* lc_sum_dev, int64_t W);
+int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);
+int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx, int64_t n);
+int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const int32_t* target,
+                        int64_t N, int64_t C, float inv_n, float* out, float* g_logits,
+                        double* loss_sum_dev, int32_t* correct_dev);
+int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
+                      const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
+                      float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev);
+int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
+                       const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
+                       float* gradBias, int relu_mask, const float* r_prev, int64_t ld_r_prev, void* g_prev,
+                       void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT);
+int vbnn_nll_forward(vbnn_ctx* ctx, const float* out, int64_t ld, const int32_t* target, int64_t N, int64_t C,
+                     float inv_n, double* loss_sum_dev, int32_t* correct_dev);
+int vbnn_nll_backward(vbnn_ctx* ctx, const int32_t* target, int64_t N, int64_t C, float inv_n, float* g);
+int vbnn_logsoftmax_backward(vbnn_ctx* ctx, const float* out, const float* g, float* gx, int64_t N, int64_t C);
+]]
+
+local M = {}
+M.C = ffi.load(os.getenv('VBNN_HIP_LIB') or 'vbnn_hip')
+M.ffi = ffi
+
+-- status -> Lua error (the error convention of SURVEY.md 8b: no C++ exception crosses the ABI)
+function M.check(status)
+    if status ~= 0 then
+        error('libvbnn_hip status ' .. tostring(status) .. ': ' .. ffi.string(M.C.vbnn_last_error()), 2)
+    end
+end
+
+-- one context per process (device from VBNN_DEVICE, default stream)
+local ctx_box = ffi.new('vbnn_ctx*[1]')
+M.check(M.C.vbnn_ctx_create(tonumber(os.getenv('VBNN_DEVICE') or '0'), nil, ctx_box))
+M.ctx = ffi.gc(ctx_box[0], M.C.vbnn_ctx_destroy)
+
+-- device buffer with finaliser
+function M.alloc(bytes)
+    local p = ffi.new('void*[1]')
+    M.check(M.C.vbnn_buf_alloc(M.ctx, bytes, p))
+    return ffi.gc(p[0], function(d) M.C.vbnn_buf_free(M.ctx, d) end)
+end
+
+function M.pad_ld(k) return math.floor((k + 63) / 64) * 64 end
+
+return M

@@ -52,9 +52,14 @@ struct EpiFwd {
         for (int j = 0; j < 4; ++j) {
             const float mb = a1[j] + bv[j];
             if (noise) {
-                const float sd = sqrtf(a2[j]);
+                // v_rsq_f32 (1 ulp) instead of a correctly rounded sqrt + divide: this is outside the RNG
+                // contract, and 2 ulp on sqrt(v) is far inside the fp32 parity tolerance. v == 0 (an all-zero
+                // input row) must give sd = 0 and r = 0, not inf * 0.
+                const bool pos = a2[j] > 0.f;
+                const float rs = __builtin_amdgcn_rsqf(a2[j]);
+                const float sd = pos ? a2[j] * rs : 0.f;
                 yv[j] = fmaf(sd, z.v[j], mb);
-                rv[j] = (a2[j] > 0.f) ? z.v[j] / (2.0f * sd) : 0.f;
+                rv[j] = pos ? 0.5f * z.v[j] * rs : 0.f;
             } else {
                 yv[j] = mb;
                 rv[j] = 0.f;
