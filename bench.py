@@ -150,7 +150,13 @@ def main():
         print("bench.py needs an MI355X: no HIP device is visible and there is no CPU fallback", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VBNN_FORCE_DIST=1: run the RCCL code path (process group, bucketed all-reduce, barriers) even with one
+    # rank -- the only way to exercise it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("VBNN_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
     L.lib()                                               # fail loudly if the HIP extension is missing
@@ -159,7 +165,7 @@ def main():
     N = cfg["batch"]
     opt = dict(var_init=1e-3, B=1e6, S=1, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
                hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True)
-    eng = FusedMLP(opt, world_size=world, rank=rank)
+    eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
     # synthetic minibatch, resident in HBM: x ~ N(0,1) addressed by GLOBAL row, targets uniform in 0..9
     x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
     fill_normal(x, 3, L.STREAM_DATA, 0, 0, row0=rank * N)
@@ -175,18 +181,18 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
@@ -216,7 +222,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -48,7 +48,8 @@ const char* vbnn_last_error(void);
 /* test / A-B hook. VBNN_DEBUG_GEMM_KERNEL: 0 = pick by shape (default), 1 = always the general MFMA
  * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it. */
 #define VBNN_DEBUG_GEMM_KERNEL 0
-#define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel schedule 0..3, see gemm_v2.h (default 2) */
+#define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel: 0 = DMAs burst after the barrier, 2 = interleaved with the MFMAs (default) */
+#define VBNN_DEBUG_V2_TILE 2       /* pipelined kernel block tile: 0 = by shape (default), 128 = 128 x 128, 256 = 256 x 128 */
 int vbnn_debug_set(int key, int value);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
@@ -200,6 +201,21 @@ int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, 
  * LC is one optimiser step stale, main.lua:174-177); NULL: derive from means / lvars. */
 int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const float* vars, const float* mu_sqe,
                  const double* stats, float B, float* lc_elem, double* lc_sum_dev, int64_t W);
+
+/* ---- the update that follows the hot path -------------------------------- */
+
+/* optim.adam as VBLinear:update calls it on means / lvars (VBLinear.lua:135-143), one streaming pass:
+ *   g = grad (+ grad2);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g.g;
+ *   x -= lr sqrt(1 - b2^t) / (1 - b1^t) . m / (sqrt(v) + eps)
+ * grad2 (optional) is added to grad first (the torch.add of likelihood and KL parts, VBLinear.lua:131-134);
+ * lambda < 1 selects the early torch/optim variant's decay b1_t = b1 lambda^(t-1) (config.lua:52,56,61), 1 = off;
+ * t is state.t after its increment (>= 1). norms_dev (optional, 2 doubles): { |update|, |x_new| }, the two norms of
+ * the reference's `mu_normratio = torch.norm(update) / torch.norm(x)` (VBLinear.lua:139,144).
+ * optim is not vendored by the reference and its version is unpinned: this is the published algorithm. */
+int vbnn_adam_step(vbnn_ctx* ctx, float* x, const float* grad, const float* grad2, float* m, float* v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float lambda, int64_t t, double* norms_dev);
+/* optim.sgd with only learningRate set (config.lua:51-54): x -= lr * grad (VBLinear.lua:125-128, mlp.lua:120-128). */
+int vbnn_sgd_step(vbnn_ctx* ctx, float* x, const float* grad, int64_t n, float lr);
 
 /* ---- glue modules on the measured path (mlp.lua:12-32) --------------------------------------- */
 int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);

@@ -93,6 +93,9 @@ int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, 
                           const double* stats, float B, float S, float* gradSum, float* lcg, int64_t W);
 int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const float* vars, const float* mu_sqe,
                  const double* stats, float B, float* lc_elem, double* lc_sum_dev, int64_t W);
+int vbnn_adam_step(vbnn_ctx* ctx, float* x, const float* grad, const float* grad2, float* m, float* v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float lambda, int64_t t, double* norms_dev);
+int vbnn_sgd_step(vbnn_ctx* ctx, float* x, const float* grad, int64_t n, float lr);
 int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);
 int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx, int64_t n);
 int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const int32_t* target,

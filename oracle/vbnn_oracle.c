@@ -336,3 +336,27 @@ VBO_API double vbo_get_accuracy(const float* out, const int32_t* target, int64_t
     }
     return 100.0 * (double)correct / (double)N;
 }
+
+/* ------------------------------------------------------------------ the update after the hot path
+ * (VBLinear.lua:124-166, mlp.lua:117-142). optim.adam / optim.sgd are un-vendored and unpinned; the
+ * reference's author even ran a patched optim (third return value, VBLinear.lua:135-144). Restated here is
+ * the published torch/optim adam [recalled]:
+ *   state.t += 1; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g.g; denom = sqrt(v) + eps;
+ *   stepSize = lr sqrt(1 - b2^t) / (1 - b1^t); x -= stepSize m / denom.
+ * `update_out` (optional) receives stepSize m / denom, the quantity whose norm VBLinear.lua:139,144 logs. */
+VBO_API void vbo_adam_step(float* x, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                           float eps, int64_t t, float* update_out) {
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const float step = (float)((double)lr * sqrt(bc2) / bc1);
+    for (int64_t i = 0; i < n; ++i) {
+        m[i] = b1 * m[i] + (1.0f - b1) * g[i];
+        v[i] = b2 * v[i] + (1.0f - b2) * g[i] * g[i];
+        const float up = step * m[i] / (sqrtf(v[i]) + eps);
+        x[i] -= up;
+        if (update_out) update_out[i] = up;
+    }
+}
+/* optim.sgd with only learningRate set (config.lua:51-54) [recalled]: x -= lr g. */
+VBO_API void vbo_sgd_step(float* x, const float* g, int64_t n, float lr) {
+    for (int64_t i = 0; i < n; ++i) x[i] = fmaf(-lr, g[i], x[i]);
+}

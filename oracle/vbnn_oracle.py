@@ -35,8 +35,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        if os.path.exists(os.path.join(_HERE, "vbnn_oracle.c")):
+            build()                 # no-op when the library is newer than its sources
         _lib = C.CDLL(_LIB_PATH)
         _lib.vbo_calc_lc.restype = C.c_double
         _lib.vbo_nll_forward.restype = C.c_double
@@ -161,6 +161,18 @@ def lrt_backward(x, g, r, means, lvars, scale, gradWeight, gradBias, gradSum, wa
     return gx
 
 
+def adam_step(x, g, m, v, lr, b1, b2, eps, t):
+    """In-place optim.adam step; returns the applied update (see vbo_adam_step)."""
+    upd = np.empty_like(x)
+    lib().vbo_adam_step(_f(x), _f(np.ascontiguousarray(g, np.float32)), _f(m), _f(v), _i64(x.size), C.c_float(lr),
+                        C.c_float(b1), C.c_float(b2), C.c_float(eps), _i64(t), _f(upd))
+    return upd
+
+
+def sgd_step(x, g, lr):
+    lib().vbo_sgd_step(_f(x), _f(np.ascontiguousarray(g, np.float32)), _i64(x.size), C.c_float(lr))
+
+
 def relu_forward(x):
     y = np.empty_like(x)
     lib().vbo_relu_forward(_f(x), _f(y), _i64(x.size))
@@ -275,6 +287,26 @@ class OracleVBLinear:
     def calc_lc(self, opt):
         return calc_lc(self.vars, self.mu_sqe, self.var_hat, opt["B"])
 
+    def update(self, opt):
+        """VBLinear:update -- VBLinear.lua:124-166 (logging omitted). Returns (mu_normratio, var_normratio)."""
+        st = self.__dict__.setdefault("_opt_state", {"mean": {"t": 0}, "var": {"t": 0}})
+        sgd_step(self.bias, self.gradBias, opt["state"]["learningRate"])                     # :125-128
+        self.compute_prior()                                                                  # :130
+        mleg, mlcg = self.compute_mugrads(opt)                                                # :131
+        mugrad = mleg + mlcg                                                                  # :132
+        vleg, vlcg = self.compute_vargrads(opt)                                               # :133
+        vgrad = vleg + vlcg                                                                   # :134
+        ratios = []
+        for x, g, key, cfg in ((self.means, mugrad, "mean", opt["meanState"]), (self.lvars, vgrad, "var", opt["varState"])):
+            s = st[key]
+            if "m" not in s:
+                s["m"], s["v"] = np.zeros_like(x), np.zeros_like(x)
+            s["t"] += 1
+            upd = adam_step(x, g, s["m"], s["v"], cfg["learningRate"], cfg.get("beta1", 0.9), cfg.get("beta2", 0.999),
+                            cfg.get("epsilon", 1e-8), s["t"])
+            ratios.append(float(np.linalg.norm(upd.astype(np.float64)) / np.linalg.norm(x.astype(np.float64))))   # :139,144
+        return tuple(ratios)
+
 
 class OracleLinear:
     """plain nn.Linear (the final layer, mlp.lua:29)."""
@@ -346,3 +378,10 @@ class OracleMLP:
     def calc_lc(self, opt=None):                                         # mlp.lua:109-115
         opt = opt or self.opt
         return sum(m.calc_lc(opt) for m in self.vb)
+
+    def update(self, opt=None):                                          # mlp.lua:117-142 (final-layer slice fixed, see vbnn_amd/mlp.py)
+        opt = opt or self.opt
+        lr = opt["state"]["learningRate"]
+        sgd_step(self.last.weight, self.last.gradWeight, lr)
+        sgd_step(self.last.bias, self.last.gradBias, lr)
+        return [m.update(opt) for m in self.vb]

@@ -248,6 +248,33 @@ def test_reference_cpu_port_matches_oracle_math(oracle):
     assert y0.shape == (7, 10)
 
 
+def test_adam_and_sgd_restatement(oracle):
+    """vbo_adam_step == the published Adam in float64, and agrees with torch.optim.Adam (which places eps
+    after the bias correction: identical up to eps-sized terms when |g| >> eps); vbo_sgd_step == x - lr g."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(8)
+    x0 = rng.normal(0, 1, 257).astype(np.float32)
+    gs = [rng.normal(0, 1, 257).astype(np.float32) for _ in range(5)]
+    x, m, v = x0.copy(), np.zeros_like(x0), np.zeros_like(x0)
+    x64, m64, v64 = x0.astype(np.float64), np.zeros(257), np.zeros(257)
+    tx = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+    topt = torch.optim.Adam([tx], lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    for t, g in enumerate(gs, start=1):
+        upd = oracle.adam_step(x, g, m, v, 1e-2, 0.9, 0.999, 1e-8, t)
+        m64 = 0.9 * m64 + 0.1 * g
+        v64 = 0.999 * v64 + 0.001 * g.astype(np.float64) ** 2
+        step = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        x64 = x64 - step * m64 / (np.sqrt(v64) + 1e-8)
+        tx.grad = torch.tensor(g, dtype=torch.float64)
+        topt.step()
+        np.testing.assert_allclose(x, x64, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(x, tx.detach().numpy(), rtol=1e-4, atol=1e-5)
+        assert np.abs(upd).max() <= 1.0001e-2 * 3.2          # |update| <= lr / sqrt(1 - b2) bound, loosely
+    y = x0.copy()
+    oracle.sgd_step(y, gs[0], 0.25)
+    np.testing.assert_allclose(y, x0 - 0.25 * gs[0], rtol=1e-6, atol=1e-7)
+
+
 def test_committed_golden_vectors(oracle):
     """Regression pin: the oracle reproduces tests/golden/vblinear_small.npz (made by make_golden.py)."""
     gold = np.load(os.path.join(HERE, "golden", "vblinear_small.npz"))

@@ -361,13 +361,17 @@ def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidd
     close(eng.gradBias3, gb3, "final gradBias")
 
 
-@pytest.fixture(params=[1, 2], ids=["general-kernel", "pipelined-kernel"])
+@pytest.fixture(params=[(1, 0), (2, 256), (2, 128)], ids=["general-kernel", "pipelined-256x128", "pipelined-128x128"])
 def gemm_kernel(request, nnmod):
-    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h), whatever the shape heuristics say."""
+    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in both block tiles), whatever the shape
+    heuristics say."""
     from vbnn_amd import _lib as L
-    L.check(L.lib().vbnn_debug_set(0, request.param))
+    kernel, tile = request.param
+    L.check(L.lib().vbnn_debug_set(0, kernel))
+    L.check(L.lib().vbnn_debug_set(2, tile))
     yield request.param
     L.check(L.lib().vbnn_debug_set(0, 0))
+    L.check(L.lib().vbnn_debug_set(2, 0))
 
 
 @pytest.mark.parametrize("N,I,O", [(1, 8, 8), (37, 70, 50), (300, 200, 260), (512, 448, 384), (200, 4096, 130)])
@@ -422,6 +426,60 @@ def test_layer_bf16_against_rounded_operands(nnmod, oracle, gemm_kernel, N, I, O
     assert np.abs(host(m.gradWeight) - want_gw).max() <= 1e-3 * np.abs(want_gw).max()
     want_gs = 2 * (gvr.T @ x2r) * np.sqrt(np.exp(om.lvars.astype(np.float64)))
     assert np.abs(host(m.gradSum) - want_gs).max() <= 1e-3 * np.abs(want_gs).max()
+
+
+# ------------------------------------------------------------------------------------------- update
+OPT_STATES = dict(state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
+
+
+@pytest.mark.parametrize("mode", ["wn", "lrt"])
+def test_module_update_matches_oracle(nnmod, oracle, mode):
+    """mlp:update / VBLinear:update (mlp.lua:117-142, VBLinear.lua:124-166) after a two-draw minibatch, twice
+    (Adam state carried across): parameters, Adam-visible ratios and the next step's loss."""
+    from vbnn_amd import mlp
+    opt = opt_for(mode, S=2, input_size=70, hidden=[50, 34], **OPT_STATES)
+    net, onet = mlp.buildModel(opt), oracle.OracleMLP(opt)
+    for k, i in enumerate(net.vb_indices):
+        mod, om = net.model.get(i), onet.vb[k]
+        om.means[:] = om.weight; mod.means.copy_(mod.weight)
+        mod.compute_prior(); om.compute_prior()
+    N = 37
+    x = oracle.fill_normal(N, 70, SEED, 4, 0, 0)
+    t = (np.arange(N) * 7 % 10).astype(np.int32)
+    for it in range(2):
+        net.resetGradients(); onet.resetGradients()
+        for _ in range(2):
+            net.sample(); onet.sample()
+            err, _ = net.run(dev(x), dev(t))
+            werr, _ = onet.run(x, t)
+            assert abs(err - werr) <= 5e-5 * abs(werr) + 1e-6, (it, err, werr)
+        ratios, wratios = net.update(opt), onet.update(opt)
+        for k, i in enumerate(net.vb_indices):
+            mod, om = net.model.get(i), onet.vb[k]
+            # Adam's first steps move every weight by ~lr whatever the gradient scale, so compare absolutely
+            np.testing.assert_allclose(host(mod.means), om.means, rtol=0, atol=2e-3 * 1e-4 + 1e-7 * np.abs(om.means).max())
+            np.testing.assert_allclose(host(mod.lvars), om.lvars, rtol=0, atol=2e-3 * 5e-2)
+            np.testing.assert_allclose(host(mod.bias), om.bias, rtol=0, atol=1e-8 + 1e-5 * np.abs(om.bias).max())
+            for a, b in zip(ratios[k], wratios[k]):
+                assert abs(a - b) <= 2e-3 * b
+        last = net.model.get(2 * (len(opt["hidden"]) + 1))
+        np.testing.assert_allclose(host(last.weight), onet.last.weight, rtol=0, atol=1e-7 * np.abs(onet.last.weight).max() + 1e-9)
+
+
+def test_engine_update_matches_oracle(oracle, nnmod):
+    """FusedMLP.update (total gradients straight from the dW epilogue) == the reference's update sequence."""
+    opt, eng, onet = _engine_pair(oracle, "lrt", "f32", [50, 34], 70, True, S=1)
+    opt.update(OPT_STATES)
+    for it in range(2):
+        loss, werr = _run_pair(opt, eng, onet, oracle, 37, 70)
+        assert abs(loss - werr) <= 5e-5 * abs(werr) + 1e-6, (it, loss, werr)
+        eng.update(opt); onet.update(opt)
+        for k, v in enumerate(eng.vb):
+            om = onet.vb[k]
+            np.testing.assert_allclose(host(v.means), om.means, rtol=0, atol=2e-3 * 1e-4 + 1e-7 * np.abs(om.means).max())
+            np.testing.assert_allclose(host(v.lvars), om.lvars, rtol=0, atol=2e-3 * 5e-2)
+            np.testing.assert_allclose(host(v.bias), om.bias, rtol=0, atol=1e-8 + 1e-5 * np.abs(om.bias).max())
+        np.testing.assert_allclose(host(eng.weight3), onet.last.weight, rtol=0, atol=1e-7 * np.abs(onet.last.weight).max() + 1e-9)
 
 
 # ------------------------------------------------------------------------------------------- errors

@@ -30,7 +30,7 @@ def run(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-scheds = [int(a) for a in sys.argv[1:]] or [0, 1]
+scheds = [int(a) for a in sys.argv[1:]] or [0, 2]
 res = {}
 for rnd in range(5):
     for s in scheds:

@@ -73,6 +73,8 @@ _SIGS = {
     "vbnn_compute_mugrads": ([_vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),
     "vbnn_compute_vargrads": ([_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),
     "vbnn_calc_lc": ([_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64], _i),
+    "vbnn_adam_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _vp], _i),
+    "vbnn_sgd_step": ([_vp, _vp, _vp, _i64, _f], _i),
     "vbnn_relu_forward": ([_vp, _vp, _vp, _i64], _i),
     "vbnn_relu_backward": ([_vp, _vp, _vp, _vp, _i64], _i),
     "vbnn_logsoftmax_nll": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp], _i),

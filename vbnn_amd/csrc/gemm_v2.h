@@ -6,20 +6,27 @@
 // filled by LDS-DMA (global_load_lds_dwordx4) that stays in flight ACROSS the barrier, counted
 // s_waitcnt vmcnt(N), raw s_barrier, all LDS in one array.
 //
-//   workgroup   512 threads = 8 waves as 4 (M) x 2 (N); wave tile 64 x 64; block tile 256 x 128
-//   K step      64 bf16 = 128 B per row; A tile 32 KiB + B tile 16 KiB = 48 KiB per stage
-//   ring        3 stages (144 KiB of the CU's 160 KiB): loads run two tiles ahead of the MFMAs
+//   workgroup   2 WM waves as WM (M) x 2 (N); wave tile 64 x 64; block tile (64 WM) x 128
+//               WM = 4: 512 threads, 256 x 128 -- the default; WM = 2: 256 threads, 128 x 128 -- for outputs
+//               too small to give every CU a 256 x 128 tile (e.g. the 784 x 4096 gradient of layer 1)
+//   K step      64 bf16 = 128 B per row; stage = A tile (8 KiB per 64 rows) + B tile (16 KiB)
+//   ring        3 stages (144 KiB at WM = 4): DMAs run two tiles ahead of the MFMAs
 //   tile stream DUAL alternates the pairs: (A,B,k0) -> acc1, (A2,B2,k0) -> acc2, (A,B,k0+64) ...
 //               so the register cost of the second GEMM is only its accumulator
 //   MFMA        v_mfma_f32_16x16x32_bf16, 32 per wave per tile (4 x 4 output tiles x 2 k-halves)
 //   LDS image   lane-linear as the DMA writes it (8 rows x 128 B per wave-instruction); the bank
 //               swizzle chunk' = chunk ^ ((row >> 1) & 7) is applied on the per-lane SOURCE address
 //               and again on the ds_read_b128 address (rule 21: both sides or neither). With it the
-//               16 rows x 1 chunk a lane group reads fall on 16 distinct 16-byte bank slots.
-//   per tile    s_waitcnt vmcnt(6)  -> this wave's DMAs for tile u have landed (tile u+1's 6 may fly)
+//               16 rows x 1 chunk a lane group reads fall on 16 distinct 16-byte bank slots
+//               (SQ_LDS_BANK_CONFLICT = 0 measured).
+//   per tile    s_waitcnt vmcnt(G)  -> this wave's G DMAs of tile u have landed (tile u+1's may fly)
 //               s_barrier           -> everybody's have; everybody is done reading tile u-1
-//               issue DMAs of tile u+2 into the buffer tile u-1 occupied
-//               16 ds_read_b128 + 32 MFMA on tile u
+//               16 ds_read_b128 + 32 MFMA on tile u, with the G DMAs of tile u+2 (into the buffer tile
+//               u-1 occupied) issued one after every four MFMAs (SCHED 2). Bursting them right after the
+//               barrier instead (SCHED 0) serialises the CU's 64 B/clk texture path in front of the matrix
+//               pipe: s_memtime stamps put 32 % of a wave's time in that burst; interleaving is +20 %.
+//   epilogue    accumulators re-laid through LDS into rows of n, so a wave-instruction stores 4 rows x 64
+//               contiguous m; transposed outputs take a second LDS trip (see the end of the kernel).
 //
 // Any M, N >= 1 (row-clamped sources, masked epilogue); K is padded by the packed-operand
 // convention (ld % 64 == 0, zero fill).
@@ -27,12 +34,12 @@
 #include "common.h"
 #include <type_traits>
 
-constexpr int V2_BM = 256, V2_BN = 128, V2_BK = 64;
-constexpr int V2_A_BYTES = V2_BM * V2_BK * 2;           // 32768
+constexpr int V2_BN = 128, V2_BK = 64;
 constexpr int V2_B_BYTES = V2_BN * V2_BK * 2;           // 16384
-constexpr int V2_STAGE = V2_A_BYTES + V2_B_BYTES;       // 49152
 constexpr int V2_STAGES = 3;
-constexpr int V2_LDS = V2_STAGE * V2_STAGES;            // 147456
+constexpr int v2_a_bytes(int WM) { return 64 * WM * V2_BK * 2; }
+constexpr int v2_stage(int WM) { return v2_a_bytes(WM) + V2_B_BYTES; }
+constexpr int v2_lds(int WM) { return v2_stage(WM) * V2_STAGES; }     // 147456 (WM 4) / 98304 (WM 2)
 
 // Diagnostic stamps (tools/gemm_lab.hip builds with -DV2_DIAG; the library never does): per-wave cycle
 // sums of the segments of schedule 0, written to a buffer of their own, never to an output.
@@ -48,7 +55,7 @@ __device__ unsigned long long* g_v2_diag = nullptr;
     } while (0)
 #define V2_STAMP_FLUSH                                                                                \
     if (g_v2_diag && lane == 0) {                                                                     \
-        for (int k = 0; k < 4; ++k) g_v2_diag[((size_t)blockIdx.x * 8 + wave) * 4 + k] = v2_sum[k];   \
+        for (int k = 0; k < 4; ++k) g_v2_diag[((size_t)blockIdx.x * NW + wave) * 4 + k] = v2_sum[k];  \
     }
 #else
 #define V2_STAMP_DECL
@@ -56,15 +63,28 @@ __device__ unsigned long long* g_v2_diag = nullptr;
 #define V2_STAMP_FLUSH
 #endif
 
-static int g_v2_sched = 2;        // 0: burst DMAs after the barrier; 1: staggered wave groups; 2: DMAs interleaved with the MFMAs (default); 3: 2 + fragment prefetch (vbnn_debug_set key 1)
+static int g_v2_sched = 2;        // 0: burst the DMAs after the barrier; 2: interleave them with the MFMAs (default)
+static int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <bool DUAL, int SCHED, class Epi>
-__global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
-                                                     const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
-                                                     int M, int N, int nk, int tiles_m, int tiles_n, Epi epi) {
+template <int N> __device__ __forceinline__ void v2_wait_vmcnt();
+template <> __device__ __forceinline__ void v2_wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void v2_wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void v2_wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+
+template <bool DUAL, int SCHED, int WM, class Epi>
+__global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
+                                                          const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
+                                                          int M, int N, int nk, int tiles_m, int tiles_n, Epi epi) {
+    constexpr int NW = 2 * WM;                 // waves per workgroup
+    constexpr int BM = 64 * WM;
+    constexpr int A_BYTES = v2_a_bytes(WM), STAGE = v2_stage(WM);
+    constexpr int AG = (BM / 8) / NW;          // 8-row DMA groups of the A tile per wave (4)
+    constexpr int BG = (V2_BN / 8) / NW;       // ... of the B tile (2 at WM = 4, 4 at WM = 2)
+    constexpr int G = AG + BG;                 // DMAs per wave per tile
+    static_assert(AG == 4 && (G == 6 || G == 8), "unsupported geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -73,7 +93,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
 
     // ---- block -> tile mapping. Blocks that share an XCD (bid % 8, T1) get a contiguous chunk of
     // the tile list; inside it tiles are walked in 4 (M) x 8 (N) groups so the ~32 blocks running
-    // together on an XCD share 4 A panels and 8 B panels in its L2.
+    // together on an XCD share 4 A panels and 8 B panels in its L2 (measured hit rate 81 % = the ideal
+    // 1 - 12/64 of that grouping).
     const int nblk = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {
@@ -83,41 +104,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
     int tm, tn;
     {
         constexpr int GM = 4, GN = 8;
-        const int groups_n = (tiles_n + GN - 1) / GN;
-        const int per_band = GM * tiles_n;                // tiles in a band of GM tile-rows
+        const int per_band = GM * tiles_n;                // tiles in a band of GM tile-rows (all bands but the last are full)
         const int band = bid / per_band;
         const int in_band = bid - band * per_band;
         const int band_rows = min(GM, tiles_m - band * GM);
-        // inside a band: groups of (band_rows x GN), the last group may be narrower
-        const int full = band_rows * GN;
-        int grp = in_band / full;
-        int in_grp = in_band - grp * full;
-        if (grp >= groups_n) { grp = groups_n - 1; in_grp = in_band - grp * full; }
+        const int full = band_rows * GN;                  // tiles in a full group of GN tile-columns
+        const int grp = in_band / full;                   // only the last group of a band can be narrower
+        const int in_grp = in_band - grp * full;
         const int grp_cols = min(GN, tiles_n - grp * GN);
-        tm = band * GM + in_grp / grp_cols;
+        tm = min(band * GM + in_grp / grp_cols, tiles_m - 1);
         tn = grp * GN + in_grp % grp_cols;
-        if (tm >= tiles_m) { tm = tiles_m - 1; }          // unreachable for consistent inputs; keeps loads in range
     }
-    const int m0 = tm * V2_BM, n0 = tn * V2_BN;
+    const int m0 = tm * BM, n0 = tn * V2_BN;
 
-    // ---- LDS-DMA source pointers. A: 32 groups of 8 rows, 4 per wave; B: 16 groups, 2 per wave.
-    // Lane l of the instruction for group g fills LDS position (row 8g + (l>>3), chunk slot l&7) with
-    // global chunk (l&7) ^ f(row), f(row) = (row >> 1) & 7.
-    const bf16_t* a_src[2][4];
-    const bf16_t* b_src[2][2];
+    // ---- LDS-DMA source pointers. Lane l of the instruction for 8-row group g fills LDS position
+    // (row 8g + (l>>3), chunk slot l&7) with global chunk (l&7) ^ f(row), f(row) = (row >> 1) & 7.
+    const bf16_t* a_src[2][AG];
+    const bf16_t* b_src[2][BG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = wave + 8 * i;
-        const int row = 8 * g + (lane >> 3);
+    for (int i = 0; i < AG; ++i) {
+        const int row = 8 * (wave + NW * i) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         const int64_t off = (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
         a_src[0][i] = A + off;
         a_src[1][i] = DUAL ? A2 + off : A + off;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int g = wave + 8 * i;
-        const int row = 8 * g + (lane >> 3);
+    for (int i = 0; i < BG; ++i) {
+        const int row = 8 * (wave + NW * i) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         const int64_t off = (int64_t)min(n0 + row, N - 1) * ldb + chunk * 8;
         b_src[0][i] = B + off;
@@ -125,35 +139,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
     }
     const int U = DUAL ? 2 * nk : nk;       // tiles in the stream
 
-    // `pair` is a compile-time constant at every call site (the loop below is unrolled by the pair
+    // `pair` / `idx` are compile-time constants at every call site (the loop below is unrolled by the pair
     // period), so the pointer arrays stay in registers (runtime-indexed arrays would go to scratch).
-    auto issue_part = [&](int u, auto pair_c, auto part_c) {
-        constexpr int P = decltype(pair_c)::value;
-        constexpr int PART = decltype(part_c)::value;     // 0: A groups 0-2, 1: A group 3 + both B groups, 2: all six
-        const int64_t koff = (int64_t)(DUAL ? (u >> 1) : u) * V2_BK;
-        unsigned char* base = lds + (u % V2_STAGES) * V2_STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (PART == 2 || (PART == 0) == (i < 3))
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][i] + koff), (lptr_t)(base + (wave + 8 * i) * 1024), 16, 0, 0);
-        if (PART != 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][i] + koff),
-                                                 (lptr_t)(base + V2_A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
-        }
-    };
-    auto issue = [&](int u, auto pair_c) { issue_part(u, pair_c, std::integral_constant<int, 2>()); };
-    auto issue_one = [&](int u, auto pair_c, auto idx_c) {      // DMA number IDX (0-3: A groups, 4-5: B groups) of tile u
+    auto issue_one = [&](int u, auto pair_c, auto idx_c) {      // DMA number IDX (0..AG-1: A groups, then B groups) of tile u
         constexpr int P = decltype(pair_c)::value;
         constexpr int IDX = decltype(idx_c)::value;
         const int64_t koff = (int64_t)(DUAL ? (u >> 1) : u) * V2_BK;
-        unsigned char* base = lds + (u % V2_STAGES) * V2_STAGE;
-        if constexpr (IDX < 4)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + 8 * IDX) * 1024), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][IDX - 4] + koff),
-                                             (lptr_t)(base + V2_A_BYTES + (wave + 8 * (IDX - 4)) * 1024), 16, 0, 0);
+        unsigned char* base = lds + (u % V2_STAGES) * STAGE;
+        if constexpr (IDX < AG)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + NW * IDX) * 1024), 16, 0, 0);
+        else if constexpr (IDX < G)
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][IDX - AG] + koff),
+                                             (lptr_t)(base + A_BYTES + (wave + NW * (IDX - AG)) * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int u, auto pair_c) {
+        issue_one(u, pair_c, std::integral_constant<int, 0>()); issue_one(u, pair_c, std::integral_constant<int, 1>());
+        issue_one(u, pair_c, std::integral_constant<int, 2>()); issue_one(u, pair_c, std::integral_constant<int, 3>());
+        issue_one(u, pair_c, std::integral_constant<int, 4>()); issue_one(u, pair_c, std::integral_constant<int, 5>());
+        issue_one(u, pair_c, std::integral_constant<int, 6>()); issue_one(u, pair_c, std::integral_constant<int, 7>());
     };
 
     // ---- fragment read offsets (bytes inside a stage). Lane reads row r = base + (l & 15), chunk
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
     for (int s = 0; s < 2; ++s) {
         const int csw = ((4 * s + q) ^ rsw) * 16;
         a_off[s] = (wm * 64 + (lane & 15)) * 128 + csw;
-        b_off[s] = V2_A_BYTES + (wn * 64 + (lane & 15)) * 128 + csw;
+        b_off[s] = A_BYTES + (wn * 64 + (lane & 15)) * 128 + csw;
     }
 
     f32x4 acc1[4][4], acc2[4][4];
@@ -174,23 +177,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-    auto compute = [&](const unsigned char* stage, f32x4 (&acc)[4][4]) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[s] + i * 16 * 128);
-                bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[s] + i * 16 * 128);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-    };
 
     std::integral_constant<int, 0> c0;
     std::integral_constant<int, 1> c1;
@@ -200,170 +186,52 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
     issue(0, c0);
     if (U > 1) { if (DUAL) issue(1, c1); else issue(1, c0); }
 
-    if constexpr (SCHED == 0) {
-        // ---- schedule 0: one barrier per tile, every wave reads then multiplies
-        auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
-            V2_STAMP(0);
-            if (u + 1 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            V2_STAMP(1);                                     // [0->1] waiting for this wave's DMAs
-            __builtin_amdgcn_s_barrier();
-            V2_STAMP(2);                                     // [1->2] barrier
-            if (u + 2 < U) issue(u + 2, pair_c);            // tile u+2 belongs to the same pair as tile u
-            V2_STAMP(3);                                     // [2->3] issuing 6 DMAs
-            compute(lds + (u % V2_STAGES) * V2_STAGE, acc);
-            V2_STAMP(4);                                     // [3->4] 16 ds_read_b128 + 32 MFMA
-        };
-        if (DUAL) {
-            for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
-        } else {
-            for (int u = 0; u < U; ++u) step(u, c0, acc1);
-        }
-    } else if constexpr (SCHED == 2) {
-        // ---- schedule 2: one barrier per tile as schedule 0, but the six DMAs of tile u+2 are spread through the
-        // MFMA stream of tile u (one after every 5-6 MFMAs) instead of bursting after the barrier: the texture path
-        // (64 B/clk/CU) then works beside the matrix pipe instead of in front of it.
-        auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
-            if (u + 1 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const unsigned char* stage = lds + (u % V2_STAGES) * V2_STAGE;
-            const bool more = u + 2 < U;
+    auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
+        V2_STAMP(0);
+        if (u + 1 < U) v2_wait_vmcnt<G>();
+        else           v2_wait_vmcnt<0>();
+        V2_STAMP(1);                                     // [0->1] waiting for this wave's DMAs
+        __builtin_amdgcn_s_barrier();
+        V2_STAMP(2);                                     // [1->2] barrier
+        const bool more = u + 2 < U;                     // tile u+2 belongs to the same pair as tile u
+        if (SCHED == 0 && more) issue(u + 2, pair_c);
+        V2_STAMP(3);                                     // [2->3] issuing the DMAs (schedule 0)
+        const unsigned char* stage = lds + (u % V2_STAGES) * STAGE;
 #pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-                bf16x8 af[4], bf[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
-                    bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                    if (more) {
-                        if (sidx == 0 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
-                        if (sidx == 0 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
-                        if (sidx == 0 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
-                        if (sidx == 1 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
-                        if (sidx == 1 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
-                        if (sidx == 1 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
-                    }
-                    __builtin_amdgcn_sched_barrier(0);       // keep each DMA behind its four MFMAs
-                }
-            }
-        };
-        if (DUAL) {
-            for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
-        } else {
-            for (int u = 0; u < U; ++u) step(u, c0, acc1);
-        }
-    } else if constexpr (SCHED == 3) {
-        // ---- schedule 3 (= 2 with both k-halves' fragments read up front and s_setprio around the MFMAs): one barrier per tile as schedule 0, but the six DMAs of tile u+2 are spread through the
-        // MFMA stream of tile u (one after every 5-6 MFMAs) instead of bursting after the barrier: the texture path
-        // (64 B/clk/CU) then works beside the matrix pipe instead of in front of it.
-        auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
-            if (u + 1 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const unsigned char* stage = lds + (u % V2_STAGES) * V2_STAGE;
-            const bool more = u + 2 < U;
-            bf16x8 afr[2][4], bfr[2][4];
-#pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    afr[sidx][i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
-                    bfr[sidx][i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
-                }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[sidx][i], bfr[sidx][j], acc[i][j], 0, 0, 0);
-                    if (more) {
-                        if (sidx == 0 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
-                        if (sidx == 0 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
-                        if (sidx == 0 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
-                        if (sidx == 1 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
-                        if (sidx == 1 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
-                        if (sidx == 1 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
-                    }
-                    __builtin_amdgcn_sched_barrier(0);       // keep each DMA behind its four MFMAs
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        if (DUAL) {
-            for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
-        } else {
-            for (int u = 0; u < U; ++u) step(u, c0, acc1);
-        }
-    } else {
-        // ---- schedule 1: the two waves of a SIMD (w and w + 4) run one barrier apart, so one reads LDS
-        // while the other owns the matrix pipe (MI355X_MICROARCH.md "Two waves per SIMD", item 9; the
-        // `if (wr == 1) s_barrier` of the 8-phase template). A tile is four slots:
-        //   READ(k-half 0) | MFMA(0) | READ(1) | MFMA(1),   16 MFMA per slot, a barrier after each.
-        // Early waves (0-3) are in slot 4u when late waves (4-7) are in slot 4u - 1.
-        // RAW: every wave waits for its DMAs of tile u+1 before the barrier that opens slot 4u+4
-        //      (early waves: their 4th barrier of tile u; late waves: their 3rd).
-        // WAR: reads are retired (lgkmcnt(0)) before the barrier that closes their slot, and tile u+2 is
-        //      issued into tile u-1's buffer at the top of tile u, after every read of tile u-1.
-        const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
-        auto read_half = [&](const unsigned char* stage, int sidx, bf16x8 (&af)[4], bf16x8 (&bf)[4]) {
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            bf16x8 af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
                 bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto mfma_half = [&](const bf16x8 (&af)[4], const bf16x8 (&bf)[4], f32x4 (&acc)[4][4]) {
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto wait_next = [&](int u) {                        // DMAs of tile u+1 (tile u+2's may stay in flight)
-            if (u + 2 < U) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        if (U > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (late) __builtin_amdgcn_s_barrier();              // the stagger
-        auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
-            const unsigned char* stage = lds + (u % V2_STAGES) * V2_STAGE;
-            bf16x8 af[4], bf[4];
-            if (u + 2 < U) issue_part(u + 2, pair_c, std::integral_constant<int, 0>());   // 3 DMAs per READ slot
-            read_half(stage, 0, af, bf);
-            __builtin_amdgcn_s_barrier();
-            mfma_half(af, bf, acc);
-            __builtin_amdgcn_s_barrier();
-            if (u + 2 < U) issue_part(u + 2, pair_c, std::integral_constant<int, 1>());
-            read_half(stage, 1, af, bf);
-            if (late) wait_next(u);
-            __builtin_amdgcn_s_barrier();
-            mfma_half(af, bf, acc);
-            if (!late) wait_next(u);
-            __builtin_amdgcn_s_barrier();
-        };
-        if (DUAL) {
-            for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
-        } else {
-            for (int u = 0; u < U; ++u) step(u, c0, acc1);
+                if (SCHED == 2) {
+                    if (more) {                          // one DMA behind every four MFMAs
+                        if (sidx == 0 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
+                        if (sidx == 0 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
+                        if (sidx == 0 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
+                        if (sidx == 0 && i == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 6>());
+                        if (sidx == 1 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
+                        if (sidx == 1 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
+                        if (sidx == 1 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
+                        if (sidx == 1 && i == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 7>());
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep each DMA behind its four MFMAs
+                }
+            }
         }
-        if (!late) __builtin_amdgcn_s_barrier();             // early waves take the barrier the late ones took up front
+        V2_STAMP(4);                                     // [3->4] 16 ds_read_b128 + 32 MFMA
+    };
+    if (DUAL) {
+        for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+    } else {
+        for (int u = 0; u < U; ++u) step(u, c0, acc1);
     }
-
     V2_STAMP_FLUSH
 
     // ---- epilogue. The ring is idle now: each wave re-lays its 64 x 64 accumulator tile through a private
@@ -373,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v2(const bf16_t* __restrict__ 
     typedef typename Epi::elem_t ET;
     constexpr int SP = 68;                                    // fp32 staging pitch (floats): conflict-free b128 rows
     constexpr int TP = 72;                                    // transposed staging pitch (elements), 16-byte multiple
+    static_assert(NW * 18432 <= v2_lds(WM), "epilogue staging must fit the ring");
     __syncthreads();                                          // every wave is done reading the last tile
     float* st = reinterpret_cast<float*>(lds + wave * 18432);
     const int c16 = lane & 15, q4 = lane >> 4;
@@ -441,13 +310,14 @@ template <typename T>
 static inline bool gemm_v2_possible(int64_t lda, int64_t ldb) {
     return sizeof(T) == 2 && (lda % 64) == 0 && (ldb % 64) == 0;
 }
+// blocks of the 256 x 128 tiling / of the 128 x 128 tiling
+static inline int64_t v2_tiles(int64_t M, int64_t N, int bm) { return ((M + bm - 1) / bm) * ((N + V2_BN - 1) / V2_BN); }
 template <typename T>
 static inline bool gemm_v2_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
     (void)K;
     if (!gemm_v2_possible<T>(lda, ldb)) return false;
-    // worth it only when the 256 x 128 tiling gives the chip something like one block per CU
-    const int64_t tiles = ((M + V2_BM - 1) / V2_BM) * ((N + V2_BN - 1) / V2_BN);
-    return tiles >= 96;
+    // worth it only when a tiling gives the chip something like one block per CU
+    return v2_tiles(M, N, 128) >= 96;
 }
 
 template <typename T, bool DUAL, class Epi>
@@ -466,16 +336,35 @@ static int launch_gemm_v2(hipStream_t stream, const T* A, const T* A2, int64_t l
             vbnn_set_error("packed leading dimension too small for K=%d", K);
             return VBNN_ERR_INVALID;
         }
-        const int tiles_m = (M + V2_BM - 1) / V2_BM, tiles_n = (N + V2_BN - 1) / V2_BN;
-        auto kern = (g_v2_sched == 0) ? gemm_nt_v2<DUAL, 0, Epi> : (g_v2_sched == 1) ? gemm_nt_v2<DUAL, 1, Epi> : (g_v2_sched == 2) ? gemm_nt_v2<DUAL, 2, Epi> : gemm_nt_v2<DUAL, 3, Epi>;
-        static bool configured[4] = {false, false, false, false};      // per instantiation of this launcher
-        if (!configured[g_v2_sched]) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
-            if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
-            configured[g_v2_sched] = true;
+        // 256 x 128 tiles unless they would leave more than a quarter of the 256 CUs without a block while the
+        // 128 x 128 tiling fills more of them (the 784 x 4096 gradient: 128 blocks vs 224)
+        const int64_t t256 = v2_tiles(M, N, 256), t128 = v2_tiles(M, N, 128);
+        const bool small = g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256);
+        const int sched = g_v2_sched == 0 ? 0 : 2;
+        const void* kern;
+        int threads, lds_bytes, bm;
+        if (small) {
+            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 2, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 2, Epi>;
+            threads = 256; lds_bytes = v2_lds(2); bm = 128;
+        } else {
+            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 4, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 4, Epi>;
+            threads = 512; lds_bytes = v2_lds(4); bm = 256;
         }
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), V2_LDS, stream, (const bf16_t*)A, (const bf16_t*)A2, lda,
-                           (const bf16_t*)B, (const bf16_t*)B2, ldb, M, N, nk, tiles_m, tiles_n, epi);
+        static bool configured[2][2] = {{false, false}, {false, false}};      // per instantiation of this launcher
+        if (!configured[small][sched != 0]) {
+            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+            configured[small][sched != 0] = true;
+        }
+        const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + V2_BN - 1) / V2_BN;
+        const bf16_t* a = (const bf16_t*)A; const bf16_t* a2 = (const bf16_t*)A2;
+        const bf16_t* b = (const bf16_t*)B; const bf16_t* b2 = (const bf16_t*)B2;
+        int nk_ = nk, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
+        int64_t lda_ = lda, ldb_ = ldb;
+        Epi epi_ = epi;
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &epi_};
+        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n), dim3(threads), args, lds_bytes, stream);
+        if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v2 failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
         return vbnn_check_launch("gemm_nt_v2");
     }
 }

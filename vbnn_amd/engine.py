@@ -24,7 +24,7 @@ class _VB:
 
 
 class FusedMLP:
-    def __init__(self, opt, device=None, world_size=1, rank=0, process_group=None):
+    def __init__(self, opt, device=None, world_size=1, rank=0, process_group=None, force_reduce=False):
         self.opt = opt
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.ctx = Context.get(self.device)
@@ -34,6 +34,7 @@ class FusedMLP:
         assert self.mode in ("wn", "lrt")
         self.seed = int(opt.get("seed", 3))
         self.world, self.rank, self.pg = world_size, rank, process_group
+        self.reduce = world_size > 1 or force_reduce
         self.fuse_kl = bool(opt.get("fuse_kl", True))
         self.B, self.S = float(opt.get("B", 1e6)), float(opt.get("S", 1))
         hidden = list(opt["hidden"])
@@ -280,7 +281,7 @@ class FusedMLP:
     # right after that layer's accGradParameters so it overlaps the rest of backward. The criterion
     # already divides by the GLOBAL batch and the KL gradient carries 1/world, so the sum is the result.
     def _reduce(self, bucket):
-        if self.world > 1:
+        if self.reduce:
             import torch.distributed as dist
             self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -289,6 +290,31 @@ class FusedMLP:
         for w in self._works:
             w.wait()
         self._works = []
+
+    # ---- mlp:update + VBLinear:update (mlp.lua:117-142, VBLinear.lua:124-166) on the device: the dW epilogue
+    # already produced the TOTAL gradients (likelihood / S + KL), so the update is one Adam pass per parameter
+    # tensor; nothing is downloaded. Needs fuse_kl (otherwise use vbnn_amd/mlp.py's module-level update).
+    def update(self, opt=None):
+        if not self.fuse_kl:
+            raise RuntimeError("FusedMLP.update needs opt.fuse_kl = True (total gradients from the dW epilogue)")
+        opt = opt or self.opt
+        self.finish()
+        lib, h = L.lib(), self.ctx.h
+        lr = float(opt["state"]["learningRate"])
+        st = self.__dict__.setdefault("_opt_state", {})
+        for v in self.vb:
+            L.check(lib.vbnn_sgd_step(h, _p(v.bias), _p(v.gradBias), v.O, lr))
+            for key, x, g, cfg in (("mean", v.means, v.gradWeight, opt["meanState"]), ("var", v.lvars, v.gradSum, opt["varState"])):
+                s = st.setdefault((v.layer_id, key), {"t": 0})
+                if "m" not in s:
+                    s["m"], s["v"] = torch.zeros_like(x), torch.zeros_like(x)
+                s["t"] += 1
+                L.check(lib.vbnn_adam_step(h, _p(x), _p(g), None, _p(s["m"]), _p(s["v"]), x.numel(),
+                                           float(cfg["learningRate"]), float(cfg.get("beta1", 0.9)),
+                                           float(cfg.get("beta2", 0.999)), float(cfg.get("epsilon", 1e-8)),
+                                           float(cfg.get("lambda", 1.0)), s["t"], None))
+        L.check(lib.vbnn_sgd_step(h, _p(self.weight3), _p(self.gradWeight3), self.weight3.numel(), lr))
+        L.check(lib.vbnn_sgd_step(h, _p(self.bias3), _p(self.gradBias3), self.bias3.numel(), lr))
 
     # ---- reporting (each of these synchronises)
     def loss_and_accuracy(self):

@@ -89,5 +89,23 @@ class MLP:
         return lc
 
 
+    def update(self, opt=None):                                          # mlp.lua:117-142
+        """optim.sgd on the final Linear (`opt.state.learningRate`), then VBLinear:update per VB layer.
+        Documented fix: the reference narrows the flat parameter vector to its LAST 110 entries
+        (mlp.lua:41-42: 10*10 + 10, right only when the last hidden layer has 10 units); here the final
+        Linear's whole weight and bias are updated, which is what that slice means for hidden = {10}."""
+        opt = opt or self.opt
+        lr = float(opt["state"]["learningRate"])
+        last = self.model.get(2 * (len(opt["hidden"]) + 1))
+        lib, h = L.lib(), last.ctx.h
+        if opt.get("type", "vb") == "vb":
+            L.check(lib.vbnn_sgd_step(h, nn._p(last.weight), nn._p(last.gradWeight), last.weight.numel(), lr))
+            L.check(lib.vbnn_sgd_step(h, nn._p(last.bias), nn._p(last.gradBias), last.bias.numel(), lr))
+            return [self.model.get(i).update(opt) for i in self.vb_indices]  # :137-141
+        for p, g in zip(self.parameters, self.gradParameters):              # :125-128
+            L.check(lib.vbnn_sgd_step(h, nn._p(p), nn._p(g), p.numel(), lr))
+        return []
+
+
 def buildModel(opt, device=None):
     return MLP().buildModel(opt, device)

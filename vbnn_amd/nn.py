@@ -541,3 +541,30 @@ class VBLinear(Linear):
         L.check(L.lib().vbnn_calc_lc(self.ctx.h, None, None, _p(self.vars), _p(self.mu_sqe), _p(self._stats_cached),
                                      float(opt["B"]), _p(lc_elem), _p(self._lc), self.W))
         return (self._lc, lc_elem) if elementwise else self._lc
+
+    # -- VBLinear.lua:124-166: SGD on bias, compute_prior, likelihood + KL gradients, optim.adam on means (meanState)
+    # and lvars (varState). Returns (mu_normratio, var_normratio), the two ratios the reference logs (:139,144);
+    # its other twelve Log:add statistics (:149-164) are host-side logging and are not reproduced.
+    def update(self, opt):
+        lib, h = L.lib(), self.ctx.h
+        st = self.__dict__.setdefault("_opt_state", {})
+        L.check(lib.vbnn_sgd_step(h, _p(self.bias), _p(self.gradBias), self.bias.numel(),
+                                  float(opt["state"]["learningRate"])))                               # :125-128
+        self.compute_prior()                                                                           # :130
+        mleg, mlcg = self.compute_mugrads(opt)                                                         # :131
+        vleg, vlcg = self.compute_vargrads(opt)                                                        # :133
+        ratios = []
+        for key, x, g1, g2, cfg in (("mean", self.means, mleg, mlcg, opt["meanState"]),
+                                    ("var", self.lvars, vleg, vlcg, opt["varState"])):
+            s = st.setdefault(key, {"t": 0})
+            if "m" not in s:
+                s["m"], s["v"] = torch.zeros_like(x), torch.zeros_like(x)
+                s["norms"] = torch.zeros(2, dtype=torch.float64, device=self.device)
+            s["t"] += 1
+            L.check(lib.vbnn_adam_step(h, _p(x), _p(g1), _p(g2), _p(s["m"]), _p(s["v"]), x.numel(),
+                                       float(cfg["learningRate"]), float(cfg.get("beta1", 0.9)),
+                                       float(cfg.get("beta2", 0.999)), float(cfg.get("epsilon", 1e-8)),
+                                       float(cfg.get("lambda", 1.0)), s["t"], _p(s["norms"])))         # :135-143
+            n = s["norms"].tolist()
+            ratios.append(n[0] / n[1] if n[1] > 0 else float("inf"))
+        return tuple(ratios)
