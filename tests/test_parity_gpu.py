@@ -428,6 +428,51 @@ def test_layer_bf16_against_rounded_operands(nnmod, oracle, gemm_kernel, N, I, O
     assert np.abs(host(m.gradSum) - want_gs).max() <= 1e-3 * np.abs(want_gs).max()
 
 
+# ------------------------------------------------------------------------------------------- MC loop / test path
+@pytest.mark.parametrize("mode", ["lrt", "wn"])
+def test_engine_test_path_matches_oracle(oracle, nnmod, mode):
+    """mlp:test (mlp.lua:86-107): quicktest = clamp_to_map + one pass; otherwise the mean over testSamples draws."""
+    N, I0 = 37, 70
+    x = oracle.fill_normal(N, I0, SEED, 4, 0, 0)
+    t = (np.arange(N) * 7 % 10).astype(np.int32)
+    for quick in (True, False):
+        opt, eng, onet = _engine_pair(oracle, mode, "f32", [50, 34], I0, True, S=1)
+        opt["quicktest"] = quick
+        opt["testSamples"] = 3
+        err, acc = eng.test(dev(x), dev(t))
+        if quick:
+            for om in onet.vb:
+                om.clamp_to_map()
+            werr, wacc = onet.run(x, t)
+        else:
+            werr = wacc = 0.0
+            for _ in range(3):
+                onet.sample()
+                e, a = onet.run(x, t)
+                werr += e / 3; wacc += a / 3
+        assert abs(err - werr) <= 3e-5 * abs(werr) + 1e-6, (quick, err, werr)
+        assert abs(acc - wacc) <= 100.0 * 1.01 / N
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_engine_is_bitwise_reproducible_and_handles_tiny_batches(oracle, nnmod, dtype):
+    """No float atomics feed a gradient: two engines with the same seed produce bit-identical gradient arenas.
+    Batches of 1 and 5 rows (below every tile and vector width) run and, in fp32, match the oracle."""
+    for N in (1, 5, 37):
+        arenas = []
+        for rep in range(2):
+            opt, eng, onet = _engine_pair(oracle, "lrt", dtype, [50, 34], 70, True, S=2)
+            loss, werr = _run_pair(opt, eng, onet, oracle, N, 70)
+            arenas.append(host(eng.grads).copy())
+            if dtype == "f32":
+                assert abs(loss - werr) <= 3e-5 * abs(werr) + 1e-6, (N, loss, werr)
+                mle, mlc = onet.vb[0].compute_mugrads(opt)
+                want = mle + mlc
+                np.testing.assert_allclose(host(eng.vb[0].gradWeight), want, rtol=0, atol=3e-5 * np.abs(want).max() + 1e-10)
+        assert np.array_equal(arenas[0].view(np.uint32), arenas[1].view(np.uint32)), f"N={N}: gradients differ between runs"
+        assert np.isfinite(arenas[0]).all()
+
+
 # ------------------------------------------------------------------------------------------- update (SURVEY 8f next #1)
 OPT_STATES = dict(state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
 

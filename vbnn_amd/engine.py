@@ -93,6 +93,7 @@ class FusedMLP:
         self._corr = torch.zeros(1, dtype=torch.int32, device=dev)
         self._lc = torch.zeros(1, dtype=torch.float64, device=dev)
         self.draw = 0
+        self._map = False
         self._first = True
         self._N = None
         self._works = []
@@ -150,9 +151,44 @@ class FusedMLP:
         L.check(lib.vbnn_pack(self.ctx.h, self.code, L.PACK_COPY, _p(self.weight3), None, self.sizes[-1],
                               self.n_classes, self.sizes[-1], self.w3_s.ptr, self.w3_s.ld, self.w3T_s.ptr, self.w3T_s.ld))
 
+    def _lrt(self):
+        return self.mode == "lrt" and not self._map
+
+    # ---- VBLinear:clamp_to_map on every VB layer (mlp.lua:88-91): the forward uses the means as weights.
+    def clamp_to_map(self):
+        self._map = True
+        if self.mode == "wn":                 # the weight shadows currently hold a sampled draw: repack the means
+            lib = L.lib()
+            for v in self.vb:
+                L.check(lib.vbnn_pack(self.ctx.h, self.code, L.PACK_COPY, _p(v.means), None, v.I, v.O, v.I,
+                                      v.mu_s.ptr, v.mu_s.ld, v.muT_s.ptr if v.muT_s else None,
+                                      v.muT_s.ld if v.muT_s else 0))
+
+    # ---- mlp:test (mlp.lua:86-107): `quicktest` = one MAP pass, otherwise the average over testSamples draws.
+    # The reference's `run` also back-propagates at test time and throws the gradients away; here the test pass
+    # is forward + criterion only. Returns (mean error, accuracy in percent) of THIS rank's rows.
+    def test(self, inputs, targets):
+        N = inputs.shape[0]
+        self.prepare()
+        draws = 1 if self.opt.get("quicktest") else int(self.opt["testSamples"])
+        err = acc = 0.0
+        for _ in range(draws):
+            L.check(L.lib().vbnn_buf_zero(self.ctx.h, _p(self._acc), 16))
+            L.check(L.lib().vbnn_buf_zero(self.ctx.h, _p(self._corr), 4))
+            if self.opt.get("quicktest"):
+                self.clamp_to_map()
+            else:
+                self.sample()
+            self.run(inputs, targets, backward=False)
+            loss, correct = self.loss_and_accuracy()
+            err += loss * self.world            # the criterion divides by the global batch; this is the local mean
+            acc += 100.0 * correct / N
+        return err / draws, acc / draws
+
     # ---- mlp.lua:69-74
     def sample(self):
         self.draw += 1
+        self._map = False
         if self.mode == "wn":
             lib = L.lib()
             for v in self.vb:
@@ -165,7 +201,7 @@ class FusedMLP:
     # ---- final Linear + criterion through the generic GEMM kernels (class counts above 16)
     def _generic_head(self, N, targets, inv_n, accumulate):
         lib, ctx, code = L.lib(), self.ctx.h, self.code
-        lrt = self.mode == "lrt"
+        lrt = self._lrt()
         H, Cn = self.sizes[-1], self.n_classes
         a = L.FwdArgs(w=self.w3_s.ptr, w2=None, x=self.h_s.ptr, x2=None, ld_w=self.w3_s.ld, ld_x=self.h_s.ld,
                       N=N, I=H, O=Cn, bias=_p(self.bias3), y=_p(self.logits), ld_y=Cn)
@@ -190,7 +226,7 @@ class FusedMLP:
     # ---- argument blocks of the three GEMM families for VB layer `li` (also used by bench.py to time
     # exactly the launches of the step in isolation)
     def _fwd_args(self, li, N, row0):
-        v, lrt = self.vb[li], self.mode == "lrt"
+        v, lrt = self.vb[li], self._lrt()
         last = li == len(self.vb) - 1
         nxt = None if last else self.vb[li + 1]
         return L.FwdArgs(w=v.mu_s.ptr, w2=v.var_s.ptr if lrt else None, x=v.x_s.ptr, x2=v.x2_s.ptr if lrt else None,
@@ -205,7 +241,7 @@ class FusedMLP:
                          ld_hT=self.hT_s.ld if last else nxt.xT_s.ld)
 
     def _dw_args(self, li, N, accumulate):
-        v, lrt = self.vb[li], self.mode == "lrt"
+        v, lrt = self.vb[li], self._lrt()
         d = L.DwArgs(xT=v.xT_s.ptr, x2T=v.x2T_s.ptr if lrt else None, gT=v.gT_s.ptr,
                      gvT=v.gvT_s.ptr if lrt else None, ld_n=v.xT_s.ld, N=N, I=v.I, O=v.O, scale=1.0,
                      accumulate=accumulate, seed=self.seed, layer=v.layer_id, draw=self.draw, lvars=_p(v.lvars))
@@ -219,7 +255,7 @@ class FusedMLP:
         return d
 
     def _dx_args(self, li, N):
-        v, p, lrt = self.vb[li], self.vb[li - 1], self.mode == "lrt"
+        v, p, lrt = self.vb[li], self.vb[li - 1], self._lrt()
         return L.DxArgs(wT=v.muT_s.ptr, w2T=v.varT_s.ptr if lrt else None, g=v.g_s.ptr,
                         gv=v.gv_s.ptr if lrt else None, ld_wT=v.muT_s.ld, ld_g=v.g_s.ld, N=N, I=v.I, O=v.O,
                         x=v.x_s.ptr, ld_x=v.x_s.ld, gx=None, ld_gx=0, relu_mask=1,
@@ -228,7 +264,7 @@ class FusedMLP:
                         gvT_prev=p.gvT_s.ptr if lrt else None, ld_gpT=p.gT_s.ld)
 
     # ---- mlp.lua:76-84, fused
-    def run(self, inputs, targets, row0=None):
+    def run(self, inputs, targets, row0=None, backward=True):
         lib, ctx, code = L.lib(), self.ctx.h, self.code
         x = inputs.reshape(inputs.shape[0], -1)                         # nn.Reshape (mlp.lua:12)
         N = x.shape[0]
@@ -236,7 +272,7 @@ class FusedMLP:
         self._alloc_batch(N)
         if row0 is None:
             row0 = self.rank * N
-        lrt = self.mode == "lrt"
+        lrt = self._lrt()
         accumulate = 0 if self._first else 1
         inv_n = 1.0 / (N * self.world)
         v0 = self.vb[0]
@@ -257,6 +293,8 @@ class FusedMLP:
             L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
                                           _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
                                           _p(self.g_logits), _p(self._acc), _p(self._corr)))
+            if not backward:
+                return
             L.check(lib.vbnn_head_backward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
                                            _p(self.g_logits), N, H, Cn, accumulate, _p(self.gradWeight3),
                                            _p(self.gradBias3), 1, _p(vl.r) if lrt else None, vl.O, vl.g_s.ptr,
