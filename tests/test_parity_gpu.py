@@ -428,6 +428,54 @@ def test_layer_bf16_against_rounded_operands(nnmod, oracle, gemm_kernel, N, I, O
     assert np.abs(host(m.gradSum) - want_gs).max() <= 1e-3 * np.abs(want_gs).max()
 
 
+# ------------------------------------------------------------------------------------------- BASELINE.json's full sizes
+def test_full_size_bf16_layer_exact_on_integers(nnmod):
+    """The 4096 x 4096 layer at batch 4096 (BASELINE configs[2]) on integer operands: forward, gradInput and
+    gradWeight of the pipelined kernel must equal the integer results exactly (fp32 sgemm on the host is exact
+    here too: every partial sum stays below 2^24)."""
+    N = I = O = 4096
+    rng = np.random.default_rng(4096)
+    W = rng.integers(-3, 4, (O, I)).astype(np.float32)
+    b = rng.integers(-5, 6, O).astype(np.float32)
+    x = rng.integers(-3, 4, (N, I)).astype(np.float32)
+    g = rng.integers(-2, 3, (N, O)).astype(np.float32)
+    m = nnmod.Linear(I, O, dict(dtype="bf16"))
+    m.weight.copy_(dev(W)); m.bias.copy_(dev(b))
+    y = host(m.updateOutput(dev(x)))
+    assert np.array_equal(y, x @ W.T + b)
+    m.gradWeight.zero_(); m.gradBias.zero_()
+    gx = host(m.backward(dev(x), dev(g), 1.0))
+    assert np.array_equal(gx, g @ W)
+    assert np.array_equal(host(m.gradWeight), g.T @ x)
+    assert np.array_equal(host(m.gradBias), g.sum(axis=0))
+
+
+def test_full_size_lrt_forward_against_rounded_operands(nnmod, oracle):
+    """The wide configuration's second VB layer (4096 -> 4096, batch 4096, bf16, LRT): y against float64 BLAS on
+    identically rounded operands (oracle/ref_numpy.lrt_forward), 1e-3 of max|y|; the noise is the oracle's Philox
+    stream for global rows, and an all-zero input row must come out finite with r = 0."""
+    from oracle.ref_numpy import bf16_round, lrt_forward
+    N = I = O = 4096
+    opt, m, om = _layer_pair(nnmod, oracle, "lrt", I, O, dtype="bf16")
+    x = oracle.fill_normal(N, I, SEED, 4, 9, 0)
+    x[17, :] = 0.0
+    m.sample(); m.row0 = 8192
+    y = host(m.updateOutput(dev(x))).astype(np.float64)
+    zeta = oracle.fill_normal(N, O, SEED, 2, 0, m.draw, 8192).astype(np.float64)
+    want, v = lrt_forward(x, om.means, om.lvars, om.bias.astype(np.float64), zeta, bf16_round)
+    assert np.abs(y - want).max() <= 1e-3 * np.abs(want).max()
+    r = host(m.r)
+    assert np.isfinite(r).all() and np.all(r[17] == 0.0)
+    m.row0 = 0
+
+
+def test_empty_batch_is_an_error_not_a_crash(nnmod):
+    from vbnn_amd import _lib as L
+    m = nnmod.Linear(8, 4)
+    with pytest.raises(L.VbnnError):
+        m.updateOutput(torch.zeros(0, 8, device="cuda"))
+
+
 # ------------------------------------------------------------------------------------------- MC loop / test path (SURVEY 8f next #2)
 @pytest.mark.parametrize("mode", ["lrt", "wn"])
 def test_engine_test_path_matches_oracle(oracle, nnmod, mode):

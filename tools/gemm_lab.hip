@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
             std::sort(ts.begin(), ts.end());
             const double fl = 2.0 * M * N * K * (dual ? 2 : 1);
             printf("M=%d N=%d K=%d %s sched%d: median %.1f us  %.0f TF", M, N, K, dual ? "dual  " : "single", sched, ts[2], fl / ts[2] / 1e6);
-            if (sched == 0) {
+            if (true) {
                 std::vector<unsigned long long> hd((size_t)tiles * 8 * 4);
                 CK(hipMemcpy(hd.data(), diag, hd.size() * 8, hipMemcpyDeviceToHost));
                 double s[4] = {0, 0, 0, 0};
