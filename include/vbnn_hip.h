@@ -114,7 +114,8 @@ typedef struct vbnn_fwd_args {
     uint64_t seed; uint32_t layer; uint32_t draw; int64_t row0;
     /* outputs, each optional */
     float* y;  int64_t ld_y;        /* pre-activation output (the module's `output`), N x O     */
-    float* r;  int64_t ld_r;        /* z / (2 sqrt(v)), saved for backward (LRT), N x O f32      */
+    void* r;  int64_t ld_r;         /* z / (2 sqrt(v)), saved for backward (LRT), N x ld_r:      */
+    int r_packed;                   /* 0: float (the module path); 1: element type = dtype       */
     int relu;                       /* apply ReLU before writing the packed outputs below        */
     void* h;  void* h2;  int64_t ld_h;     /* next layer's packed input and its square, N x ld_h  */
     void* hT; void* h2T; int64_t ld_hT;    /* their transposes, O x ld_hT                         */
@@ -137,7 +138,7 @@ typedef struct vbnn_dx_args {
     float* gx; int64_t ld_gx;       /* gradInput N x I f32, optional                            */
     /* optional fused hand-off to the previous VB layer: g_prev = gx . [x > 0], gv_prev = g_prev . r_prev */
     int relu_mask;
-    const float* r_prev; int64_t ld_r_prev;
+    const void* r_prev; int64_t ld_r_prev; int r_prev_packed;   /* the previous layer's `r`, same typing rule */
     void* g_prev; void* gv_prev; int64_t ld_gp;      /* N x ld_gp   */
     void* gT_prev; void* gvT_prev; int64_t ld_gpT;   /* I x ld_gpT  */
 } vbnn_dx_args;
@@ -202,6 +203,12 @@ int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, 
 int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const float* vars, const float* mu_sqe,
                  const double* stats, float B, float* lc_elem, double* lc_sum_dev, int64_t W);
 
+/* The minibatch (N x I f32, row pitch ld_src) as GEMM operands in one pass: x_s, x2_s = (rounded x)^2 (N x ld_x)
+ * and their transposes (I x ld_xT); x2_s / xT_s / x2T_s optional. Replaces the host->device copies of
+ * main.lua:22-25 plus two vbnn_pack calls. */
+int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64_t ld_src, int64_t N, int64_t I, void* x_s,
+                    void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT);
+
 /* ---- the update that follows the hot path -------------------------------- */
 
 /* optim.adam as VBLinear:update calls it on means / lvars (VBLinear.lua:135-143), one streaming pass:
@@ -241,8 +248,8 @@ int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, con
  * VB layer's packed gradient operands (same meaning as the hand-off fields of vbnn_dx_args). */
 int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                        const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
-                       float* gradBias, int relu_mask, const float* r_prev, int64_t ld_r_prev, void* g_prev,
-                       void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT);
+                       float* gradBias, int relu_mask, const void* r_prev, int64_t ld_r_prev, int r_prev_packed,
+                       void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT);
 
 /* The same criterion as separate modules, for the module-level call order of mlp.lua:77-80:
  * nn.LogSoftMax:updateOutput is vbnn_logsoftmax_nll with g_logits = loss = correct = NULL. */

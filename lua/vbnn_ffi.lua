@@ -44,7 +44,8 @@ typedef struct vbnn_fwd_args {
     const float* bias;
     uint64_t seed; uint32_t layer; uint32_t draw; int64_t row0;
     float* y;  int64_t ld_y;
-    float* r;  int64_t ld_r;
+    void* r;  int64_t ld_r;
+    int r_packed;
     int relu;
     void* h;  void* h2;  int64_t ld_h;
     void* hT; void* h2T; int64_t ld_hT;
@@ -60,7 +61,7 @@ typedef struct vbnn_dx_args {
     const void* x; int64_t ld_x;
     float* gx; int64_t ld_gx;
     int relu_mask;
-    const float* r_prev; int64_t ld_r_prev;
+    const void* r_prev; int64_t ld_r_prev; int r_prev_packed;
     void* g_prev; void* gv_prev; int64_t ld_gp;
     void* gT_prev; void* gvT_prev; int64_t ld_gpT;
 } vbnn_dx_args;
@@ -93,6 +94,8 @@ int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, 
                           const double* stats, float B, float S, float* gradSum, float* lcg, int64_t W);
 int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const float* vars, const float* mu_sqe,
                  const double* stats, float B, float* lc_elem, double* lc_sum_dev, int64_t W);
+int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64_t ld_src, int64_t N, int64_t I, void* x_s,
+                    void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT);
 int vbnn_adam_step(vbnn_ctx* ctx, float* x, const float* grad, const float* grad2, float* m, float* v, int64_t n,
                    float lr, float beta1, float beta2, float eps, float lambda, int64_t t, double* norms_dev);
 int vbnn_sgd_step(vbnn_ctx* ctx, float* x, const float* grad, int64_t n, float lr);
@@ -106,8 +109,8 @@ int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, con
                       float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev);
 int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                        const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
-                       float* gradBias, int relu_mask, const float* r_prev, int64_t ld_r_prev, void* g_prev,
-                       void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT);
+                       float* gradBias, int relu_mask, const void* r_prev, int64_t ld_r_prev, int r_prev_packed,
+                       void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT);
 int vbnn_nll_forward(vbnn_ctx* ctx, const float* out, int64_t ld, const int32_t* target, int64_t N, int64_t C,
                      float inv_n, double* loss_sum_dev, int32_t* correct_dev);
 int vbnn_nll_backward(vbnn_ctx* ctx, const int32_t* target, int64_t N, int64_t C, float inv_n, float* g);

@@ -142,7 +142,7 @@ def emulate_lrt_step(layers, w3, b3, x, t, zetas, rnd=lambda a: a, S=1.0, B=1e6,
         with np.errstate(divide="ignore", invalid="ignore"):
             r = np.where(v > 0, z / (2 * np.sqrt(v)), 0.0).astype(np.float32)
         h = rnd(np.maximum(y, 0))
-        rs.append(r)
+        rs.append(rnd(r))                                           # the engine stores r in the operand type
         xs.append(h.astype(f8))
         x2s.append(rnd(h * h).astype(f8))
     logits = (xs[-1] @ rnd(w3).astype(f8).T + b3).astype(np.float32)

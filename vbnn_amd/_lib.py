@@ -28,14 +28,14 @@ class FwdArgs(C.Structure):
     _fields_ = [("w", _vp), ("w2", _vp), ("x", _vp), ("x2", _vp), ("ld_w", _i64), ("ld_x", _i64),
                 ("N", _i64), ("I", _i64), ("O", _i64), ("bias", _vp),
                 ("seed", _u64), ("layer", _u32), ("draw", _u32), ("row0", _i64),
-                ("y", _vp), ("ld_y", _i64), ("r", _vp), ("ld_r", _i64), ("relu", _i),
+                ("y", _vp), ("ld_y", _i64), ("r", _vp), ("ld_r", _i64), ("r_packed", _i), ("relu", _i),
                 ("h", _vp), ("h2", _vp), ("ld_h", _i64), ("hT", _vp), ("h2T", _vp), ("ld_hT", _i64)]
 
 
 class DxArgs(C.Structure):
     _fields_ = [("wT", _vp), ("w2T", _vp), ("g", _vp), ("gv", _vp), ("ld_wT", _i64), ("ld_g", _i64),
                 ("N", _i64), ("I", _i64), ("O", _i64), ("x", _vp), ("ld_x", _i64),
-                ("gx", _vp), ("ld_gx", _i64), ("relu_mask", _i), ("r_prev", _vp), ("ld_r_prev", _i64),
+                ("gx", _vp), ("ld_gx", _i64), ("relu_mask", _i), ("r_prev", _vp), ("ld_r_prev", _i64), ("r_prev_packed", _i),
                 ("g_prev", _vp), ("gv_prev", _vp), ("ld_gp", _i64),
                 ("gT_prev", _vp), ("gvT_prev", _vp), ("ld_gpT", _i64)]
 
@@ -73,14 +73,15 @@ _SIGS = {
     "vbnn_compute_mugrads": ([_vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),
     "vbnn_compute_vargrads": ([_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),
     "vbnn_calc_lc": ([_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64], _i),
+    "vbnn_pack_input": ([_vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64], _i),
     "vbnn_adam_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _vp], _i),
     "vbnn_sgd_step": ([_vp, _vp, _vp, _i64, _f], _i),
     "vbnn_relu_forward": ([_vp, _vp, _vp, _i64], _i),
     "vbnn_relu_backward": ([_vp, _vp, _vp, _vp, _i64], _i),
     "vbnn_logsoftmax_nll": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp], _i),
     "vbnn_head_forward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _f, _vp, _vp, _vp, _vp, _vp], _i),
-    "vbnn_head_backward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _i64,
-                           _vp, _vp, _i64], _i),
+    "vbnn_head_backward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _vp, _i, _vp, _i64, _i, _vp, _vp,
+                           _i64, _vp, _vp, _i64], _i),
     "vbnn_nll_forward": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp], _i),
     "vbnn_nll_backward": ([_vp, _vp, _i64, _i64, _f, _vp], _i),
     "vbnn_logsoftmax_backward": ([_vp, _vp, _vp, _vp, _i64, _i64], _i),

@@ -540,30 +540,43 @@ __global__ __launch_bounds__(256) void k_prep_layer(const float* __restrict__ me
     const int64_t ntiles = tiles_c * tiles_r;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     double s1 = 0.0, s2 = 0.0;
+    (void)tx; (void)ty;
+    // every thread moves 4 consecutive elements at a time: 16-byte loads of means / lvars, 8-byte (bf16) stores of
+    // the shadows, and -- after the LDS transpose -- 4 consecutive rows of one column for the transposed shadows
+    const bool vec_in = ((I & 3) == 0) && ((((uintptr_t)means | (uintptr_t)lvars) & 15u) == 0);
+    const bool vec_t = muT_s && ((ld_wT & 3) == 0);
     for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
         const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
-#pragma unroll 4
-        for (int rr = ty; rr < 64; rr += 4) {
-            const int64_t r = r0 + rr, c = c0 + tx;
-            float m = 0.f, v = 0.f;
-            if (r < O && c < I) {
-                m = means[r * I + c];
-                const float l = lvars[r * I + c];
-                v = expf(l);
-                s1 += (double)(v + m * m); s2 += (double)l;
-                mu_s[r * ld_w + c] = Elt<T>::to(m);
-                var_s[r * ld_w + c] = Elt<T>::to(v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            const int rr = idx >> 4, c4 = (idx & 15) * 4;
+            const int64_t r = r0 + rr, c = c0 + c4;
+            float m[4] = {0.f, 0.f, 0.f, 0.f}, l[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
+            const int valid = (r < O) ? (int)min((int64_t)4, I - c) : 0;
+            if (valid > 0) {
+                load4<float>(means + r * I + c, m, valid, vec_in);
+                load4<float>(lvars + r * I + c, l, valid, vec_in);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < valid) { v[e] = expf(l[e]); s1 += (double)(v[e] + m[e] * m[e]); s2 += (double)l[e]; }
+                store4<T>(mu_s + r * ld_w + c, m[0], m[1], m[2], m[3], valid, true);
+                store4<T>(var_s + r * ld_w + c, v[0], v[1], v[2], v[3], valid, true);
             }
-            tm[rr][tx] = m; tv[rr][tx] = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tm[rr][c4 + e] = m[e]; tv[rr][c4 + e] = v[e]; }
         }
         if (muT_s) {
             __syncthreads();
-#pragma unroll 4
-            for (int cc = ty; cc < 64; cc += 4) {
-                const int64_t c = c0 + cc, r = r0 + tx;
-                if (c < I && r < O) {
-                    muT_s[c * ld_wT + r] = Elt<T>::to(tm[tx][cc]);
-                    varT_s[c * ld_wT + r] = Elt<T>::to(tv[tx][cc]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = threadIdx.x + 256 * k;
+                const int cc = idx >> 4, r4 = (idx & 15) * 4;
+                const int64_t c = c0 + cc, r = r0 + r4;
+                const int valid = (c < I) ? (int)min((int64_t)4, O - r) : 0;
+                if (valid > 0) {
+                    store4<T>(muT_s + c * ld_wT + r, tm[r4][cc], tm[r4 + 1][cc], tm[r4 + 2][cc], tm[r4 + 3][cc], valid, vec_t);
+                    store4<T>(varT_s + c * ld_wT + r, tv[r4][cc], tv[r4 + 1][cc], tv[r4 + 2][cc], tv[r4 + 3][cc], valid, vec_t);
                 }
             }
             __syncthreads();
@@ -593,6 +606,76 @@ extern "C" int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, con
     else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_prior_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->scratch, nb, O * I, stats);
     return vbnn_check_launch("k_prep_layer");
+    VBNN_API_END
+}
+
+// ---------------------------------------------------------------------------------- pack_input
+// The minibatch as GEMM operands in one pass: x, x.x (of the ROUNDED x, as every epilogue produces it) and both
+// transposes. Same tiling as k_prep_layer: 4 elements per thread, LDS transpose.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ src, int64_t ld_src, int64_t N, int64_t I, T* x_s,
+                                                    T* x2_s, int64_t ld_x, T* xT_s, T* x2T_s, int64_t ld_xT) {
+    __shared__ float ta[64][65];
+    __shared__ float tb[64][65];
+    const int64_t tiles_c = (I + 63) / 64, tiles_r = (N + 63) / 64;
+    const int64_t ntiles = tiles_c * tiles_r;
+    const bool vec_in = ((ld_src & 3) == 0) && (((uintptr_t)src & 15u) == 0);
+    const bool vec_t = (ld_xT & 3) == 0;
+    for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
+        const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            const int rr = idx >> 4, c4 = (idx & 15) * 4;
+            const int64_t r = r0 + rr, c = c0 + c4;
+            float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+            const int valid = (r < N) ? (int)min((int64_t)4, I - c) : 0;
+            if (valid > 0) {
+                load4<float>(src + r * ld_src + c, a, valid, vec_in);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float ar = Elt<T>::from(Elt<T>::to(a[e])); b[e] = ar * ar; }
+                store4<T>(x_s + r * ld_x + c, a[0], a[1], a[2], a[3], valid, true);
+                if (x2_s) store4<T>(x2_s + r * ld_x + c, b[0], b[1], b[2], b[3], valid, true);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ta[rr][c4 + e] = a[e]; tb[rr][c4 + e] = b[e]; }
+        }
+        if (xT_s) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = threadIdx.x + 256 * k;
+                const int cc = idx >> 4, r4 = (idx & 15) * 4;
+                const int64_t c = c0 + cc, r = r0 + r4;
+                const int valid = (c < I) ? (int)min((int64_t)4, N - r) : 0;
+                if (valid > 0) {
+                    store4<T>(xT_s + c * ld_xT + r, ta[r4][cc], ta[r4 + 1][cc], ta[r4 + 2][cc], ta[r4 + 3][cc], valid, vec_t);
+                    if (x2T_s)
+                        store4<T>(x2T_s + c * ld_xT + r, tb[r4][cc], tb[r4 + 1][cc], tb[r4 + 2][cc], tb[r4 + 3][cc], valid, vec_t);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64_t ld_src, int64_t N, int64_t I, void* x_s,
+                               void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && src && x_s, "null argument");
+    VBNN_REQUIRE(N > 0 && I > 0 && ld_src >= I && ld_x >= I && ld_x % 4 == 0, "shape");
+    VBNN_REQUIRE(!x2T_s || xT_s, "x2T_s needs xT_s");
+    VBNN_REQUIRE(!xT_s || ld_xT >= N, "ld_xT");
+    const int64_t ntiles = ((N + 63) / 64) * ((I + 63) / 64);
+    const int nb = (int)(ntiles < 4096 ? ntiles : 4096);
+    if (dtype == VBNN_F32)
+        hipLaunchKernelGGL(k_pack_input<float>, dim3(nb), dim3(256), 0, ctx->stream, src, ld_src, N, I, (float*)x_s, (float*)x2_s,
+                           ld_x, (float*)xT_s, (float*)x2T_s, ld_xT);
+    else if (dtype == VBNN_BF16)
+        hipLaunchKernelGGL(k_pack_input<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, src, ld_src, N, I, (bf16_t*)x_s,
+                           (bf16_t*)x2_s, ld_x, (bf16_t*)xT_s, (bf16_t*)x2T_s, ld_xT);
+    else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
+    return vbnn_check_launch("k_pack_input");
     VBNN_API_END
 }
 

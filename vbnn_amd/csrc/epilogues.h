@@ -26,7 +26,7 @@ struct EpiFwd {
     int noise;
     uint64_t seed; uint32_t layer, draw; int64_t row0;
     float* y; int64_t ld_y; int y_vec;
-    float* r; int64_t ld_r; int r_vec;
+    float* r; T* r_t; int64_t ld_r; int r_vec;       // r as f32 (module path) or as T (fused path), never both
     int relu;
     T* h; T* h2; int64_t ld_h;
     T* hT; T* h2T; int64_t ld_hT;
@@ -67,6 +67,7 @@ struct EpiFwd {
         }
         if (y) store4<float>(y + (int64_t)n * ld_y + m, yv[0], yv[1], yv[2], yv[3], valid, y_vec);
         if (r) store4<float>(r + (int64_t)n * ld_r + m, rv[0], rv[1], rv[2], rv[3], valid, r_vec);
+        if (r_t) store4<T>(r_t + (int64_t)n * ld_r + m, rv[0], rv[1], rv[2], rv[3], valid, r_vec);
         if (h || hT) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -106,7 +107,7 @@ struct EpiDx {
     const T* x; int64_t ld_x;
     float* gx; int64_t ld_gx; int gx_vec;
     int relu_mask;
-    const float* r_prev; int64_t ld_r_prev; int r_vec;
+    const float* r_prev; const T* r_prev_t; int64_t ld_r_prev; int r_vec;
     T* g_prev; T* gv_prev; int64_t ld_gp;
     T* gT_prev; T* gvT_prev; int64_t ld_gpT;
     int I, N;
@@ -132,6 +133,7 @@ struct EpiDx {
         if (g_prev || gT_prev) {
             float rp[4] = {0.f, 0.f, 0.f, 0.f};
             if (r_prev) load4<float>(r_prev + (int64_t)n * ld_r_prev + m, rp, valid, r_vec);
+            if (r_prev_t) load4<T>(r_prev_t + (int64_t)n * ld_r_prev + m, rp, valid, r_vec);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 t1[j] = (relu_mask && !(xv[j] > 0.f)) ? 0.f : gv4[j];

@@ -36,7 +36,9 @@ static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
     e.noise = a->w2 != nullptr;
     e.seed = a->seed; e.layer = a->layer; e.draw = a->draw; e.row0 = a->row0;
     e.y = a->y; e.ld_y = a->ld_y; e.y_vec = a->y && aligned16(a->y) && (a->ld_y % 4 == 0);
-    e.r = a->r; e.ld_r = a->ld_r; e.r_vec = a->r && aligned16(a->r) && (a->ld_r % 4 == 0);
+    e.r = a->r_packed ? nullptr : (float*)a->r;
+    e.r_t = a->r_packed ? (T*)a->r : nullptr;
+    e.ld_r = a->ld_r; e.r_vec = a->r && aligned16(a->r) && (a->ld_r % 4 == 0);
     e.relu = a->relu;
     e.h = (T*)a->h; e.h2 = (T*)a->h2; e.ld_h = a->ld_h;
     e.hT = (T*)a->hT; e.h2T = (T*)a->h2T; e.ld_hT = a->ld_hT;
@@ -52,7 +54,9 @@ static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
     e.x = (const T*)a->x; e.ld_x = a->ld_x;
     e.gx = a->gx; e.ld_gx = a->ld_gx; e.gx_vec = a->gx && aligned16(a->gx) && (a->ld_gx % 4 == 0);
     e.relu_mask = a->relu_mask;
-    e.r_prev = a->r_prev; e.ld_r_prev = a->ld_r_prev; e.r_vec = a->r_prev && aligned16(a->r_prev) && (a->ld_r_prev % 4 == 0);
+    e.r_prev = a->r_prev_packed ? nullptr : (const float*)a->r_prev;
+    e.r_prev_t = a->r_prev_packed ? (const T*)a->r_prev : nullptr;
+    e.ld_r_prev = a->ld_r_prev; e.r_vec = a->r_prev && aligned16(a->r_prev) && (a->ld_r_prev % 4 == 0);
     e.g_prev = (T*)a->g_prev; e.gv_prev = (T*)a->gv_prev; e.ld_gp = a->ld_gp;
     e.gT_prev = (T*)a->gT_prev; e.gvT_prev = (T*)a->gvT_prev; e.ld_gpT = a->ld_gpT;
     e.I = (int)a->I; e.N = (int)a->N;

@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void k_head_dw_finish(const float* __restrict_
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void k_head_dx(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
                                                  const float* __restrict__ g, int64_t N, int64_t H, int C, int relu_mask,
-                                                 const float* __restrict__ r_prev, int64_t ld_r, T* g_prev, T* gv_prev, int64_t ld_gp,
-                                                 T* gT_prev, T* gvT_prev, int64_t ld_gpT) {
+                                                 const float* __restrict__ r_prev, const T* __restrict__ r_prev_t, int64_t ld_r,
+                                                 T* g_prev, T* gv_prev, int64_t ld_gp, T* gT_prev, T* gvT_prev, int64_t ld_gpT) {
     __shared__ float tg[64][65];
     __shared__ float tv[64][65];
     __shared__ float gs[64][HEAD_CMAX];
@@ -236,20 +236,24 @@ __global__ __launch_bounds__(256) void k_head_dx(const T* __restrict__ h, int64_
                 }
             float hv[8], rv[8];
             const bool full = VEC && (i + 8 <= H);
+            const bool has_r = r_prev || r_prev_t;
             if (full) {
                 Vec8<T>::load(h + n * ld_h + i, hv);
                 if (r_prev) Vec8<float>::load(r_prev + n * ld_r + i, rv);
+                if (r_prev_t) Vec8<T>::load(r_prev_t + n * ld_r + i, rv);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     hv[e] = (i + e < H) ? Elt<T>::from(h[n * ld_h + i + e]) : 0.f;
-                    rv[e] = (r_prev && i + e < H) ? r_prev[n * ld_r + i + e] : 0.f;
+                    rv[e] = 0.f;
+                    if (r_prev && i + e < H) rv[e] = r_prev[n * ld_r + i + e];
+                    if (r_prev_t && i + e < H) rv[e] = Elt<T>::from(r_prev_t[n * ld_r + i + e]);
                 }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 gp[e] = (relu_mask && !(hv[e] > 0.f)) ? 0.f : gx[e];
-                gvp[e] = r_prev ? gp[e] * rv[e] : 0.f;
+                gvp[e] = has_r ? gp[e] * rv[e] : 0.f;
             }
             if (full) {
                 if (g_prev) Vec8<T>::store(g_prev + n * ld_gp + i, gp);
@@ -317,8 +321,10 @@ extern "C" int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_
 template <typename T>
 static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3, int64_t ld_w, const float* g_logits, int64_t N,
                            int64_t H, int64_t C, int accumulate, float* gradWeight, float* gradBias, int relu_mask,
-                           const float* r_prev, int64_t ld_r_prev, T* g_prev, T* gv_prev, int64_t ld_gp, T* gT_prev, T* gvT_prev,
-                           int64_t ld_gpT) {
+                           const void* r_prev_any, int64_t ld_r_prev, int r_prev_packed, T* g_prev, T* gv_prev, int64_t ld_gp,
+                           T* gT_prev, T* gvT_prev, int64_t ld_gpT) {
+    const float* r_prev = r_prev_packed ? nullptr : (const float*)r_prev_any;
+    const T* r_prev_t = r_prev_packed ? (const T*)r_prev_any : nullptr;
     if (gradWeight) {
         const int64_t cap = (int64_t)(ctx->scratch_doubles * 2) / (C * H + C);
         VBNN_REQUIRE(cap >= 1, "hidden size too large for the reduction scratch");
@@ -344,24 +350,24 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
     }
     if (g_prev || gT_prev) {
         const unsigned nb = (unsigned)(((N + 63) / 64) * ((H + 63) / 64));
-        const bool vec = (ld_h % 8 == 0) && (!r_prev || ld_r_prev % 4 == 0) && (!g_prev || ld_gp % 8 == 0) &&
+        const bool vec = (ld_h % 8 == 0) && (!r_prev_any || ld_r_prev % 8 == 0) && (!g_prev || ld_gp % 8 == 0) &&
                          (!(gT_prev || gvT_prev) || ld_gpT % 8 == 0) &&
-                         ((((uintptr_t)h | (uintptr_t)r_prev | (uintptr_t)g_prev | (uintptr_t)gv_prev | (uintptr_t)gT_prev |
+                         ((((uintptr_t)h | (uintptr_t)r_prev_any | (uintptr_t)g_prev | (uintptr_t)gv_prev | (uintptr_t)gT_prev |
                             (uintptr_t)gvT_prev) & 15u) == 0);
         if (vec)
             hipLaunchKernelGGL((k_head_dx<T, true>), dim3(nb), dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
-                               relu_mask, r_prev, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT);
+                               relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT);
         else
             hipLaunchKernelGGL((k_head_dx<T, false>), dim3(nb), dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
-                               relu_mask, r_prev, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT);
+                               relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT);
     }
     return vbnn_check_launch("k_head_backward");
 }
 
 extern "C" int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                                   const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
-                                  float* gradBias, int relu_mask, const float* r_prev, int64_t ld_r_prev, void* g_prev,
-                                  void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT) {
+                                  float* gradBias, int relu_mask, const void* r_prev, int64_t ld_r_prev, int r_prev_packed,
+                                  void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && h && w3 && g_logits, "null argument");
     VBNN_REQUIRE(N > 0 && H > 0 && C > 0 && C <= HEAD_CMAX, "shape (C <= 16)");
@@ -371,12 +377,12 @@ extern "C" int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64
     VBNN_REQUIRE(!(gT_prev || gvT_prev) || ld_gpT >= N, "ld_gpT");
     if (dtype == VBNN_F32)
         return head_backward_t<float>(ctx, (const float*)h, ld_h, (const float*)w3, ld_w, g_logits, N, H, C, accumulate, gradWeight,
-                                      gradBias, relu_mask, r_prev, ld_r_prev, (float*)g_prev, (float*)gv_prev, ld_gp,
-                                      (float*)gT_prev, (float*)gvT_prev, ld_gpT);
+                                      gradBias, relu_mask, r_prev, ld_r_prev, r_prev_packed, (float*)g_prev, (float*)gv_prev,
+                                      ld_gp, (float*)gT_prev, (float*)gvT_prev, ld_gpT);
     if (dtype == VBNN_BF16)
         return head_backward_t<bf16_t>(ctx, (const bf16_t*)h, ld_h, (const bf16_t*)w3, ld_w, g_logits, N, H, C, accumulate,
-                                       gradWeight, gradBias, relu_mask, r_prev, ld_r_prev, (bf16_t*)g_prev, (bf16_t*)gv_prev,
-                                       ld_gp, (bf16_t*)gT_prev, (bf16_t*)gvT_prev, ld_gpT);
+                                       gradWeight, gradBias, relu_mask, r_prev, ld_r_prev, r_prev_packed, (bf16_t*)g_prev,
+                                       (bf16_t*)gv_prev, ld_gp, (bf16_t*)gT_prev, (bf16_t*)gvT_prev, ld_gpT);
     vbnn_set_error("unsupported dtype %d", dtype);
     return VBNN_ERR_UNSUPPORTED;
     VBNN_API_END

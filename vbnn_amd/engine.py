@@ -119,7 +119,7 @@ class FusedMLP:
             v.xT_s, v.x2T_s = _Packed(v.I, N, tdt, dev), _Packed(v.I, N, tdt, dev)
             v.g_s, v.gv_s = _Packed(N, v.O, tdt, dev), _Packed(N, v.O, tdt, dev)
             v.gT_s, v.gvT_s = _Packed(v.O, N, tdt, dev), _Packed(v.O, N, tdt, dev)
-            v.r = torch.zeros(N, v.O, dtype=torch.float32, device=dev)
+            v.r = torch.zeros(N, v.O, dtype=tdt, device=dev)          # z / (2 sqrt(v)), stored in the operand type
         H = self.sizes[-1]
         self.h_s = _Packed(N, H, tdt, dev)            # input of the final Linear
         self.hT_s = _Packed(H, N, tdt, dev)
@@ -218,7 +218,7 @@ class FusedMLP:
         vl = self.vb[-1]
         dx = L.DxArgs(wT=self.w3T_s.ptr, w2T=None, g=self.g3_s.ptr, gv=None, ld_wT=self.w3T_s.ld, ld_g=self.g3_s.ld,
                       N=N, I=H, O=Cn, x=self.h_s.ptr, ld_x=self.h_s.ld, gx=None, ld_gx=0, relu_mask=1,
-                      r_prev=_p(vl.r) if lrt else None, ld_r_prev=vl.O, g_prev=vl.g_s.ptr,
+                      r_prev=_p(vl.r) if lrt else None, ld_r_prev=vl.O, r_prev_packed=1, g_prev=vl.g_s.ptr,
                       gv_prev=vl.gv_s.ptr if lrt else None, ld_gp=vl.g_s.ld, gT_prev=vl.gT_s.ptr,
                       gvT_prev=vl.gvT_s.ptr if lrt else None, ld_gpT=vl.gT_s.ld)
         L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
@@ -232,7 +232,7 @@ class FusedMLP:
         return L.FwdArgs(w=v.mu_s.ptr, w2=v.var_s.ptr if lrt else None, x=v.x_s.ptr, x2=v.x2_s.ptr if lrt else None,
                          ld_w=v.mu_s.ld, ld_x=v.x_s.ld, N=N, I=v.I, O=v.O, bias=_p(v.bias), seed=self.seed,
                          layer=v.layer_id, draw=self.draw, row0=row0, y=None, ld_y=0,
-                         r=_p(v.r) if lrt else None, ld_r=v.O, relu=1,
+                         r=_p(v.r) if lrt else None, ld_r=v.O, r_packed=1, relu=1,
                          h=self.h_s.ptr if last else nxt.x_s.ptr,
                          h2=None if (last or not lrt) else nxt.x2_s.ptr,
                          ld_h=self.h_s.ld if last else nxt.x_s.ld,
@@ -259,7 +259,7 @@ class FusedMLP:
         return L.DxArgs(wT=v.muT_s.ptr, w2T=v.varT_s.ptr if lrt else None, g=v.g_s.ptr,
                         gv=v.gv_s.ptr if lrt else None, ld_wT=v.muT_s.ld, ld_g=v.g_s.ld, N=N, I=v.I, O=v.O,
                         x=v.x_s.ptr, ld_x=v.x_s.ld, gx=None, ld_gx=0, relu_mask=1,
-                        r_prev=_p(p.r) if lrt else None, ld_r_prev=p.O, g_prev=p.g_s.ptr,
+                        r_prev=_p(p.r) if lrt else None, ld_r_prev=p.O, r_prev_packed=1, g_prev=p.g_s.ptr,
                         gv_prev=p.gv_s.ptr if lrt else None, ld_gp=p.g_s.ld, gT_prev=p.gT_s.ptr,
                         gvT_prev=p.gvT_s.ptr if lrt else None, ld_gpT=p.gT_s.ld)
 
@@ -276,11 +276,8 @@ class FusedMLP:
         accumulate = 0 if self._first else 1
         inv_n = 1.0 / (N * self.world)
         v0 = self.vb[0]
-        L.check(lib.vbnn_pack(ctx, code, L.PACK_COPY, _p(x), None, x.stride(0), N, v0.I, v0.x_s.ptr, v0.x_s.ld,
-                              v0.xT_s.ptr, v0.xT_s.ld))
-        if lrt:
-            L.check(lib.vbnn_pack(ctx, code, L.PACK_SQUARE, _p(x), None, x.stride(0), N, v0.I, v0.x2_s.ptr, v0.x2_s.ld,
-                                  v0.x2T_s.ptr, v0.x2T_s.ld))
+        L.check(lib.vbnn_pack_input(ctx, code, _p(x), x.stride(0), N, v0.I, v0.x_s.ptr, v0.x2_s.ptr if lrt else None,
+                                    v0.x_s.ld, v0.xT_s.ptr, v0.x2T_s.ptr if lrt else None, v0.xT_s.ld))
         nl = len(self.vb)
         # ---------------- forward
         for li in range(nl):
@@ -297,7 +294,7 @@ class FusedMLP:
                 return
             L.check(lib.vbnn_head_backward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
                                            _p(self.g_logits), N, H, Cn, accumulate, _p(self.gradWeight3),
-                                           _p(self.gradBias3), 1, _p(vl.r) if lrt else None, vl.O, vl.g_s.ptr,
+                                           _p(self.gradBias3), 1, _p(vl.r) if lrt else None, vl.O, 1, vl.g_s.ptr,
                                            vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr,
                                            vl.gvT_s.ptr if lrt else None, vl.gT_s.ld))
             self._reduce(self.bucket3)
