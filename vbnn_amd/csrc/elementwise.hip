@@ -350,7 +350,15 @@ __global__ __launch_bounds__(256) void k_col_sum_finish(const float* __restrict_
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= O) return;
     float tot = 0.f;
-    for (int r = 0; r < R; ++r) tot += partial[(int64_t)r * O + o];
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {                      // eight independent loads in flight, summed in chunk order
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = partial[(int64_t)(r + u) * O + o];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += p[u];
+    }
+    for (; r < R; ++r) tot += partial[(int64_t)r * O + o];
     const float old = accumulate ? gradBias[o] : 0.f;
     gradBias[o] = fmaf(scale, tot, old);
 }

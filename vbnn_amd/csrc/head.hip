@@ -60,8 +60,18 @@ __global__ __launch_bounds__(256) void k_head_forward(const T* __restrict__ h, i
     const int64_t ksteps = Hp / KE;
     const int64_t k_lo = ksteps * wave / 4, k_hi = ksteps * (wave + 1) / 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int64_t ks = k_lo; ks < k_hi; ++ks) {
+    int64_t ks = k_lo;
+    for (; ks + 4 <= k_hi; ks += 4) {                 // four K steps of loads in flight (latency-bound otherwise)
+        frag_t a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const frag_t*>(wp + (ks + u) * KE);
+            b[u] = *reinterpret_cast<const frag_t*>(hp + (ks + u) * KE);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = mfma_step<T>(a[u], b[u], acc);
+    }
+    for (; ks < k_hi; ++ks) {
         const frag_t a = *reinterpret_cast<const frag_t*>(wp + ks * KE);
         const frag_t b = *reinterpret_cast<const frag_t*>(hp + ks * KE);
         acc = mfma_step<T>(a, b, acc);
@@ -143,16 +153,27 @@ __global__ __launch_bounds__(256) void k_head_dw_partial(const T* __restrict__ h
         }
         __syncthreads();
         if (col_ok) {
-            for (int rr = sub; rr < rows; rr += 4) {
-                float hv[8];
-                Vec8<T>::load(h + (nb + rr) * ld_h + i0, hv);
+            // four rows in flight per thread: the loop is latency-bound otherwise (4 waves per CU, one 16-byte
+            // load per 80 FMAs)
+            for (int rr = sub; rr < rows; rr += 16) {
+                float hv[4][8];
 #pragma unroll
-                for (int c = 0; c < HEAD_CMAX; ++c)
-                    if (c < C) {
-                        const float gv = gs[rr][c];
+                for (int u = 0; u < 4; ++u) {
+                    const int r_ = min(rr + 4 * u, rows - 1);
+                    Vec8<T>::load(h + (nb + r_) * ld_h + i0, hv[u]);
+                }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[c][e] = fmaf(gv, hv[e], acc[c][e]);
+                for (int u = 0; u < 4; ++u) {
+                    if (rr + 4 * u < rows) {
+#pragma unroll
+                        for (int c = 0; c < HEAD_CMAX; ++c)
+                            if (c < C) {
+                                const float gv = gs[rr + 4 * u][c];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) acc[c][e] = fmaf(gv, hv[u][e], acc[c][e]);
+                            }
                     }
+                }
             }
         }
         if (blockIdx.x == 0 && threadIdx.x < C)
@@ -184,7 +205,15 @@ __global__ __launch_bounds__(256) void k_head_dw_finish(const float* __restrict_
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over C * H
     if (k < (int64_t)C * H) {
         float tot = 0.f;
-        for (int r = 0; r < R; ++r) tot += partial[(int64_t)r * C * H + k];
+        int r = 0;
+        for (; r + 8 <= R; r += 8) {                  // eight independent loads in flight, summed in chunk order
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = partial[(int64_t)(r + u) * C * H + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tot += p[u];
+        }
+        for (; r < R; ++r) tot += partial[(int64_t)r * C * H + k];
         gradWeight[k] = (accumulate ? gradWeight[k] : 0.f) + tot;
     }
     if (blockIdx.x == 0 && threadIdx.x < C && gradBias) {
