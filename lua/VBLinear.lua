@@ -9,7 +9,8 @@
 --
 -- This is the MODULE-LEVEL path: each call uploads its input and downloads its output (PCIe), which is what
 -- "unchanged mlp.lua" implies because nn.ReLU / nn.LogSoftMax between the layers are stock host modules. The
--- device-resident path is lua/mlp_hip.lua (one FFI call sequence per minibatch, activations never leave HBM).
+-- device-resident path is the call sequence of vbnn_amd/engine.py:FusedMLP.run over the same FFI
+-- (INTEGRATION.md section 4): one sequence per minibatch, activations never leave HBM.
 --
 -- NOT EXECUTED in the build image (no LuaJIT / Torch7 there): kept in step with vbnn_amd/nn.py, which is the
 -- same logic in Python and is what the GPU parity tests run.

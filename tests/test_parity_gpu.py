@@ -428,6 +428,24 @@ def test_layer_bf16_against_rounded_operands(nnmod, oracle, gemm_kernel, N, I, O
     assert np.abs(host(m.gradSum) - want_gs).max() <= 1e-3 * np.abs(want_gs).max()
 
 
+@pytest.mark.parametrize("mode", ["lrt", "wn"])
+def test_engine_deep_stack_matches_oracle(oracle, nnmod, mode):
+    """BASELINE configs[4]'s structure (a deep stack of VB layers) at test scale: five VB layers, three draws
+    accumulated with the fused KL epilogue (the gradInput hand-off chain runs through four ReLUs)."""
+    hidden, I0, N = [48, 40, 36, 32, 28], 44, 33
+    opt, eng, onet = _engine_pair(oracle, mode, "f32", hidden, I0, True, S=3)
+    loss, werr = _run_pair(opt, eng, onet, oracle, N, I0)
+    assert abs(loss - werr) <= 5e-5 * abs(werr) + 1e-6, (loss, werr)
+    for k, v in enumerate(eng.vb):
+        om = onet.vb[k]
+        mle, mlc = om.compute_mugrads(opt)
+        vle, vlc = om.compute_vargrads(opt)
+        want_mu, want_lv = mle + mlc, vle + vlc
+        np.testing.assert_allclose(host(v.gradWeight), want_mu, rtol=0, atol=5e-5 * np.abs(want_mu).max() + 1e-10)
+        np.testing.assert_allclose(host(v.gradSum), want_lv, rtol=0, atol=3e-4 * np.abs(want_lv).max() + 1e-10)
+        np.testing.assert_allclose(host(v.gradBias), om.gradBias, rtol=0, atol=5e-5 * np.abs(om.gradBias).max() + 1e-10)
+
+
 # ------------------------------------------------------------------------------------------- BASELINE.json's full sizes
 def test_full_size_bf16_layer_exact_on_integers(nnmod):
     """The 4096 x 4096 layer at batch 4096 (BASELINE configs[2]) on integer operands: forward, gradInput and

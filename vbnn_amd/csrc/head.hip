@@ -176,8 +176,10 @@ __global__ __launch_bounds__(256) void k_head_dw_partial(const T* __restrict__ h
                 }
             }
         }
-        if (blockIdx.x == 0 && threadIdx.x < C)
-            for (int rr = 0; rr < rows; ++rr) accb += g[(nb + rr) * C + threadIdx.x];
+        // bias gradient (column sums of the UNROUNDED g): 16 row lanes per class, folded at the end in a fixed order.
+        // (A single thread per class walking the rows is a 128-deep chain of dependent-latency loads.)
+        if (blockIdx.x == 0 && (threadIdx.x & 15) < C)
+            for (int rr = threadIdx.x >> 4; rr < rows; rr += 16) accb += g[(nb + rr) * C + (threadIdx.x & 15)];
     }
     // fold the four row lanes: red[sub][cg][c * 8 + e]
     const int stride = C * 8;
@@ -198,7 +200,17 @@ __global__ __launch_bounds__(256) void k_head_dw_partial(const T* __restrict__ h
             partial[((int64_t)blockIdx.y * C + c) * H + i] = tot;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < C) partial_b[(int64_t)blockIdx.y * C + threadIdx.x] = accb;
+    if (blockIdx.x == 0) {
+        __syncthreads();                                   // `red` is free again
+        red[threadIdx.x] = accb;                           // [16 row lanes][16 classes]
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float tot = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) tot += red[rg * 16 + threadIdx.x];
+            partial_b[(int64_t)blockIdx.y * C + threadIdx.x] = tot;
+        }
+    }
 }
 __global__ __launch_bounds__(256) void k_head_dw_finish(const float* __restrict__ partial, const float* __restrict__ partial_b, int R,
                                                         int64_t H, int C, int accumulate, float* gradWeight, float* gradBias) {
