@@ -48,7 +48,8 @@ const char* vbnn_last_error(void);
 /* test / A-B hook. VBNN_DEBUG_GEMM_KERNEL: 0 = pick by shape (default), 1 = always the general MFMA
  * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it. */
 #define VBNN_DEBUG_GEMM_KERNEL 0
-#define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel: 0 = DMAs burst after the barrier, 2 = interleaved with the MFMAs (default) */
+#define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel DMA schedule: -1 = by tile (default), 0 = burst after the barrier,
+                                      2 = interleaved with the MFMAs, 4 = 2 with skewed SIMD partners (gemm_v2.h) */
 #define VBNN_DEBUG_V2_TILE 2       /* pipelined kernel block tile: 0 = by shape (default), 128 = 128 x 128, 256 = 256 x 128 */
 int vbnn_debug_set(int key, int value);
 

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     hipStream_t st = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int dual = 0; dual < 2; ++dual)
-        for (int sched = 0; sched < 3; sched += 2) {
+        for (int sched = 0; sched < 5; sched += 2) {
             g_v2_sched = sched;
             auto launch = [&] {
                 if (dual) launch_gemm_v2<bf16_t, true, EpiSum>(st, A, A2, K, B, B2, K, M, N, K, epi);

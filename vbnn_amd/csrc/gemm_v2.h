@@ -63,7 +63,10 @@ __device__ unsigned long long* g_v2_diag = nullptr;
 #define V2_STAMP_FLUSH
 #endif
 
-static int g_v2_sched = 2;        // 0: burst the DMAs after the barrier; 2: interleave them with the MFMAs (default)
+// DMA schedule: 0 = burst after the barrier; 2 = interleaved with the MFMAs; 4 = 2 with the SIMD partners' DMA slots
+// skewed (measured: no better than 2); -1 = auto: 2 for the 8-wave 256 x 128 tile (+8 % over 0), 0 for the 4-wave
+// 128 x 128 tile (one wave per SIMD has no partner to cover an interleaved DMA issue: 0 is 8 % faster there).
+static int g_v2_sched = -1;
 static int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -148,9 +151,11 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         unsigned char* base = lds + (u % V2_STAGES) * STAGE;
         if constexpr (IDX < AG)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + NW * IDX) * 1024), 16, 0, 0);
+#ifndef V2_LAB_SKIP_B      // tools/gemm_lab.hip only: time the loop with a third of the DMA traffic removed (wrong results)
         else if constexpr (IDX < G)
             __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][IDX - AG] + koff),
                                              (lptr_t)(base + A_BYTES + (wave + NW * (IDX - AG)) * 1024), 16, 0, 0);
+#endif
     };
     auto issue = [&](int u, auto pair_c) {
         issue_one(u, pair_c, std::integral_constant<int, 0>()); issue_one(u, pair_c, std::integral_constant<int, 1>());
@@ -180,6 +185,11 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
 
     std::integral_constant<int, 0> c0;
     std::integral_constant<int, 1> c1;
+    // SCHED 4: the two waves of a SIMD (w and w + 4, MI355X_MICROARCH.md "Two waves per SIMD") put their DMAs on
+    // opposite sides of each four-MFMA group, so one wave's ~80-cycle DMA issue sits beside the other's MFMAs
+    // instead of both stalling together.
+    const bool late = (WM == 4) && (__builtin_amdgcn_readfirstlane(wave) >= 4);
+    (void)late;
     V2_STAMP_DECL
 
     // ---- prologue: two tiles in flight
@@ -188,7 +198,11 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
 
     auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
         V2_STAMP(0);
+#ifdef V2_LAB_SKIP_B
+        if (u + 1 < U) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
         if (u + 1 < U) v2_wait_vmcnt<G>();
+#endif
         else           v2_wait_vmcnt<0>();
         V2_STAMP(1);                                     // [0->1] waiting for this wave's DMAs
         __builtin_amdgcn_s_barrier();
@@ -205,23 +219,28 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
                 af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
                 bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
             }
+            auto slot = [&](int s_, int i_) {            // the DMA that belongs to MFMA group (k-half s_, row i_)
+                if (s_ == 0 && i_ == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
+                if (s_ == 0 && i_ == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
+                if (s_ == 0 && i_ == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
+                if (s_ == 0 && i_ == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 6>());
+                if (s_ == 1 && i_ == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
+                if (s_ == 1 && i_ == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
+                if (s_ == 1 && i_ == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
+                if (s_ == 1 && i_ == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 7>());
+            };
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (SCHED == 4) {                        // late waves issue their DMA AHEAD of the four MFMAs ...
+                    if (more && late) slot(sidx, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                if (SCHED == 2) {
-                    if (more) {                          // one DMA behind every four MFMAs
-                        if (sidx == 0 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
-                        if (sidx == 0 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
-                        if (sidx == 0 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
-                        if (sidx == 0 && i == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 6>());
-                        if (sidx == 1 && i == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
-                        if (sidx == 1 && i == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
-                        if (sidx == 1 && i == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
-                        if (sidx == 1 && i == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 7>());
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // keep each DMA behind its four MFMAs
+                if (SCHED == 2 || SCHED == 4) {          // ... early waves BEHIND them: one DMA per four MFMAs either way
+                    if (more && (SCHED == 2 || !late)) slot(sidx, i);
+                    __builtin_amdgcn_sched_barrier(0);   // keep each DMA where it was put
                 }
             }
         }
@@ -340,21 +359,23 @@ static int launch_gemm_v2(hipStream_t stream, const T* A, const T* A2, int64_t l
         // 128 x 128 tiling fills more of them (the 784 x 4096 gradient: 128 blocks vs 224)
         const int64_t t256 = v2_tiles(M, N, 256), t128 = v2_tiles(M, N, 128);
         const bool small = g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256);
-        const int sched = g_v2_sched == 0 ? 0 : 2;
+        const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small ? 0 : 2);
+        const int si = sched >> 1;                       // 0, 1, 2
         const void* kern;
         int threads, lds_bytes, bm;
-        if (small) {
+        if (small) {                                     // four waves: no SIMD partner to skew against
             kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 2, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 2, Epi>;
             threads = 256; lds_bytes = v2_lds(2); bm = 128;
         } else {
-            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 4, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 4, Epi>;
+            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 4, Epi>
+                 : sched == 2 ? (const void*)gemm_nt_v2<DUAL, 2, 4, Epi> : (const void*)gemm_nt_v2<DUAL, 4, 4, Epi>;
             threads = 512; lds_bytes = v2_lds(4); bm = 256;
         }
-        static bool configured[2][2] = {{false, false}, {false, false}};      // per instantiation of this launcher
-        if (!configured[small][sched != 0]) {
+        static bool configured[2][3] = {{false, false, false}, {false, false, false}};      // per instantiation of this launcher
+        if (!configured[small][si]) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
-            configured[small][sched != 0] = true;
+            configured[small][si] = true;
         }
         const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + V2_BN - 1) / V2_BN;
         const bf16_t* a = (const bf16_t*)A; const bf16_t* a2 = (const bf16_t*)A2;
