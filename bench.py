@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="wide", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="run accGradParameters on a second stream (A/B; slower)")
     ap.add_argument("--mode", default="lrt", choices=["lrt", "wn"])
     args = ap.parse_args()
 
@@ -164,7 +165,7 @@ def main():
     cfg = CONFIGS[args.config]
     N = cfg["batch"]
     opt = dict(var_init=1e-3, B=1e6, S=1, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
-               hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True)
+               hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap)
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
     # synthetic minibatch, resident in HBM: x ~ N(0,1) addressed by GLOBAL row, targets uniform in 0..9
     x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")

@@ -539,6 +539,25 @@ def test_engine_is_bitwise_reproducible_and_handles_tiny_batches(oracle, nnmod, 
         assert np.isfinite(arenas[0]).all()
 
 
+def test_engine_two_stream_backward_is_identical(oracle, nnmod):
+    """opt.overlap = True (accGradParameters on a second HIP stream) changes scheduling only: the gradient arena
+    is bit-identical to the single-stream run, draw after draw."""
+    from vbnn_amd.engine import FusedMLP
+    x = oracle.fill_normal(64, 70, SEED, 4, 0, 0)
+    t = (np.arange(64) * 7 % 10).astype(np.int32)
+    arenas = []
+    for overlap in (False, True):
+        opt = opt_for("lrt", "bf16", input_size=70, hidden=[50, 34, 30], S=2, fuse_kl=True, overlap=overlap)
+        eng = FusedMLP(opt)
+        for step in range(3):
+            eng.resetGradients(); eng.prepare()
+            for _ in range(2):
+                eng.sample(); eng.run(dev(x), dev(t))
+            eng.finish()
+        arenas.append(host(eng.grads).copy())
+    assert np.array_equal(arenas[0].view(np.uint32), arenas[1].view(np.uint32))
+
+
 # ------------------------------------------------------------------------------------------- update (SURVEY 8f next #1)
 OPT_STATES = dict(state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
 

@@ -292,10 +292,13 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         float t1[4], t2[4];
         epi.template apply<false>(wm0 + 4 * c16, wn0 + 4 * p + q4, r1[p], r2[p], t1, t2);
         if (any_t) {
+            // 8-element chunks XOR-swizzled by (row >> 2) & 7: without it the 16 lanes of a quarter-wave hit two
+            // banks (rows 4 apart are 576 B apart: 8-way conflict, 8.1 M conflict cycles per 4096^2 launch measured)
+            const int col = (((4 * p + q4) >> 3) ^ (c16 & 7)) * 8 + ((4 * p + q4) & 7);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                tl1[(4 * c16 + j) * TP + 4 * p + q4] = Elt<ET>::to(t1[j]);
-                tl2[(4 * c16 + j) * TP + 4 * p + q4] = Elt<ET>::to(t2[j]);
+                tl1[(4 * c16 + j) * TP + col] = Elt<ET>::to(t1[j]);
+                tl2[(4 * c16 + j) * TP + col] = Elt<ET>::to(t2[j]);
             }
         }
     }
@@ -311,12 +314,12 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
             const int mm = wm0 + ml;
             if (mm < Md && nn < Nd) {
                 if (tp1) {
-                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(tl1 + ml * TP + 8 * (lane & 7));
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(tl1 + ml * TP + 8 * ((lane & 7) ^ ((ml >> 2) & 7)));
                     if (vec_ok) *reinterpret_cast<bf16x8*>(tp1 + (int64_t)mm * ldt + nn) = v;
                     else for (int e = 0; e < 8; ++e) if (nn + e < Nd) tp1[(int64_t)mm * ldt + nn + e] = v[e];
                 }
                 if (tp2) {
-                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(tl2 + ml * TP + 8 * (lane & 7));
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(tl2 + ml * TP + 8 * ((lane & 7) ^ ((ml >> 2) & 7)));
                     if (vec_ok) *reinterpret_cast<bf16x8*>(tp2 + (int64_t)mm * ldt + nn) = v;
                     else for (int e = 0; e < 8; ++e) if (nn + e < Nd) tp2[(int64_t)mm * ldt + nn + e] = v[e];
                 }

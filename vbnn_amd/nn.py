@@ -30,10 +30,13 @@ class Context:
     """(device, stream) handle of the library; one per device, bound to torch's current stream."""
     _cache = {}
 
-    def __init__(self, device):
+    def __init__(self, device, stream=None):
+        """stream: a torch.cuda.Stream to bind to (default: torch's current stream on `device`). Each context
+        owns its reduction scratch, so kernels launched through different contexts may run concurrently."""
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.torch_stream = stream
+        stream = (stream or torch.cuda.current_stream(self.device)).cuda_stream
         h = C.c_void_p()
         L.check(L.lib().vbnn_ctx_create(device, C.c_void_p(stream), C.byref(h)))
         self.h = h
