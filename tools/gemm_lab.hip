@@ -1,7 +1,9 @@
 // gemm_lab.hip -- stand-alone playground for the pipelined GEMM main loop (diagnostic build, not product).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DV2_DIAG tools/gemm_lab.hip -o gpurun_out/gemm_lab && gpurun_out/gemm_lab
 // Random bf16 operands, trivial epilogue, event timing of both schedules and s_memtime segment shares.
+#ifndef LAB_NO_DIAG      // -DLAB_NO_DIAG: no stamps at all (timings comparable with the library build)
 #define V2_DIAG 1
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <cstdarg>
@@ -26,6 +28,8 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
 };
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+int lab_half(int M, int N, int K, const bf16_t* A, const bf16_t* A2, const bf16_t* B, const bf16_t* B2, float* out);
+
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
     const size_t ea = (size_t)M * K, eb = (size_t)N * K;
@@ -41,7 +45,9 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(B, hb.data(), eb * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B2, ha.data(), std::min(ea, eb) * 2, hipMemcpyHostToDevice));
     const int tiles = ((M + 255) / 256) * ((N + 127) / 128);
     CK(hipMalloc(&diag, (size_t)tiles * 8 * 4 * 8)); CK(hipMemset(diag, 0, (size_t)tiles * 8 * 4 * 8));
+#ifdef V2_DIAG
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_v2_diag), &diag, sizeof(diag)));
+#endif
     EpiSum epi{out, M, N};
     hipStream_t st = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -64,7 +70,8 @@ int main(int argc, char** argv) {
             std::sort(ts.begin(), ts.end());
             const double fl = 2.0 * M * N * K * (dual ? 2 : 1);
             printf("M=%d N=%d K=%d %s sched%d: median %.1f us  %.0f TF", M, N, K, dual ? "dual  " : "single", sched, ts[2], fl / ts[2] / 1e6);
-            if (true) {
+#ifdef V2_DIAG
+            {
                 std::vector<unsigned long long> hd((size_t)tiles * 8 * 4);
                 CK(hipMemcpy(hd.data(), diag, hd.size() * 8, hipMemcpyDeviceToHost));
                 double s[4] = {0, 0, 0, 0};
@@ -73,7 +80,139 @@ int main(int argc, char** argv) {
                 printf("   cycles/wave: wait_dma %.0f (%.0f%%) barrier %.0f (%.0f%%) issue %.0f (%.0f%%) read+mfma %.0f (%.0f%%)",
                        s[0] / nw, 100 * s[0] / tot, s[1] / nw, 100 * s[1] / tot, s[2] / nw, 100 * s[2] / tot, s[3] / nw, 100 * s[3] / tot);
             }
+#endif
             printf("\n");
         }
+    return lab_half(M, N, K, A, A2, B, B2, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Experiment (lab only): "loader half". Waves 0-3 issue ALL twelve DMAs of a tile (their own groups and their SIMD
+// partners'), waves 4-7 issue none: does a wave's DMA issue overlap its partner's MFMAs when only one of the two
+// carries DMAs? Same ring / swizzle / waits as gemm_nt_v2<true, 2, 4>, direct (unstaged) epilogue.
+template <class Epi>
+__global__ __launch_bounds__(512, 2) void gemm_lab_half(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
+                                                        const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
+                                                        int M, int N, int nk, int tiles_n, Epi epi) {
+    constexpr int A_BYTES = v2_a_bytes(4), STAGE = v2_stage(4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 256, n0 = tn * 128;
+    const int lw = wave & 3;                         // loader index
+    const bf16_t* a_src[2][8];
+    const bf16_t* b_src[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 8 * (lw + 4 * i) + (lane >> 3);
+        const int64_t off = (int64_t)min(m0 + row, M - 1) * lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        a_src[0][i] = A + off; a_src[1][i] = A2 + off;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (lw + 4 * i) + (lane >> 3);
+        const int64_t off = (int64_t)min(n0 + row, N - 1) * ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        b_src[0][i] = B + off; b_src[1][i] = B2 + off;
+    }
+    const int U = 2 * nk;
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) < 4;
+    auto issue_one = [&](int u, auto pair_c, auto idx_c) {
+        constexpr int P = decltype(pair_c)::value;
+        constexpr int IDX = decltype(idx_c)::value;
+        const int64_t koff = (int64_t)(u >> 1) * V2_BK;
+        unsigned char* base = lds + (u % V2_STAGES) * STAGE;
+        if constexpr (IDX < 8)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (lw + 4 * IDX) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][IDX - 8] + koff), (lptr_t)(base + A_BYTES + (lw + 4 * (IDX - 8)) * 1024), 16, 0, 0);
+    };
+    auto issue_all = [&](int u, auto pair_c) {
+        issue_one(u, pair_c, std::integral_constant<int, 0>()); issue_one(u, pair_c, std::integral_constant<int, 1>());
+        issue_one(u, pair_c, std::integral_constant<int, 2>()); issue_one(u, pair_c, std::integral_constant<int, 3>());
+        issue_one(u, pair_c, std::integral_constant<int, 4>()); issue_one(u, pair_c, std::integral_constant<int, 5>());
+        issue_one(u, pair_c, std::integral_constant<int, 6>()); issue_one(u, pair_c, std::integral_constant<int, 7>());
+        issue_one(u, pair_c, std::integral_constant<int, 8>()); issue_one(u, pair_c, std::integral_constant<int, 9>());
+        issue_one(u, pair_c, std::integral_constant<int, 10>()); issue_one(u, pair_c, std::integral_constant<int, 11>());
+    };
+    const int rsw = (lane & 15) >> 1, q = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int csw = ((4 * s + q) ^ rsw) * 16;
+        a_off[s] = (wm * 64 + (lane & 15)) * 128 + csw;
+        b_off[s] = A_BYTES + (wn * 64 + (lane & 15)) * 128 + csw;
+    }
+    f32x4 acc1[4][4], acc2[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    std::integral_constant<int, 0> c0; std::integral_constant<int, 1> c1;
+    if (loader) { issue_all(0, c0); issue_all(1, c1); }
+    auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
+        if (loader) {
+            if (u + 1 < U) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const bool more = loader && (u + 2 < U);
+        const unsigned char* stage = lds + (u % V2_STAGES) * STAGE;
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
+                bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    if (more && (j == 1 || j == 3)) {       // a DMA after every second MFMA of the first 24
+                        const int slot = sidx * 8 + i * 2 + (j >> 1);
+                        if (slot == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
+                        if (slot == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
+                        if (slot == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
+                        if (slot == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
+                        if (slot == 4) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
+                        if (slot == 5) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
+                        if (slot == 6) issue_one(u + 2, pair_c, std::integral_constant<int, 6>());
+                        if (slot == 7) issue_one(u + 2, pair_c, std::integral_constant<int, 7>());
+                        if (slot == 8) issue_one(u + 2, pair_c, std::integral_constant<int, 8>());
+                        if (slot == 9) issue_one(u + 2, pair_c, std::integral_constant<int, 9>());
+                        if (slot == 10) issue_one(u + 2, pair_c, std::integral_constant<int, 10>());
+                        if (slot == 11) issue_one(u + 2, pair_c, std::integral_constant<int, 11>());
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    };
+    for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+    float t1[4], t2[4];
+    const int em = m0 + wm * 64 + (lane >> 4) * 4, en = n0 + wn * 64 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi.template apply<true>(em + i * 16, en + j * 16, acc1[i][j], acc2[i][j], t1, t2);
+}
+
+int lab_half(int M, int N, int K, const bf16_t* A, const bf16_t* A2, const bf16_t* B, const bf16_t* B2, float* out) {
+    EpiSum epi{out, M, N};
+    auto kern = gemm_lab_half<EpiSum>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, v2_lds(4)));
+    const int tm = (M + 255) / 256, tn = (N + 127) / 128, nk = K / 64;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ts;
+    for (int r = 0; r < 6; ++r) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(512), v2_lds(4), 0, A, A2, (int64_t)K, B, B2, (int64_t)K, M, N, nk, tn, epi);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r) ts.push_back(ms / 10 * 1e3f);
+    }
+    std::sort(ts.begin(), ts.end());
+    printf("M=%d N=%d K=%d dual   loader-half: median %.1f us  %.0f TF\n", M, N, K, ts[2], 4.0 * M * N * K / ts[2] / 1e6);
     return 0;
 }

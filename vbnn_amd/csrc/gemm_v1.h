@@ -8,9 +8,11 @@
 // (gemm_v2.h) does not take.
 //
 // Geometry: 256 threads = 4 waves (2 x 2), block tile (32*WR) x (32*WR), WR = 2 or 4 MFMA
-// tiles per wave per dimension, K step = 64 bytes of K per row (16 f32 / 32 bf16).
-// Operands are "packed": K contiguous, leading dimension padded to VBNN_KPAD elements with
-// zeros, so the K loop needs no tail handling.
+// tiles per wave per dimension. K step = KS x 64 bytes of K per row: KS = 1 for the 128 x 128 tile;
+// KS = 2 for the 64 x 64 tile of small problems (tens of blocks on 256 CUs, so every K step is a full
+// global-load latency: half as many barrier / latency round trips).
+// Operands are "packed": K contiguous, leading dimension padded to VBNN_KPAD = 64 elements with
+// zeros, so the K loop needs no tail handling in either geometry.
 #pragma once
 #include "common.h"
 
@@ -33,21 +35,23 @@ __device__ __forceinline__ f32x4 mfma_step<bf16_t>(const bf16x8& a, const bf16x8
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-constexpr int V1_ROW_BYTES = 80;   // 64 B of K + 16 B pad: conflict-free ds_read_b128 down a column
-
-template <typename T, bool DUAL, int WR, class Epi>
+template <typename T, bool DUAL, int WR, int KS, class Epi>
 __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const T* __restrict__ A2, int64_t lda,
                                                   const T* __restrict__ B, const T* __restrict__ B2, int64_t ldb,
                                                   int M, int N, int Kp, Epi epi) {
-    constexpr int BT = 32 * WR;                 // block tile rows (M and N)
-    constexpr int KE = 64 / (int)sizeof(T);     // K elements per step
-    constexpr int CE = 16 / (int)sizeof(T);     // elements per 16-byte chunk
-    constexpr int CHUNKS = BT * 4;              // 16-byte chunks per operand tile
-    constexpr int CPT = CHUNKS / 256;           // chunks per thread per operand tile (1 or 2)
+    constexpr int BT = 32 * WR;                       // block tile rows (M and N)
+    constexpr int RB = 64 * KS;                       // bytes of K per row per step
+    constexpr int PITCH = RB + 16;                    // + 16 B pad: conflict-free ds_read_b128 down a column
+    constexpr int KE = RB / (int)sizeof(T);           // K elements per step
+    constexpr int CE = 16 / (int)sizeof(T);           // elements per 16-byte chunk
+    constexpr int CPR = RB / 16;                      // chunks per row
+    constexpr int CHUNKS = BT * CPR;                  // 16-byte chunks per operand tile
+    constexpr int CPT = CHUNKS / 256;                 // chunks per thread per operand tile
     constexpr int NOP = DUAL ? 4 : 2;
+    static_assert(CHUNKS % 256 == 0, "tile does not divide over 256 threads");
     typedef typename Frag<T>::type frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NOP * BT * V1_ROW_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NOP * BT * PITCH];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -62,8 +66,8 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const int chunk = tid + c * 256;
-        const int row = chunk >> 2, kc = chunk & 3;
-        lds_off[c] = row * V1_ROW_BYTES + kc * 16;
+        const int row = chunk / CPR, kc = chunk % CPR;
+        lds_off[c] = row * PITCH + kc * 16;
 #pragma unroll
         for (int op = 0; op < NOP; ++op) {
             const bool isA = (op & 1) == 0;
@@ -84,15 +88,15 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
 #pragma unroll
         for (int c = 0; c < CPT; ++c) stage[op][c] = *reinterpret_cast<const uint4*>(gptr[op][c]);
 
-    const int a_row = (wm * WR * 16 + (lane & 15)) * V1_ROW_BYTES + (lane >> 4) * 16;
-    const int b_row = (wn * WR * 16 + (lane & 15)) * V1_ROW_BYTES + (lane >> 4) * 16;
+    const int a_row = (wm * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
+    const int b_row = (wn * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
 
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int op = 0; op < NOP; ++op)
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                *reinterpret_cast<uint4*>(lds + op * BT * V1_ROW_BYTES + lds_off[c]) = stage[op][c];
+                *reinterpret_cast<uint4*>(lds + op * BT * PITCH + lds_off[c]) = stage[op][c];
         __syncthreads();
         if (kt + 1 < nk) {
 #pragma unroll
@@ -101,26 +105,29 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
                 for (int c = 0; c < CPT; ++c)
                     stage[op][c] = *reinterpret_cast<const uint4*>(gptr[op][c] + (int64_t)(kt + 1) * KE);
         }
-        frag_t af[WR], bf[WR];
 #pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            af[i] = *reinterpret_cast<const frag_t*>(lds + 0 * BT * V1_ROW_BYTES + a_row + i * 16 * V1_ROW_BYTES);
-            bf[i] = *reinterpret_cast<const frag_t*>(lds + 1 * BT * V1_ROW_BYTES + b_row + i * 16 * V1_ROW_BYTES);
-        }
-#pragma unroll
-        for (int i = 0; i < WR; ++i)
-#pragma unroll
-            for (int j = 0; j < WR; ++j) acc1[i][j] = mfma_step<T>(af[i], bf[j], acc1[i][j]);
-        if (DUAL) {
+        for (int ks = 0; ks < KS; ++ks) {             // 64 bytes of K per row per sub-step
+            frag_t af[WR], bf[WR];
 #pragma unroll
             for (int i = 0; i < WR; ++i) {
-                af[i] = *reinterpret_cast<const frag_t*>(lds + 2 * BT * V1_ROW_BYTES + a_row + i * 16 * V1_ROW_BYTES);
-                bf[i] = *reinterpret_cast<const frag_t*>(lds + 3 * BT * V1_ROW_BYTES + b_row + i * 16 * V1_ROW_BYTES);
+                af[i] = *reinterpret_cast<const frag_t*>(lds + 0 * BT * PITCH + a_row + i * 16 * PITCH + ks * 64);
+                bf[i] = *reinterpret_cast<const frag_t*>(lds + 1 * BT * PITCH + b_row + i * 16 * PITCH + ks * 64);
             }
 #pragma unroll
             for (int i = 0; i < WR; ++i)
 #pragma unroll
-                for (int j = 0; j < WR; ++j) acc2[i][j] = mfma_step<T>(af[i], bf[j], acc2[i][j]);
+                for (int j = 0; j < WR; ++j) acc1[i][j] = mfma_step<T>(af[i], bf[j], acc1[i][j]);
+            if (DUAL) {
+#pragma unroll
+                for (int i = 0; i < WR; ++i) {
+                    af[i] = *reinterpret_cast<const frag_t*>(lds + 2 * BT * PITCH + a_row + i * 16 * PITCH + ks * 64);
+                    bf[i] = *reinterpret_cast<const frag_t*>(lds + 3 * BT * PITCH + b_row + i * 16 * PITCH + ks * 64);
+                }
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+#pragma unroll
+                    for (int j = 0; j < WR; ++j) acc2[i][j] = mfma_step<T>(af[i], bf[j], acc2[i][j]);
+            }
         }
         __syncthreads();
     }
@@ -136,19 +143,32 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
 template <typename T, bool DUAL, class Epi>
 static int launch_gemm_v1(hipStream_t stream, const T* A, const T* A2, int64_t lda, const T* B, const T* B2,
                           int64_t ldb, int M, int N, int K, const Epi& epi) {
-    const int KE = 64 / (int)sizeof(T);
-    const int Kp = (K + KE - 1) / KE * KE;
-    if (lda < Kp || ldb < Kp) {
-        vbnn_set_error("packed leading dimension too small: lda=%lld ldb=%lld need >= %d", (long long)lda, (long long)ldb, Kp);
-        return VBNN_ERR_INVALID;
-    }
     const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (blocks128 >= 128) {
+        const int KE = 64 / (int)sizeof(T);
+        const int Kp = (K + KE - 1) / KE * KE;
+        if (lda < Kp || ldb < Kp) {
+            vbnn_set_error("packed leading dimension too small: lda=%lld ldb=%lld need >= %d", (long long)lda, (long long)ldb, Kp);
+            return VBNN_ERR_INVALID;
+        }
         dim3 grid((M + 127) / 128, (N + 127) / 128);
-        hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 4, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+        hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 4, 1, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
     } else {
-        dim3 grid((M + 63) / 64, (N + 63) / 64);
-        hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 2, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+        constexpr int KS = 2;                                     // 128 B of K per row per step: 32 f32 / 64 bf16
+        constexpr int KE2 = 128 / (int)sizeof(T);                 // (4 x 64 x 144 B of LDS for the dual tile)
+        const int Kp = (K + KE2 - 1) / KE2 * KE2;
+        if (lda < Kp || ldb < Kp) {
+            vbnn_set_error("packed leading dimension too small: lda=%lld ldb=%lld need >= %d", (long long)lda, (long long)ldb, Kp);
+            return VBNN_ERR_INVALID;
+        }
+        const long blocks64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+        if (blocks64 >= 96) {
+            dim3 grid((M + 63) / 64, (N + 63) / 64);
+            hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 2, KS, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+        } else {        // latency-bound sizes (the 256 x 400 outputs of the small MLP): 32 x 32 tiles, 4x the blocks
+            dim3 grid((M + 31) / 32, (N + 31) / 32);
+            hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 1, KS, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+        }
     }
     return vbnn_check_launch("gemm_nt_v1");
 }
