@@ -50,7 +50,8 @@ const char* vbnn_last_error(void);
 #define VBNN_DEBUG_GEMM_KERNEL 0
 #define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel DMA schedule: -1 = by tile (default), 0 = burst after the barrier,
                                       2 = interleaved with the MFMAs, 4 = 2 with skewed SIMD partners (gemm_v2.h) */
-#define VBNN_DEBUG_V2_TILE 2       /* pipelined kernel block tile: 0 = by shape (default), 128 = 128 x 128, 256 = 256 x 128 */
+#define VBNN_DEBUG_V2_TILE 2       /* pipelined kernel block tile: 0 = by shape (default), 256 = 256 x 128, 128 = 128 x 128,
+                                      64 = 128 x 128 with a 2-stage ring, two workgroups per CU */
 int vbnn_debug_set(int key, int value);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream

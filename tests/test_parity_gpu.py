@@ -361,7 +361,8 @@ def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidd
     close(eng.gradBias3, gb3, "final gradBias")
 
 
-@pytest.fixture(params=[(1, 0), (2, 256), (2, 128)], ids=["general-kernel", "pipelined-256x128", "pipelined-128x128"])
+@pytest.fixture(params=[(1, 0), (2, 256), (2, 128), (2, 64)],
+                ids=["general-kernel", "pipelined-256x128", "pipelined-128x128", "pipelined-128x128-pairs"])
 def gemm_kernel(request, nnmod):
     """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in both block tiles), whatever the shape
     heuristics say."""

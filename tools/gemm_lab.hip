@@ -202,13 +202,13 @@ __global__ __launch_bounds__(512, 2) void gemm_lab_half(const bf16_t* __restrict
 int lab_half(int M, int N, int K, const bf16_t* A, const bf16_t* A2, const bf16_t* B, const bf16_t* B2, float* out) {
     EpiSum epi{out, M, N};
     auto kern = gemm_lab_half<EpiSum>;
-    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, v2_lds(4)));
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, v2_lds(4, 3)));
     const int tm = (M + 255) / 256, tn = (N + 127) / 128, nk = K / 64;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ts;
     for (int r = 0; r < 6; ++r) {
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(512), v2_lds(4), 0, A, A2, (int64_t)K, B, B2, (int64_t)K, M, N, nk, tn, epi);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(512), v2_lds(4, 3), 0, A, A2, (int64_t)K, B, B2, (int64_t)K, M, N, nk, tn, epi);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r) ts.push_back(ms / 10 * 1e3f);
     }

@@ -36,10 +36,10 @@
 
 constexpr int V2_BN = 128, V2_BK = 64;
 constexpr int V2_B_BYTES = V2_BN * V2_BK * 2;           // 16384
-constexpr int V2_STAGES = 3;
 constexpr int v2_a_bytes(int WM) { return 64 * WM * V2_BK * 2; }
 constexpr int v2_stage(int WM) { return v2_a_bytes(WM) + V2_B_BYTES; }
-constexpr int v2_lds(int WM) { return v2_stage(WM) * V2_STAGES; }     // 147456 (WM 4) / 98304 (WM 2)
+// LDS per workgroup: the ring, or the epilogue's 18 KiB-per-wave staging if that is larger (2 stages, 4 waves)
+constexpr int v2_lds(int WM, int ST) { return v2_stage(WM) * ST > 2 * WM * 18432 ? v2_stage(WM) * ST : 2 * WM * 18432; }   // 147456 / 98304 / 73728
 
 // Diagnostic stamps (tools/gemm_lab.hip builds with -DV2_DIAG; the library never does): per-wave cycle
 // sums of the segments of schedule 0, written to a buffer of their own, never to an output.
@@ -77,7 +77,7 @@ template <> __device__ __forceinline__ void v2_wait_vmcnt<0>() { asm volatile("s
 template <> __device__ __forceinline__ void v2_wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void v2_wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
-template <bool DUAL, int SCHED, int WM, class Epi>
+template <bool DUAL, int SCHED, int WM, int ST, class Epi>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                           const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
                                                           int M, int N, int nk, int tiles_m, int tiles_n, Epi epi) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         constexpr int P = decltype(pair_c)::value;
         constexpr int IDX = decltype(idx_c)::value;
         const int64_t koff = (int64_t)(DUAL ? (u >> 1) : u) * V2_BK;
-        unsigned char* base = lds + (u % V2_STAGES) * STAGE;
+        unsigned char* base = lds + (u % ST) * STAGE;
         if constexpr (IDX < AG)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + NW * IDX) * 1024), 16, 0, 0);
 #ifndef V2_LAB_SKIP_B      // tools/gemm_lab.hip only: time the loop with a third of the DMA traffic removed (wrong results)
@@ -192,25 +192,29 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     (void)late;
     V2_STAMP_DECL
 
-    // ---- prologue: two tiles in flight
+    // ---- prologue: ST - 1 tiles in flight
     issue(0, c0);
-    if (U > 1) { if (DUAL) issue(1, c1); else issue(1, c0); }
+    if (ST == 3 && U > 1) { if (DUAL) issue(1, c1); else issue(1, c0); }
 
-    auto step = [&](int u, auto pair_c, f32x4 (&acc)[4][4]) {
+    // tile u + LA (LA = ST - 1 tiles of lookahead) is issued while tile u is computed; its operand pair is the pair
+    // of tile u when LA = 2 and the other pair when LA = 1 (DUAL alternates pairs tile by tile)
+    constexpr int LA = ST - 1;
+    auto step = [&](int u, auto pair_c, auto next_c, f32x4 (&acc)[4][4]) {
+        auto la_c = std::conditional_t<ST == 3, decltype(pair_c), decltype(next_c)>();
         V2_STAMP(0);
 #ifdef V2_LAB_SKIP_B
         if (u + 1 < U) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #else
-        if (u + 1 < U) v2_wait_vmcnt<G>();
+        if (ST == 3 && u + 1 < U) v2_wait_vmcnt<G>();     // tile u + 1's DMAs may stay in flight
 #endif
-        else           v2_wait_vmcnt<0>();
+        else                       v2_wait_vmcnt<0>();
         V2_STAMP(1);                                     // [0->1] waiting for this wave's DMAs
         __builtin_amdgcn_s_barrier();
         V2_STAMP(2);                                     // [1->2] barrier
-        const bool more = u + 2 < U;                     // tile u+2 belongs to the same pair as tile u
-        if (SCHED == 0 && more) issue(u + 2, pair_c);
+        const bool more = u + LA < U;
+        if (SCHED == 0 && more) issue(u + LA, la_c);
         V2_STAMP(3);                                     // [2->3] issuing the DMAs (schedule 0)
-        const unsigned char* stage = lds + (u % V2_STAGES) * STAGE;
+        const unsigned char* stage = lds + (u % ST) * STAGE;
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
             bf16x8 af[4], bf[4];
@@ -220,14 +224,14 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
                 bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
             }
             auto slot = [&](int s_, int i_) {            // the DMA that belongs to MFMA group (k-half s_, row i_)
-                if (s_ == 0 && i_ == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 0>());
-                if (s_ == 0 && i_ == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 1>());
-                if (s_ == 0 && i_ == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 2>());
-                if (s_ == 0 && i_ == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 6>());
-                if (s_ == 1 && i_ == 0) issue_one(u + 2, pair_c, std::integral_constant<int, 3>());
-                if (s_ == 1 && i_ == 1) issue_one(u + 2, pair_c, std::integral_constant<int, 4>());
-                if (s_ == 1 && i_ == 2) issue_one(u + 2, pair_c, std::integral_constant<int, 5>());
-                if (s_ == 1 && i_ == 3) issue_one(u + 2, pair_c, std::integral_constant<int, 7>());
+                if (s_ == 0 && i_ == 0) issue_one(u + LA, la_c, std::integral_constant<int, 0>());
+                if (s_ == 0 && i_ == 1) issue_one(u + LA, la_c, std::integral_constant<int, 1>());
+                if (s_ == 0 && i_ == 2) issue_one(u + LA, la_c, std::integral_constant<int, 2>());
+                if (s_ == 0 && i_ == 3) issue_one(u + LA, la_c, std::integral_constant<int, 6>());
+                if (s_ == 1 && i_ == 0) issue_one(u + LA, la_c, std::integral_constant<int, 3>());
+                if (s_ == 1 && i_ == 1) issue_one(u + LA, la_c, std::integral_constant<int, 4>());
+                if (s_ == 1 && i_ == 2) issue_one(u + LA, la_c, std::integral_constant<int, 5>());
+                if (s_ == 1 && i_ == 3) issue_one(u + LA, la_c, std::integral_constant<int, 7>());
             };
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -247,9 +251,9 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         V2_STAMP(4);                                     // [3->4] 16 ds_read_b128 + 32 MFMA
     };
     if (DUAL) {
-        for (int u = 0; u < U; u += 2) { step(u, c0, acc1); step(u + 1, c1, acc2); }
+        for (int u = 0; u < U; u += 2) { step(u, c0, c1, acc1); step(u + 1, c1, c0, acc2); }
     } else {
-        for (int u = 0; u < U; ++u) step(u, c0, acc1);
+        for (int u = 0; u < U; ++u) step(u, c0, c0, acc1);
     }
     V2_STAMP_FLUSH
 
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     typedef typename Epi::elem_t ET;
     constexpr int SP = 68;                                    // fp32 staging pitch (floats): conflict-free b128 rows
     constexpr int TP = 72;                                    // transposed staging pitch (elements), 16-byte multiple
-    static_assert(NW * 18432 <= v2_lds(WM), "epilogue staging must fit the ring");
+    static_assert(NW * 18432 <= v2_lds(WM, ST), "epilogue staging must fit the allocation");
     __syncthreads();                                          // every wave is done reading the last tile
     float* st = reinterpret_cast<float*>(lds + wave * 18432);
     const int c16 = lane & 15, q4 = lane >> 4;
@@ -361,24 +365,33 @@ static int launch_gemm_v2(hipStream_t stream, const T* A, const T* A2, int64_t l
         // 256 x 128 tiles unless they would leave more than a quarter of the 256 CUs without a block while the
         // 128 x 128 tiling fills more of them (the 784 x 4096 gradient: 128 blocks vs 224)
         const int64_t t256 = v2_tiles(M, N, 256), t128 = v2_tiles(M, N, 128);
-        const bool small = g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256);
-        const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small ? 0 : 2);
+        // Variant kept behind the debug key only: 128 x 128 tiles with a 2-stage ring use 72 KiB of LDS, so TWO
+        // workgroups share a CU and one's epilogue runs beside the other's main loop. Meant for the K-short forward
+        // of layer 1 (26 tile steps, then an epilogue as long as the main loop); measured 113 us against 110 us for
+        // the 256 x 128 tile there (and 291 vs 257 us at K = 4096), so it is never picked automatically.
+        const bool pairs = g_v2_tile == 64;
+        const bool small = pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256);
+        const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small && !pairs ? 0 : 2);
+        const int vi = pairs ? 2 : small ? 1 : 0;        // variant: 256 x 128 / 128 x 128 / 128 x 128 co-resident
         const int si = sched >> 1;                       // 0, 1, 2
         const void* kern;
         int threads, lds_bytes, bm;
-        if (small) {                                     // four waves: no SIMD partner to skew against
-            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 2, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 2, Epi>;
-            threads = 256; lds_bytes = v2_lds(2); bm = 128;
+        if (pairs) {
+            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 2, 2, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 2, 2, Epi>;
+            threads = 256; lds_bytes = v2_lds(2, 2); bm = 128;
+        } else if (small) {                              // four waves, one workgroup per CU: no SIMD partner
+            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 2, 3, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 2, 3, Epi>;
+            threads = 256; lds_bytes = v2_lds(2, 3); bm = 128;
         } else {
-            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 4, Epi>
-                 : sched == 2 ? (const void*)gemm_nt_v2<DUAL, 2, 4, Epi> : (const void*)gemm_nt_v2<DUAL, 4, 4, Epi>;
-            threads = 512; lds_bytes = v2_lds(4); bm = 256;
+            kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 4, 3, Epi>
+                 : sched == 2 ? (const void*)gemm_nt_v2<DUAL, 2, 4, 3, Epi> : (const void*)gemm_nt_v2<DUAL, 4, 4, 3, Epi>;
+            threads = 512; lds_bytes = v2_lds(4, 3); bm = 256;
         }
-        static bool configured[2][3] = {{false, false, false}, {false, false, false}};      // per instantiation of this launcher
-        if (!configured[small][si]) {
+        static bool configured[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};   // per instantiation
+        if (!configured[vi][si]) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
-            configured[small][si] = true;
+            configured[vi][si] = true;
         }
         const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + V2_BN - 1) / V2_BN;
         const bf16_t* a = (const bf16_t*)A; const bf16_t* a2 = (const bf16_t*)A2;
