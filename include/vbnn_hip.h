@@ -245,13 +245,16 @@ int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const in
 int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
                       float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev);
-/* Backward of the same head: gradWeight (C x H) / gradBias (C) of the final Linear (accumulate as in
- * vbnn_acc_grad_parameters; NULL to skip), and its gradInput pushed through the ReLU straight into the last
- * VB layer's packed gradient operands (same meaning as the hand-off fields of vbnn_dx_args). */
+/* Backward of the same head in one pass over h: gradWeight (C x H) / gradBias (C) of the final Linear (accumulate
+ * as in vbnn_acc_grad_parameters; NULL to skip), its gradInput pushed through the ReLU straight into the last VB
+ * layer's packed gradient operands (same meaning as the hand-off fields of vbnn_dx_args), and optionally
+ * gradBias_prev (H, f32): the column sums of g_prev as stored, i.e. what vbnn_acc_grad_bias(g_prev, scale 1) would
+ * give -- the bias gradient of that VB layer (VBLinear.lua:112-113, parent.accGradParameters); NULL to skip. */
 int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                        const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
-                       float* gradBias, int relu_mask, const void* r_prev, int64_t ld_r_prev, int r_prev_packed,
-                       void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT);
+                       float* gradBias, float* gradBias_prev, int relu_mask, const void* r_prev, int64_t ld_r_prev,
+                       int r_prev_packed, void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev,
+                       int64_t ld_gpT);
 
 /* The same criterion as separate modules, for the module-level call order of mlp.lua:77-80:
  * nn.LogSoftMax:updateOutput is vbnn_logsoftmax_nll with g_logits = loss = correct = NULL. */

@@ -109,8 +109,9 @@ int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, con
                       float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev);
 int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                        const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
-                       float* gradBias, int relu_mask, const void* r_prev, int64_t ld_r_prev, int r_prev_packed,
-                       void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT);
+                       float* gradBias, float* gradBias_prev, int relu_mask, const void* r_prev, int64_t ld_r_prev,
+                       int r_prev_packed, void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev,
+                       int64_t ld_gpT);
 int vbnn_nll_forward(vbnn_ctx* ctx, const float* out, int64_t ld, const int32_t* target, int64_t N, int64_t C,
                      float inv_n, double* loss_sum_dev, int32_t* correct_dev);
 int vbnn_nll_backward(vbnn_ctx* ctx, const int32_t* target, int64_t N, int64_t C, float inv_n, float* g);

@@ -5,10 +5,10 @@
 // configuration), not GEMM-shaped work for 256 x 128 tiles:
 //   forward   16 rows per workgroup, K split over its 4 waves, one 16x16 MFMA column of logits per wave,
 //             partials folded through LDS, log-softmax / loss / arg-max / d(loss)/d(logits) in registers
-//   dW        each thread owns 8 consecutive hidden units and C accumulators each, g rows broadcast
-//             from LDS; deterministic two-stage reduction over row chunks (no float atomics)
-//   dX        64 x 64 tiles, 16-byte loads/stores, the two transposed operand copies written through an
-//             LDS transpose so every global access is a full 16-byte-per-lane segment
+//   backward  ONE pass over h and r: 64 x 64 tiles, 16-byte loads/stores; the gradInput (through the ReLU, times r)
+//             and its transposed copies via an LDS tile; gradWeight and the bias gradient of the layer below as
+//             16x16 MFMA tiles contracted over the minibatch rows of that same LDS tile; row-chunk partials summed
+//             in a fixed order by a finish kernel (no float atomics)
 #include "common.h"
 #include "gemm_v1.h"      // Frag<T>, mfma_step<T>
 
@@ -16,6 +16,18 @@ constexpr int HEAD_CMAX = 16;
 
 template <typename T> struct Vec8;             // eight consecutive packed elements
 template <> struct Vec8<bf16_t> {
+    typedef bf16x8 raw_t;                                   // 16 bytes kept unconverted while loads are in flight
+    static __device__ __forceinline__ raw_t load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+    static __device__ __forceinline__ void cvt(const raw_t& t, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+    }
+    static __device__ __forceinline__ raw_t load_guarded(const bf16_t* p, int valid) {       // leading `valid` elements, 0 after
+        raw_t t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = e < valid ? p[e] : (bf16_t)0.f;
+        return t;
+    }
     static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
         const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -29,6 +41,20 @@ template <> struct Vec8<bf16_t> {
     }
 };
 template <> struct Vec8<float> {
+    struct raw_t { f32x4 a, b; };
+    static __device__ __forceinline__ raw_t load_raw(const float* p) {
+        return raw_t{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
+    }
+    static __device__ __forceinline__ void cvt(const raw_t& t, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = t.a[e]; v[4 + e] = t.b[e]; }
+    }
+    static __device__ __forceinline__ raw_t load_guarded(const float* p, int valid) {
+        raw_t t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t.a[e] = e < valid ? p[e] : 0.f; t.b[e] = e + 4 < valid ? p[e + 4] : 0.f; }
+        return t;
+    }
     static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
@@ -124,214 +150,221 @@ __global__ __launch_bounds__(256) void k_head_forward(const T* __restrict__ h, i
     }
 }
 
-// ------------------------------------------------------------------------------------------ dW / dbias
-// stage 1: grid (H / 512, R). Thread (cg = tid & 63, sub = tid >> 6) owns hidden units 8 cg .. 8 cg + 7 of the
-// block's 512 and the rows n = chunk0 + sub, sub + 4, ... ; the four row lanes are folded through LDS.
-template <typename T>
-__global__ __launch_bounds__(256) void k_head_dw_partial(const T* __restrict__ h, int64_t ld_h, const float* __restrict__ g,
-                                                         int64_t N, int64_t H, int C, int rows_per_chunk,
-                                                         float* __restrict__ partial /* [R][C][H] */,
-                                                         float* __restrict__ partial_b /* [R][C] */) {
-    extern __shared__ __attribute__((aligned(16))) float red[];          // [4][64][C * 8] reduction, then g staging in front
-    __shared__ float gs[128][HEAD_CMAX];
-    const int cg = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int64_t i0 = (int64_t)blockIdx.x * 512 + cg * 8;
-    const int64_t n0 = (int64_t)blockIdx.y * rows_per_chunk, n1 = min(N, n0 + rows_per_chunk);
-    float acc[HEAD_CMAX][8];
-#pragma unroll
-    for (int c = 0; c < HEAD_CMAX; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
-    float accb = 0.f;
-    const bool col_ok = i0 < H;                  // ld_h is padded: a chunk that starts in range is readable in full
-    for (int64_t nb = n0; nb < n1; nb += 128) {
-        const int rows = (int)min((int64_t)128, n1 - nb);
-        __syncthreads();
-        for (int k = threadIdx.x; k < rows * C; k += 256) {
-            const int rr = k / C, cc = k - rr * C;
-            gs[rr][cc] = Elt<T>::from(Elt<T>::to(g[(nb + rr) * C + cc]));    // the operand rounding of the packed GEMM path
-        }
-        __syncthreads();
-        if (col_ok) {
-            // four rows in flight per thread: the loop is latency-bound otherwise (4 waves per CU, one 16-byte
-            // load per 80 FMAs)
-            for (int rr = sub; rr < rows; rr += 16) {
-                float hv[4][8];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r_ = min(rr + 4 * u, rows - 1);
-                    Vec8<T>::load(h + (nb + r_) * ld_h + i0, hv[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (rr + 4 * u < rows) {
-#pragma unroll
-                        for (int c = 0; c < HEAD_CMAX; ++c)
-                            if (c < C) {
-                                const float gv = gs[rr + 4 * u][c];
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) acc[c][e] = fmaf(gv, hv[u][e], acc[c][e]);
-                            }
-                    }
-                }
-            }
-        }
-        // bias gradient (column sums of the UNROUNDED g): 16 row lanes per class, folded at the end in a fixed order.
-        // (A single thread per class walking the rows is a 128-deep chain of dependent-latency loads.)
-        if (blockIdx.x == 0 && (threadIdx.x & 15) < C)
-            for (int rr = threadIdx.x >> 4; rr < rows; rr += 16) accb += g[(nb + rr) * C + (threadIdx.x & 15)];
-    }
-    // fold the four row lanes: red[sub][cg][c * 8 + e]
-    const int stride = C * 8;
-#pragma unroll
-    for (int c = 0; c < HEAD_CMAX; ++c)
-        if (c < C) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[(sub * 64 + cg) * stride + c * 8 + e] = acc[c][e];
-        }
-    __syncthreads();
-    for (int k = threadIdx.x; k < 64 * stride; k += 256) {
-        const int g_ = k / stride, rem = k - g_ * stride;
-        const int c = rem >> 3, e = rem & 7;
-        const int64_t i = (int64_t)blockIdx.x * 512 + g_ * 8 + e;
-        if (i < H) {
-            const float tot = (red[(0 * 64 + g_) * stride + rem] + red[(1 * 64 + g_) * stride + rem]) +
-                              (red[(2 * 64 + g_) * stride + rem] + red[(3 * 64 + g_) * stride + rem]);
-            partial[((int64_t)blockIdx.y * C + c) * H + i] = tot;
-        }
-    }
-    if (blockIdx.x == 0) {
-        __syncthreads();                                   // `red` is free again
-        red[threadIdx.x] = accb;                           // [16 row lanes][16 classes]
-        __syncthreads();
-        if (threadIdx.x < C) {
-            float tot = 0.f;
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) tot += red[rg * 16 + threadIdx.x];
-            partial_b[(int64_t)blockIdx.y * C + threadIdx.x] = tot;
-        }
-    }
-}
-__global__ __launch_bounds__(256) void k_head_dw_finish(const float* __restrict__ partial, const float* __restrict__ partial_b, int R,
-                                                        int64_t H, int C, int accumulate, float* gradWeight, float* gradBias) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over C * H
-    if (k < (int64_t)C * H) {
-        float tot = 0.f;
-        int r = 0;
-        for (; r + 8 <= R; r += 8) {                  // eight independent loads in flight, summed in chunk order
-            float p[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = partial[(int64_t)(r + u) * C * H + k];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) tot += p[u];
-        }
-        for (; r < R; ++r) tot += partial[(int64_t)r * C * H + k];
-        gradWeight[k] = (accumulate ? gradWeight[k] : 0.f) + tot;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < C && gradBias) {
-        float tot = 0.f;
-        for (int r = 0; r < R; ++r) tot += partial_b[r * C + threadIdx.x];
-        gradBias[threadIdx.x] = (accumulate ? gradBias[threadIdx.x] : 0.f) + tot;
+// ------------------------------------------------------------------------------------------ backward
+// ONE pass over h and r for everything the head's backward produces:
+//   gx[n][i]         = sum_c g[n][c] w3[c][i];  g_prev = gx . [h > 0];  gv_prev = g_prev . r   (+ transposed copies)
+//   gradWeight[c][i] = sum_n g[n][c] h[n][i]          MFMA: M = class, N = hidden unit, K = minibatch row
+//   gradBias_prev[i] = sum_n g_prev[n][i]             the same MFMA shape with a row of ones as the A operand
+//   gradBias[c]      = sum_n g[n][c]
+// grid (H / 64, R): a block owns 64 hidden units and walks the 64-row tiles of its row chunk; thread
+// (row = tid >> 3 (+32), chunk = tid & 7) handles 8 consecutive hidden units of a row (16-byte loads / stores, the
+// next tile's loads in flight while this one is worked on). The tile of h, g_prev and gv_prev is kept in LDS in the
+// operand type: the transposed copies are read back from it as rows of n, the MFMA B fragments as columns. The sums
+// over rows leave as R partials per output; k_head_backward_finish adds them in chunk order (no float atomics).
+template <typename T> struct HeadRaw {          // one thread's 8 hidden units of h and of r, as loaded
+    typename Vec8<T>::raw_t h, rt;
+    typename Vec8<float>::raw_t rf;
+};
+template <typename T, bool VEC>
+__device__ __forceinline__ void head_load(HeadRaw<T>& o, const T* __restrict__ h, int64_t ld_h, const float* __restrict__ r_prev,
+                                          const T* __restrict__ r_prev_t, int64_t ld_r, int64_t n, int64_t n_hi, int64_t i, int64_t H) {
+    const int valid = (n < n_hi && i < H) ? (int)min((int64_t)8, H - i) : 0;
+    if (VEC && valid == 8) {
+        o.h = Vec8<T>::load_raw(h + n * ld_h + i);
+        if (r_prev_t) o.rt = Vec8<T>::load_raw(r_prev_t + n * ld_r + i);
+        if (r_prev) o.rf = Vec8<float>::load_raw(r_prev + n * ld_r + i);
+    } else {
+        o.h = Vec8<T>::load_guarded(h + n * ld_h + i, valid);
+        if (r_prev_t) o.rt = Vec8<T>::load_guarded(r_prev_t + n * ld_r + i, valid);
+        if (r_prev) o.rf = Vec8<float>::load_guarded(r_prev + n * ld_r + i, valid);
     }
 }
 
-// ------------------------------------------------------------------------------------------ dX
-//   gx[n][i] = sum_c g[n][c] w3[c][i];  g_prev = gx . [h > 0];  gv_prev = g_prev . r
-// 64 x 64 tile per block; thread (row = tid >> 3 (+32), chunk = tid & 7) handles 8 consecutive hidden units.
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void k_head_dx(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
-                                                 const float* __restrict__ g, int64_t N, int64_t H, int C, int relu_mask,
-                                                 const float* __restrict__ r_prev, const T* __restrict__ r_prev_t, int64_t ld_r,
-                                                 T* g_prev, T* gv_prev, int64_t ld_gp, T* gT_prev, T* gvT_prev, int64_t ld_gpT) {
-    __shared__ float tg[64][65];
-    __shared__ float tv[64][65];
-    __shared__ float gs[64][HEAD_CMAX];
+__global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
+                                                       const float* __restrict__ g, int64_t N, int64_t H, int C, int relu_mask,
+                                                       const float* __restrict__ r_prev, const T* __restrict__ r_prev_t, int64_t ld_r,
+                                                       T* g_prev, T* gv_prev, int64_t ld_gp, T* gT_prev, T* gvT_prev, int64_t ld_gpT,
+                                                       int rows_per_chunk, float* __restrict__ partial_w /* [R][C][H] */,
+                                                       float* __restrict__ partial_b /* [R][C] */,
+                                                       float* __restrict__ partial_bp /* [R][H] */) {
+    constexpr int CE = 16 / (int)sizeof(T);      // K elements per lane of an MFMA fragment
+    constexpr int KE = 4 * CE;                   // rows contracted per mfma_step
+    constexpr int TP = sizeof(T) == 2 ? 66 : 65;  // tile pitch, 33 / 65 dwords: rows 8 apart fall on different banks
+    typedef typename Frag<T>::type frag_t;
+    __shared__ __attribute__((aligned(16))) T th[64][TP];      // h tile
+    __shared__ __attribute__((aligned(16))) T tg[64][TP];      // g_prev tile, as stored
+    __shared__ __attribute__((aligned(16))) T tv[64][TP];      // gv_prev tile
+    __shared__ float gs[2][64][HEAD_CMAX + 1];                 // d(loss)/d(logits) rows of the tile, operand-rounded
     __shared__ __attribute__((aligned(16))) float ws[HEAD_CMAX][64];
-    const int64_t tiles_c = (H + 63) / 64;
-    const int64_t r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64;
-    for (int k = threadIdx.x; k < 64 * C; k += 256) {
-        const int rr = k / C, cc = k - rr * C;
-        gs[rr][cc] = (r0 + rr < N) ? Elt<T>::from(Elt<T>::to(g[(r0 + rr) * C + cc])) : 0.f;
-        const int wc = k / 64, wi = k - wc * 64;
-        ws[wc][wi] = (c0 + wi < H) ? Elt<T>::from(w3[(int64_t)wc * ld_w + c0 + wi]) : 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = tid & 7, c16 = lane & 15, q = lane >> 4;
+    const int64_t c0 = (int64_t)blockIdx.x * 64;
+    const int64_t n_lo = (int64_t)blockIdx.y * rows_per_chunk, n_hi = min(N, n_lo + rows_per_chunk);
+    const int64_t i8 = c0 + ch * 8;
+    for (int k = tid; k < HEAD_CMAX * 64; k += 256) {
+        const int wc = k >> 6, wi = k & 63;
+        ws[wc][wi] = (wc < C && c0 + wi < H) ? Elt<T>::from(w3[(int64_t)wc * ld_w + c0 + wi]) : 0.f;
     }
-    __syncthreads();
-    const int ch = threadIdx.x & 7;
+    const bool has_r = r_prev || r_prev_t;
+    f32x4 accw = {0.f, 0.f, 0.f, 0.f}, accp = {0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    frag_t ones;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int rr = (threadIdx.x >> 3) + 32 * p;
-        const int64_t n = r0 + rr, i = c0 + ch * 8;
-        float gp[8], gvp[8];
+    for (int e = 0; e < CE; ++e) ones[e] = Elt<T>::to(c16 == 0 ? 1.f : 0.f);
+    HeadRaw<T> cur[2] = {}, nxt[2] = {};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gp[e] = 0.f; gvp[e] = 0.f; }
-        if (n < N && i < H) {
-            float gx[8];
+    for (int p = 0; p < 2; ++p) head_load<T, VEC>(cur[p], h, ld_h, r_prev, r_prev_t, ld_r, n_lo + (tid >> 3) + 32 * p, n_hi, i8, H);
+    int buf = 0;
+    for (int64_t r0 = n_lo; r0 < n_hi; r0 += 64, buf ^= 1) {
+        for (int k = tid; k < 64 * HEAD_CMAX; k += 256) {
+            const int rr = k >> 4, cc = k & 15;
+            gs[buf][rr][cc] = (cc < C && r0 + rr < n_hi) ? Elt<T>::from(Elt<T>::to(g[(r0 + rr) * C + cc])) : 0.f;
+        }
+        const bool more = r0 + 64 < n_hi;                   // block-uniform
+        if (more) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gx[e] = 0.f;
+            for (int p = 0; p < 2; ++p)
+                head_load<T, VEC>(nxt[p], h, ld_h, r_prev, r_prev_t, ld_r, r0 + 64 + (tid >> 3) + 32 * p, n_hi, i8, H);
+        }
+        __syncthreads();         // gs[buf] (and ws) visible; every read of the previous tile's th / tg / tv is done
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int rr = (tid >> 3) + 32 * p;
+            const int64_t n = r0 + rr;
+            float hv[8], rv[8], gx[8], gp[8], gvp[8];
+            Vec8<T>::cvt(cur[p].h, hv);                      // out-of-range elements were loaded as 0
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gx[e] = 0.f; rv[e] = 0.f; }
+            if (r_prev_t) Vec8<T>::cvt(cur[p].rt, rv);
+            if (r_prev) Vec8<float>::cvt(cur[p].rf, rv);
 #pragma unroll
             for (int c = 0; c < HEAD_CMAX; ++c)
                 if (c < C) {
-                    const float gv = gs[rr][c];
+                    const float gv = gs[buf][rr][c];        // 0 for rows past the chunk
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gx[e] = fmaf(gv, ws[c][ch * 8 + e], gx[e]);
+                    for (int e = 0; e < 8; ++e) gx[e] = fmaf(gv, ws[c][ch * 8 + e], gx[e]);     // ws is 0 past H
                 }
-            float hv[8], rv[8];
-            const bool full = VEC && (i + 8 <= H);
-            const bool has_r = r_prev || r_prev_t;
-            if (full) {
-                Vec8<T>::load(h + n * ld_h + i, hv);
-                if (r_prev) Vec8<float>::load(r_prev + n * ld_r + i, rv);
-                if (r_prev_t) Vec8<T>::load(r_prev_t + n * ld_r + i, rv);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    hv[e] = (i + e < H) ? Elt<T>::from(h[n * ld_h + i + e]) : 0.f;
-                    rv[e] = 0.f;
-                    if (r_prev && i + e < H) rv[e] = r_prev[n * ld_r + i + e];
-                    if (r_prev_t && i + e < H) rv[e] = Elt<T>::from(r_prev_t[n * ld_r + i + e]);
-                }
-            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 gp[e] = (relu_mask && !(hv[e] > 0.f)) ? 0.f : gx[e];
                 gvp[e] = has_r ? gp[e] * rv[e] : 0.f;
             }
-            if (full) {
-                if (g_prev) Vec8<T>::store(g_prev + n * ld_gp + i, gp);
-                if (gv_prev) Vec8<T>::store(gv_prev + n * ld_gp + i, gvp);
-            } else {
+            if (n < n_hi && i8 < H) {
+                if (VEC && i8 + 8 <= H) {
+                    if (g_prev) Vec8<T>::store(g_prev + n * ld_gp + i8, gp);
+                    if (gv_prev) Vec8<T>::store(gv_prev + n * ld_gp + i8, gvp);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (i + e < H) {
-                        if (g_prev) g_prev[n * ld_gp + i + e] = Elt<T>::to(gp[e]);
-                        if (gv_prev) gv_prev[n * ld_gp + i + e] = Elt<T>::to(gvp[e]);
-                    }
+                    for (int e = 0; e < 8; ++e)
+                        if (i8 + e < H) {
+                            if (g_prev) g_prev[n * ld_gp + i8 + e] = Elt<T>::to(gp[e]);
+                            if (gv_prev) gv_prev[n * ld_gp + i8 + e] = Elt<T>::to(gvp[e]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                th[rr][ch * 8 + e] = Elt<T>::to(hv[e]);
+                tg[rr][ch * 8 + e] = Elt<T>::to(gp[e]);
+                tv[rr][ch * 8 + e] = Elt<T>::to(gvp[e]);
             }
         }
+        __syncthreads();
+        if (gT_prev || gvT_prev) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { tg[rr][ch * 8 + e] = gp[e]; tv[rr][ch * 8 + e] = gvp[e]; }
-    }
-    if (!gT_prev && !gvT_prev) return;
-    __syncthreads();
+            for (int p = 0; p < 2; ++p) {
+                const int cc = (tid >> 3) + 32 * p;          // hidden unit inside the tile
+                const int64_t i = c0 + cc, n = r0 + ch * 8;
+                if (i >= H || n >= n_hi) continue;
+                float a[8], b[8];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int cc = (threadIdx.x >> 3) + 32 * p;              // hidden unit inside the tile
-        const int64_t i = c0 + cc, n = r0 + ch * 8;
-        if (i >= H || n >= N) continue;
-        float a[8], b[8];
+                for (int e = 0; e < 8; ++e) { a[e] = Elt<T>::from(tg[ch * 8 + e][cc]); b[e] = Elt<T>::from(tv[ch * 8 + e][cc]); }
+                if (VEC && n + 8 <= n_hi) {
+                    if (gT_prev) Vec8<T>::store(gT_prev + i * ld_gpT + n, a);
+                    if (gvT_prev) Vec8<T>::store(gvT_prev + i * ld_gpT + n, b);
+                } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a[e] = tg[ch * 8 + e][cc]; b[e] = tv[ch * 8 + e][cc]; }
-        if (VEC && n + 8 <= N) {
-            if (gT_prev) Vec8<T>::store(gT_prev + i * ld_gpT + n, a);
-            if (gvT_prev) Vec8<T>::store(gvT_prev + i * ld_gpT + n, b);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (n + e < N) {
-                    if (gT_prev) gT_prev[i * ld_gpT + n + e] = Elt<T>::to(a[e]);
-                    if (gvT_prev) gvT_prev[i * ld_gpT + n + e] = Elt<T>::to(b[e]);
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < n_hi) {
+                            if (gT_prev) gT_prev[i * ld_gpT + n + e] = Elt<T>::to(a[e]);
+                            if (gvT_prev) gvT_prev[i * ld_gpT + n + e] = Elt<T>::to(b[e]);
+                        }
                 }
+            }
         }
+        if (partial_w) {                                     // wave w: hidden units 16 w .. 16 w + 15 of the tile
+#pragma unroll
+            for (int s = 0; s < 64 / KE; ++s) {
+                frag_t a, b, b1;
+#pragma unroll
+                for (int e = 0; e < CE; ++e) {
+                    const int k = s * KE + q * CE + e;
+                    a[e] = Elt<T>::to(gs[buf][k][c16]);
+                    b[e] = th[k][16 * wave + c16];
+                    b1[e] = tg[k][16 * wave + c16];
+                }
+                accw = mfma_step<T>(a, b, accw);
+                if (partial_bp) accp = mfma_step<T>(ones, b1, accp);
+            }
+        }
+        if (partial_b && blockIdx.x == 0 && c16 < C) {        // 16 row lanes per class, UNROUNDED g
+            const int rows = (int)min((int64_t)64, n_hi - r0);
+            for (int rr = tid >> 4; rr < rows; rr += 16) accb += g[(r0 + rr) * C + c16];
+        }
+        if (more) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
+    }
+    if (partial_w) {                                         // lane (q, c16): classes 4q .. 4q+3 of hidden unit 16 w + c16
+        const int64_t i = c0 + 16 * wave + c16;
+        if (i < H) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j < C) partial_w[((int64_t)blockIdx.y * C + 4 * q + j) * H + i] = accw[j];
+            if (partial_bp && q == 0) partial_bp[(int64_t)blockIdx.y * H + i] = accp[0];
+        }
+    }
+    if (partial_b && blockIdx.x == 0) {
+        __syncthreads();                                     // the tiles are free
+        float* red = reinterpret_cast<float*>(&th[0][0]);    // [16 row lanes][16 classes]
+        red[tid] = accb;
+        __syncthreads();
+        if (tid < C) {
+            float tot = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) tot += red[rg * 16 + tid];
+            partial_b[(int64_t)blockIdx.y * C + tid] = tot;
+        }
+    }
+}
+
+// stage 2: k over C * H (gradWeight) followed by H (gradBias_prev); chunk partials added in chunk order
+__global__ __launch_bounds__(256) void k_head_backward_finish(const float* __restrict__ partial_w, const float* __restrict__ partial_b,
+                                                              const float* __restrict__ partial_bp, int R, int64_t H, int C,
+                                                              int accumulate, float* gradWeight, float* gradBias,
+                                                              float* gradBias_prev) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nw = (int64_t)C * H;
+    const bool is_w = k < nw;
+    if ((is_w && gradWeight) || (!is_w && gradBias_prev && k < nw + H)) {
+        const float* src = is_w ? partial_w + k : partial_bp + (k - nw);
+        const int64_t stride = is_w ? nw : H;
+        float tot = 0.f;
+        int r = 0;
+        for (; r + 8 <= R; r += 8) {                  // eight independent loads in flight, summed in chunk order
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = src[(int64_t)(r + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tot += p[u];
+        }
+        for (; r < R; ++r) tot += src[(int64_t)r * stride];
+        float* dst = is_w ? gradWeight + k : gradBias_prev + (k - nw);
+        *dst = (accumulate ? *dst : 0.f) + tot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < C && gradBias) {
+        float tot = 0.f;
+        for (int r = 0; r < R; ++r) tot += partial_b[r * C + threadIdx.x];
+        gradBias[threadIdx.x] = (accumulate ? gradBias[threadIdx.x] : 0.f) + tot;
     }
 }
 
@@ -361,54 +394,58 @@ extern "C" int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_
 
 template <typename T>
 static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3, int64_t ld_w, const float* g_logits, int64_t N,
-                           int64_t H, int64_t C, int accumulate, float* gradWeight, float* gradBias, int relu_mask,
-                           const void* r_prev_any, int64_t ld_r_prev, int r_prev_packed, T* g_prev, T* gv_prev, int64_t ld_gp,
-                           T* gT_prev, T* gvT_prev, int64_t ld_gpT) {
+                           int64_t H, int64_t C, int accumulate, float* gradWeight, float* gradBias, float* gradBias_prev,
+                           int relu_mask, const void* r_prev_any, int64_t ld_r_prev, int r_prev_packed, T* g_prev, T* gv_prev,
+                           int64_t ld_gp, T* gT_prev, T* gvT_prev, int64_t ld_gpT) {
     const float* r_prev = r_prev_packed ? nullptr : (const float*)r_prev_any;
     const T* r_prev_t = r_prev_packed ? (const T*)r_prev_any : nullptr;
-    if (gradWeight) {
-        const int64_t cap = (int64_t)(ctx->scratch_doubles * 2) / (C * H + C);
-        VBNN_REQUIRE(cap >= 1, "hidden size too large for the reduction scratch");
-        int64_t R = (N + 127) / 128;
-        if (R > 32) R = 32;
-        if (R > cap) R = cap;
-        const int rows_per_chunk = (int)((N + R - 1) / R);
-        R = (N + rows_per_chunk - 1) / rows_per_chunk;
-        float* partial = reinterpret_cast<float*>(ctx->scratch);
-        float* partial_b = partial + R * C * H;
-        const dim3 grid((unsigned)((H + 511) / 512), (unsigned)R);
-        const size_t red_bytes = (size_t)4 * 64 * C * 8 * sizeof(float);
-        auto kern = k_head_dw_partial<T>;
-        static bool configured = false;
-        if (!configured) {
-            VBNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * HEAD_CMAX * 8 * 4));
-            configured = true;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(256), red_bytes, ctx->stream, h, ld_h, g_logits, N, H, (int)C, rows_per_chunk, partial,
-                           partial_b);
-        hipLaunchKernelGGL(k_head_dw_finish, dim3((unsigned)((C * H + 255) / 256)), dim3(256), 0, ctx->stream, partial, partial_b,
-                           (int)R, H, (int)C, accumulate, gradWeight, gradBias);
-    }
-    if (g_prev || gT_prev) {
-        const unsigned nb = (unsigned)(((N + 63) / 64) * ((H + 63) / 64));
-        const bool vec = (ld_h % 8 == 0) && (!r_prev_any || ld_r_prev % 8 == 0) && (!g_prev || ld_gp % 8 == 0) &&
-                         (!(gT_prev || gvT_prev) || ld_gpT % 8 == 0) &&
-                         ((((uintptr_t)h | (uintptr_t)r_prev_any | (uintptr_t)g_prev | (uintptr_t)gv_prev | (uintptr_t)gT_prev |
-                            (uintptr_t)gvT_prev) & 15u) == 0);
-        if (vec)
-            hipLaunchKernelGGL((k_head_dx<T, true>), dim3(nb), dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
-                               relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT);
-        else
-            hipLaunchKernelGGL((k_head_dx<T, false>), dim3(nb), dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
-                               relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT);
+    const bool sums = gradWeight || gradBias || gradBias_prev;
+    if (!sums && !g_prev && !gT_prev) return VBNN_OK;
+    // row chunks: about 2048 blocks (several per CU, so one's loads sit beside another's LDS work), bounded by the
+    // reduction scratch: per chunk C x H + C + H partial sums
+    const int64_t tiles_c = (H + 63) / 64, tiles_r = (N + 63) / 64;
+    const int64_t per_chunk = C * H + C + H;
+    const int64_t cap = (int64_t)(ctx->scratch_doubles * 2) / per_chunk;
+    VBNN_REQUIRE(!sums || cap >= 1, "hidden size too large for the reduction scratch");
+    int64_t R = (2048 + tiles_c - 1) / tiles_c;
+    if (R > tiles_r) R = tiles_r;
+    if (sums && R > cap) R = cap;
+    if (R < 1) R = 1;
+    VBNN_REQUIRE(R <= 65535, "too many row chunks");
+    const int rows_per_chunk = (int)((tiles_r + R - 1) / R) * 64;
+    R = (N + rows_per_chunk - 1) / rows_per_chunk;
+    float* partial_w = reinterpret_cast<float*>(ctx->scratch);
+    float* partial_b = partial_w + R * C * H;
+    float* partial_bp = partial_b + R * C;
+    const bool vec = (ld_h % 8 == 0) && (!r_prev_any || ld_r_prev % 8 == 0) && (!g_prev || ld_gp % 8 == 0) &&
+                     (!(gT_prev || gvT_prev) || ld_gpT % 8 == 0) &&
+                     ((((uintptr_t)h | (uintptr_t)r_prev_any | (uintptr_t)g_prev | (uintptr_t)gv_prev | (uintptr_t)gT_prev |
+                        (uintptr_t)gvT_prev) & 15u) == 0);
+    const dim3 grid((unsigned)tiles_c, (unsigned)R);
+    float* pw = (gradWeight || gradBias_prev) ? partial_w : nullptr;
+    float* pb = gradBias ? partial_b : nullptr;
+    float* pbp = gradBias_prev ? partial_bp : nullptr;
+    if (vec)
+        hipLaunchKernelGGL((k_head_backward<T, true>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
+                           relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
+                           pw, pb, pbp);
+    else
+        hipLaunchKernelGGL((k_head_backward<T, false>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
+                           relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
+                           pw, pb, pbp);
+    if (sums) {
+        const int64_t outs = C * H + (gradBias_prev ? H : 0);
+        hipLaunchKernelGGL(k_head_backward_finish, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, ctx->stream, partial_w,
+                           partial_b, partial_bp, (int)R, H, (int)C, accumulate, gradWeight, gradBias, gradBias_prev);
     }
     return vbnn_check_launch("k_head_backward");
 }
 
 extern "C" int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                                   const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
-                                  float* gradBias, int relu_mask, const void* r_prev, int64_t ld_r_prev, int r_prev_packed,
-                                  void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev, int64_t ld_gpT) {
+                                  float* gradBias, float* gradBias_prev, int relu_mask, const void* r_prev, int64_t ld_r_prev,
+                                  int r_prev_packed, void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev,
+                                  int64_t ld_gpT) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && h && w3 && g_logits, "null argument");
     VBNN_REQUIRE(N > 0 && H > 0 && C > 0 && C <= HEAD_CMAX, "shape (C <= 16)");
@@ -418,11 +455,11 @@ extern "C" int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64
     VBNN_REQUIRE(!(gT_prev || gvT_prev) || ld_gpT >= N, "ld_gpT");
     if (dtype == VBNN_F32)
         return head_backward_t<float>(ctx, (const float*)h, ld_h, (const float*)w3, ld_w, g_logits, N, H, C, accumulate, gradWeight,
-                                      gradBias, relu_mask, r_prev, ld_r_prev, r_prev_packed, (float*)g_prev, (float*)gv_prev,
+                                      gradBias, gradBias_prev, relu_mask, r_prev, ld_r_prev, r_prev_packed, (float*)g_prev, (float*)gv_prev,
                                       ld_gp, (float*)gT_prev, (float*)gvT_prev, ld_gpT);
     if (dtype == VBNN_BF16)
         return head_backward_t<bf16_t>(ctx, (const bf16_t*)h, ld_h, (const bf16_t*)w3, ld_w, g_logits, N, H, C, accumulate,
-                                       gradWeight, gradBias, relu_mask, r_prev, ld_r_prev, r_prev_packed, (bf16_t*)g_prev,
+                                       gradWeight, gradBias, gradBias_prev, relu_mask, r_prev, ld_r_prev, r_prev_packed, (bf16_t*)g_prev,
                                        (bf16_t*)gv_prev, ld_gp, (bf16_t*)gT_prev, (bf16_t*)gvT_prev, ld_gpT);
     vbnn_set_error("unsupported dtype %d", dtype);
     return VBNN_ERR_UNSUPPORTED;

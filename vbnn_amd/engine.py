@@ -316,7 +316,8 @@ class FusedMLP:
                 L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
         H, Cn = self.sizes[-1], self.n_classes
         vl = self.vb[-1]
-        if Cn <= 16:
+        fused_head = Cn <= 16
+        if fused_head:
             # ---------------- fused classifier head (mlp.lua:29-32): streaming kernels, no 10-wide MFMA tiles
             L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
                                           _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
@@ -325,7 +326,8 @@ class FusedMLP:
                 return
             L.check(lib.vbnn_head_backward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
                                            _p(self.g_logits), N, H, Cn, accumulate, _p(self.gradWeight3),
-                                           _p(self.gradBias3), 1, _p(vl.r) if lrt else None, vl.O, 1, vl.g_s.ptr,
+                                           _p(self.gradBias3), _p(vl.gradBias), 1, _p(vl.r) if lrt else None, vl.O, 1,
+                                           vl.g_s.ptr,
                                            vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr,
                                            vl.gvT_s.ptr if lrt else None, vl.gT_s.ld))
             self._reduce(self.bucket3)
@@ -341,7 +343,8 @@ class FusedMLP:
                 d = self._dw_args(li, N, accumulate)
                 with self._probed("accGradParameters", li):
                     L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
-                L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
+                if not (fused_head and li == nl - 1):        # the fused head already summed the last layer's g columns
+                    L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
                 self._reduce(v.bucket)
                 if li > 0:
                     dx = self._dx_args(li, N)
@@ -356,7 +359,8 @@ class FusedMLP:
                 side.wait_event(ready)
                 d = self._dw_args(li, N, accumulate)
                 L.check(lib.vbnn_acc_grad_parameters(ctx2, code, C.byref(d)))
-                L.check(lib.vbnn_acc_grad_bias(ctx2, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
+                if not (fused_head and li == nl - 1):
+                    L.check(lib.vbnn_acc_grad_bias(ctx2, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
                 with torch.cuda.stream(side):
                     self._reduce(v.bucket)                   # RCCL orders itself after the side stream
                 if li > 0:
