@@ -240,11 +240,15 @@ int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const in
 
 /* mlp.lua:29-32 fused for a small class count (C <= 16): final nn.Linear + nn.LogSoftMax +
  * nn.ClassNLLCriterion as streaming kernels over the packed N x H activation `h` (dtype) and the packed
- * final weight `w3` (C x ld_w, dtype). Forward: logits = h w3^T + bias, out = logsoftmax, loss / accuracy
- * accumulated as in vbnn_logsoftmax_nll, g_logits = d(loss)/d(logits) (N x C f32). `logits`, `out` optional. */
+ * final weight `w3` (C x ld_w, dtype). Forward: logits = h w3^T + bias, out = logsoftmax,
+ * g_logits = d(loss)/d(logits) (N x C f32); `logits`, `out` optional. The loss (sum of -out[n][target] * inv_n) and
+ * the hit count are summed in a fixed order inside the launch (bitwise reproducible) and stored to loss_sum_dev[0]
+ * / correct_dev[0] when accumulate = 0, added to them when accumulate = 1 (the S draws of a minibatch,
+ * mlp.lua:76-84): no memset of the two accumulators is needed. */
 int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
-                      float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev);
+                      float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
+                      int32_t* correct_dev);
 /* Backward of the same head in one pass over h: gradWeight (C x H) / gradBias (C) of the final Linear (accumulate
  * as in vbnn_acc_grad_parameters; NULL to skip), its gradInput pushed through the ReLU straight into the last VB
  * layer's packed gradient operands (same meaning as the hand-off fields of vbnn_dx_args), and optionally

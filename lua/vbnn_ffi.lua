@@ -106,7 +106,8 @@ int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const in
                         double* loss_sum_dev, int32_t* correct_dev);
 int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
-                      float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev);
+                      float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
+                      int32_t* correct_dev);
 int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                        const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
                        float* gradBias, float* gradBias_prev, int relu_mask, const void* r_prev, int64_t ld_r_prev,

@@ -79,7 +79,7 @@ _SIGS = {
     "vbnn_relu_forward": ([_vp, _vp, _vp, _i64], _i),
     "vbnn_relu_backward": ([_vp, _vp, _vp, _vp, _i64], _i),
     "vbnn_logsoftmax_nll": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp], _i),
-    "vbnn_head_forward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _f, _vp, _vp, _vp, _vp, _vp], _i),
+    "vbnn_head_forward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _f, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "vbnn_head_backward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp,
                            _vp, _i64, _vp, _vp, _i64], _i),
     "vbnn_nll_forward": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp], _i),

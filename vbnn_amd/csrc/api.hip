@@ -32,9 +32,15 @@ extern "C" int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out) {
     c->device = device;
     c->own_stream = false;
     c->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
-    c->scratch_doubles = 1u << 20;       // 8 MiB: block partials of the reductions
+    c->scratch_doubles = 1u << 21;       // 16 MiB: block partials of the reductions
     hipError_t e = hipMalloc((void**)&c->scratch, c->scratch_doubles * sizeof(double));
     if (e != hipSuccess) { delete c; vbnn_set_error("hipMalloc(scratch): %s", hipGetErrorString(e)); return VBNN_ERR_NOMEM; }
+    e = hipMalloc((void**)&c->counters, VBNN_CNT_TOTAL * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(c->counters, 0, VBNN_CNT_TOTAL * sizeof(unsigned));
+    if (e != hipSuccess) {
+        (void)hipFree(c->scratch); if (c->counters) (void)hipFree(c->counters); delete c;
+        vbnn_set_error("hipMalloc(counters): %s", hipGetErrorString(e)); return VBNN_ERR_NOMEM;
+    }
     *out = c;
     return VBNN_OK;
     VBNN_API_END
@@ -46,6 +52,7 @@ extern "C" int vbnn_ctx_destroy(vbnn_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VBNN_OK;

@@ -18,7 +18,10 @@ struct vbnn_ctx {
     bool own_stream;
     double* scratch;       // device scratch for block partial sums (prior / KL reductions)
     size_t scratch_doubles;
+    unsigned* counters;    // arrival tickets of the in-launch second stages (vbnn_last_arriver); zero between launches
 };
+// ticket slots
+constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TOTAL = 64;
 
 void vbnn_set_error(const char* fmt, ...);
 
@@ -57,6 +60,50 @@ static inline int vbnn_check_launch(const char* what) {
     }
     return VBNN_OK;
 }
+
+// ---- in-launch second stage of a two-stage reduction ----------------------------------------
+// vbnn_last_arriver returns true in exactly ONE of the `n` workgroups that share `counter` -- the last to arrive --
+// once the partials every one of them stored with vbnn_store_wt before the call are readable by it; that workgroup
+// then adds the partials in a fixed order (deterministic, no float atomics, no second launch: a tiny kernel costs
+// ~4.5 us of an otherwise busy stream). The hand-off is cdna_hip_programming.md Guideline 16 R1 with a ticket in
+// place of the flag: payload stored WRITE-THROUGH (sc1: relaxed agent-scope atomic stores of 4 / 8 bytes), so no
+// release fence (an agent-scope release writes back the XCD's whole dirty L2: +40-50 us measured in kernels that
+// had just written tens of MB), every storing wave drains vmcnt, barrier, one lane takes a relaxed agent-scope
+// ticket; the workgroup whose ticket is n - 1 does ONE agent-scope acquire (drops this CU's L1), drains, barrier,
+// then loads. The ticket is left at zero for the next launch (vbnn_ctx_create zeroes the array; launches on a
+// context's stream do not overlap), and no partial is read anywhere in the launch before that acquire.
+// Measured (r01): worth it for the classifier head's forward (256 workgroups; also removes two memsets per step);
+// NOT for the streaming sweeps (prep_layer, column sums, head backward: 1.5-2 k workgroups) -- the per-workgroup
+// store drain and the last arriver's serial latency chain at the kernel's tail cost more than the ~4.6 us launch
+// of a separate finish kernel, so those keep their second launch.
+#ifdef __HIPCC__
+template <typename V> __device__ __forceinline__ void vbnn_store_wt(V* p, V v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void vbnn_store_wt2(float* p /* 8-byte aligned */, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename V> __device__ __forceinline__ V vbnn_load_wt(const V* p) {      // sc1 load: L2-served, never this CU's L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool vbnn_last_arriver(unsigned* counter, unsigned n, int* flag_lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == n - 1u) ? 1 : 0;
+        if (last) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // holds the barrier below until the invalidate is done
+        }
+        *flag_lds = last;
+    }
+    __syncthreads();
+    return *flag_lds != 0;
+}
+#endif
 
 // ---- element-type helpers ------------------------------------------------------------------
 template <typename T> struct Elt;

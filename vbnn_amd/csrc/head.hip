@@ -3,7 +3,7 @@
 //
 // With C = 10 these are skinny, HBM-bound passes over the N x H activation (33 MB at the wide
 // configuration), not GEMM-shaped work for 256 x 128 tiles:
-//   forward   16 rows per workgroup, K split over its 4 waves, one 16x16 MFMA column of logits per wave,
+//   forward   16 rows per workgroup, K split over its 8 waves, one 16x16 MFMA column of logits per wave,
 //             partials folded through LDS, log-softmax / loss / arg-max / d(loss)/d(logits) in registers
 //   backward  ONE pass over h and r: 64 x 64 tiles, 16-byte loads/stores; the gradInput (through the ReLU, times r)
 //             and its transposed copies via an LDS tile; gradWeight and the bias gradient of the layer below as
@@ -13,6 +13,7 @@
 #include "gemm_v1.h"      // Frag<T>, mfma_step<T>
 
 constexpr int HEAD_CMAX = 16;
+constexpr int HEAD_FW = 8;         // waves of a forward workgroup: the K range of its 16 rows is split over them
 
 template <typename T> struct Vec8;             // eight consecutive packed elements
 template <> struct Vec8<bf16_t> {
@@ -70,32 +71,46 @@ template <> struct Vec8<float> {
 // MFMA orientation: M = class (A operand = w3 rows, rows >= C clamped and ignored), N = minibatch row.
 // Accumulator layout: lane (q = l >> 4, c = l & 15) holds classes 4q .. 4q+3 of row n0 + c.
 template <typename T>
-__global__ __launch_bounds__(256) void k_head_forward(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
+__global__ __launch_bounds__(64 * HEAD_FW) void k_head_forward(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
                                                       const float* __restrict__ bias, const int32_t* __restrict__ target, int64_t N,
                                                       int64_t Hp /* H padded to the K step */, int C, float inv_n, float* out,
-                                                      float* g_logits, float* logits, double* loss_sum, int32_t* correct) {
+                                                      float* g_logits, float* logits, double* loss_sum, int32_t* correct,
+                                                      int accumulate, double* part_loss, int32_t* part_corr, unsigned* counter) {
     constexpr int KE = 64 / (int)sizeof(T);      // K elements per MFMA step (16 bytes per lane x 4 lane groups)
     constexpr int CE = 16 / (int)sizeof(T);
     typedef typename Frag<T>::type frag_t;
-    __shared__ f32x4 part[4][64];
+    __shared__ f32x4 part[HEAD_FW][64];
+    __shared__ double red_l[HEAD_FW];
+    __shared__ int red_c[HEAD_FW];
+    __shared__ int last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n0 = (int64_t)blockIdx.x * 16;
     const int q = lane >> 4, c16 = lane & 15;
     const T* hp = h + min(n0 + c16, N - 1) * ld_h + q * CE;
     const T* wp = w3 + (int64_t)min(c16, C - 1) * ld_w + q * CE;
     const int64_t ksteps = Hp / KE;
-    const int64_t k_lo = ksteps * wave / 4, k_hi = ksteps * (wave + 1) / 4;
+    const int64_t k_lo = ksteps * wave / HEAD_FW, k_hi = ksteps * (wave + 1) / HEAD_FW;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int64_t ks = k_lo;
-    for (; ks + 4 <= k_hi; ks += 4) {                 // four K steps of loads in flight (latency-bound otherwise)
-        frag_t a[4], b[4];
+    for (; ks + 8 <= k_hi; ks += 8) {                 // eight K steps of loads in flight (latency-bound otherwise)
+        frag_t a[8], b[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             a[u] = *reinterpret_cast<const frag_t*>(wp + (ks + u) * KE);
             b[u] = *reinterpret_cast<const frag_t*>(hp + (ks + u) * KE);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = mfma_step<T>(a[u], b[u], acc);
+        for (int u = 0; u < 8; ++u) acc = mfma_step<T>(a[u], b[u], acc);
+    }
+    for (; ks + 2 <= k_hi; ks += 2) {
+        frag_t a[2], b[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            a[u] = *reinterpret_cast<const frag_t*>(wp + (ks + u) * KE);
+            b[u] = *reinterpret_cast<const frag_t*>(hp + (ks + u) * KE);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc = mfma_step<T>(a[u], b[u], acc);
     }
     for (; ks < k_hi; ++ks) {
         const frag_t a = *reinterpret_cast<const frag_t*>(wp + ks * KE);
@@ -104,49 +119,67 @@ __global__ __launch_bounds__(256) void k_head_forward(const T* __restrict__ h, i
     }
     part[wave][lane] = acc;
     __syncthreads();
-    if (wave != 0) return;
-    const f32x4 s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    const int64_t n = n0 + c16;
-    const bool row_ok = n < N;
-    float lg[4];
-    float mx = -INFINITY; int arg = 0x7fffffff;
+    if (wave == 0) {
+        f32x4 s = part[0][lane];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = 4 * q + j;
-        lg[j] = (c < C) ? s[j] + (bias ? bias[c] : 0.f) : -INFINITY;
-        if (lg[j] > mx) { mx = lg[j]; arg = c; }
-    }
+        for (int w = 1; w < HEAD_FW; ++w) s += part[w][lane];
+        const int64_t n = n0 + c16;
+        const bool row_ok = n < N;
+        float lg[4];
+        float mx = -INFINITY; int arg = 0x7fffffff;
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {           // combine the four lanes (q = 0..3) of a row
-        const float om = __shfl_xor(mx, off, 64);
-        const int oa = __shfl_xor(arg, off, 64);
-        if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }     // first maximum wins (Tensor:max)
-    }
-    float se = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (4 * q + j < C) se += expf(lg[j] - mx);
-    se += __shfl_xor(se, 16, 64);
-    se += __shfl_xor(se, 32, 64);
-    const float lse = mx + logf(se);
-    const int t = row_ok ? min(max(target[n], 0), C - 1) : 0;
-    double loss_acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = 4 * q + j;
-        if (row_ok && c < C) {
-            const float o = lg[j] - lse;
-            if (logits) logits[n * C + c] = lg[j];
-            if (out) out[n * C + c] = o;
-            g_logits[n * C + c] = (expf(o) - (c == t ? 1.0f : 0.0f)) * inv_n;
-            if (c == t) loss_acc -= (double)o * (double)inv_n;
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            lg[j] = (c < C) ? s[j] + (bias ? bias[c] : 0.f) : -INFINITY;
+            if (lg[j] > mx) { mx = lg[j]; arg = c; }
         }
-    }
-    int corr = (row_ok && q == 0 && arg == t) ? 1 : 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { loss_acc += __shfl_xor(loss_acc, off, 64); corr += __shfl_xor(corr, off, 64); }
-    if (lane == 0) {
-        if (loss_sum) atomicAdd(loss_sum, loss_acc);
-        if (correct && corr) atomicAdd(correct, corr);
+        for (int off = 16; off <= 32; off <<= 1) {           // combine the four lanes (q = 0..3) of a row
+            const float om = __shfl_xor(mx, off, 64);
+            const int oa = __shfl_xor(arg, off, 64);
+            if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }     // first maximum wins (Tensor:max)
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * q + j < C) se += expf(lg[j] - mx);
+        se += __shfl_xor(se, 16, 64);
+        se += __shfl_xor(se, 32, 64);
+        const float lse = mx + logf(se);
+        const int t = row_ok ? min(max(target[n], 0), C - 1) : 0;
+        double loss_acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            if (row_ok && c < C) {
+                const float o = lg[j] - lse;
+                if (logits) logits[n * C + c] = lg[j];
+                if (out) out[n * C + c] = o;
+                g_logits[n * C + c] = (expf(o) - (c == t ? 1.0f : 0.0f)) * inv_n;
+                if (c == t) loss_acc -= (double)o * (double)inv_n;
+            }
+        }
+        int corr = (row_ok && q == 0 && arg == t) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { loss_acc += __shfl_xor(loss_acc, off, 64); corr += __shfl_xor(corr, off, 64); }
+        if (lane == 0) { vbnn_store_wt(&part_loss[blockIdx.x], loss_acc); vbnn_store_wt(&part_corr[blockIdx.x], (int32_t)corr); }
+    }
+    // ---- second stage: the last workgroup to arrive adds the per-workgroup loss / hit partials in a fixed order
+    // (bitwise reproducible loss; and with accumulate = 0 the caller needs no memset of the two accumulators)
+    if (!vbnn_last_arriver(counter, gridDim.x, &last)) return;
+    double ls = 0.0;
+    int cs = 0;
+    for (int b = (int)threadIdx.x; b < (int)gridDim.x; b += 64 * HEAD_FW) { ls += vbnn_load_wt(&part_loss[b]); cs += vbnn_load_wt(&part_corr[b]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ls += __shfl_xor(ls, off, 64); cs += __shfl_xor(cs, off, 64); }
+    if (lane == 0) { red_l[wave] = ls; red_c[wave] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double lt = 0.0;
+        int ct = 0;
+#pragma unroll
+        for (int w = 0; w < HEAD_FW; ++w) { lt += red_l[w]; ct += red_c[w]; }
+        if (loss_sum) loss_sum[0] = (accumulate ? loss_sum[0] : 0.0) + lt;
+        if (correct) correct[0] = (accumulate ? correct[0] : 0) + ct;
     }
 }
 
@@ -371,22 +404,28 @@ __global__ __launch_bounds__(256) void k_head_backward_finish(const float* __res
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                                  const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
-                                 float* logits, float* out, float* g_logits, double* loss_sum_dev, int32_t* correct_dev) {
+                                 float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
+                                 int32_t* correct_dev) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && h && w3 && target && g_logits, "null argument");
     VBNN_REQUIRE(N > 0 && H > 0 && C > 0 && C <= HEAD_CMAX, "shape (C <= 16)");
     VBNN_REQUIRE(ld_h % VBNN_KPAD == 0 && ld_w % VBNN_KPAD == 0 && ld_h >= H && ld_w >= H, "h and w3 must be packed operands");
     VBNN_REQUIRE((((uintptr_t)h | (uintptr_t)w3) & 15u) == 0, "operands must be 16-byte aligned");
     const unsigned nb = (unsigned)((N + 15) / 16);
+    VBNN_REQUIRE((size_t)nb * 2 <= ctx->scratch_doubles, "minibatch too large for the reduction scratch");
+    double* part_loss = ctx->scratch;                                       // [nb] doubles, then [nb] ints
+    int32_t* part_corr = reinterpret_cast<int32_t*>(ctx->scratch + nb);
+    unsigned* ticket = ctx->counters + VBNN_CNT_HEAD_FWD;
     if (dtype == VBNN_F32) {
         const int64_t Hp = (H + 15) / 16 * 16;
-        hipLaunchKernelGGL(k_head_forward<float>, dim3(nb), dim3(256), 0, ctx->stream, (const float*)h, ld_h, (const float*)w3,
-                           ld_w, bias, target, N, Hp, (int)C, inv_n, out, g_logits, logits, loss_sum_dev, correct_dev);
+        hipLaunchKernelGGL(k_head_forward<float>, dim3(nb), dim3(64 * HEAD_FW), 0, ctx->stream, (const float*)h, ld_h, (const float*)w3,
+                           ld_w, bias, target, N, Hp, (int)C, inv_n, out, g_logits, logits, loss_sum_dev, correct_dev, accumulate, part_loss,
+                           part_corr, ticket);
     } else if (dtype == VBNN_BF16) {
         const int64_t Hp = (H + 31) / 32 * 32;
-        hipLaunchKernelGGL(k_head_forward<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, (const bf16_t*)h, ld_h,
+        hipLaunchKernelGGL(k_head_forward<bf16_t>, dim3(nb), dim3(64 * HEAD_FW), 0, ctx->stream, (const bf16_t*)h, ld_h,
                            (const bf16_t*)w3, ld_w, bias, target, N, Hp, (int)C, inv_n, out, g_logits, logits, loss_sum_dev,
-                           correct_dev);
+                           correct_dev, accumulate, part_loss, part_corr, ticket);
     } else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
     return vbnn_check_launch("k_head_forward");
     VBNN_API_END

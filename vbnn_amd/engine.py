@@ -136,11 +136,10 @@ class FusedMLP:
         self.g3_s = _Packed(N, self.n_classes, tdt, dev)
         self.g3T_s = _Packed(self.n_classes, N, tdt, dev)
 
-    # ---- mlp.lua:62-67. Nothing is zeroed: the first accGradParameters of the minibatch overwrites.
+    # ---- mlp.lua:62-67. Nothing is zeroed: the first accGradParameters of the minibatch overwrites the gradients
+    # and the first criterion pass overwrites the loss / hit accumulators.
     def resetGradients(self):
         self._first = True
-        L.check(L.lib().vbnn_buf_zero(self.ctx.h, _p(self._acc), 16))
-        L.check(L.lib().vbnn_buf_zero(self.ctx.h, _p(self._corr), 4))
 
     # ---- once per minibatch, after the parameters changed: VBLinear:compute_prior (VBLinear.lua:77-88)
     # fused with the packing of the GEMM shadows.
@@ -203,8 +202,7 @@ class FusedMLP:
         draws = 1 if self.opt.get("quicktest") else int(self.opt["testSamples"])
         err = acc = 0.0
         for _ in range(draws):
-            L.check(L.lib().vbnn_buf_zero(self.ctx.h, _p(self._acc), 16))
-            L.check(L.lib().vbnn_buf_zero(self.ctx.h, _p(self._corr), 4))
+            self._first = True                      # this draw's criterion pass overwrites the accumulators
             if self.opt.get("quicktest"):
                 self.clamp_to_map()
             else:
@@ -236,6 +234,9 @@ class FusedMLP:
         a = L.FwdArgs(w=self.w3_s.ptr, w2=None, x=self.h_s.ptr, x2=None, ld_w=self.w3_s.ld, ld_x=self.h_s.ld,
                       N=N, I=H, O=Cn, bias=_p(self.bias3), y=_p(self.logits), ld_y=Cn)
         L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
+        if not accumulate:                          # vbnn_logsoftmax_nll adds into its accumulators
+            L.check(lib.vbnn_buf_zero(ctx, _p(self._acc), 16))
+            L.check(lib.vbnn_buf_zero(ctx, _p(self._corr), 4))
         L.check(lib.vbnn_logsoftmax_nll(ctx, _p(self.logits), Cn, _p(targets), N, Cn, inv_n, _p(self.out),
                                         _p(self.g_logits), _p(self._acc), _p(self._corr)))
         L.check(lib.vbnn_pack(ctx, code, L.PACK_COPY, _p(self.g_logits), None, Cn, N, Cn, self.g3_s.ptr, self.g3_s.ld,
@@ -321,8 +322,9 @@ class FusedMLP:
             # ---------------- fused classifier head (mlp.lua:29-32): streaming kernels, no 10-wide MFMA tiles
             L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
                                           _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
-                                          _p(self.g_logits), _p(self._acc), _p(self._corr)))
+                                          _p(self.g_logits), accumulate, _p(self._acc), _p(self._corr)))
             if not backward:
+                self._first = False
                 return
             L.check(lib.vbnn_head_backward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
                                            _p(self.g_logits), N, H, Cn, accumulate, _p(self.gradWeight3),
