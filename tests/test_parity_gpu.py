@@ -328,7 +328,8 @@ def test_engine_bf16_close_to_f32_oracle(oracle, nnmod, gemm_kernel, mode):
             assert rel_fro <= 0.15, f"layer {k} {what}: relative Frobenius error {rel_fro:.3e}"
 
 
-@pytest.mark.parametrize("hidden,I0,N", [([50, 34], 70, 37), ([400, 400], 784, 256), ([512, 384], 320, 640)])
+@pytest.mark.parametrize("hidden,I0,N", [([50, 34], 70, 37), ([400, 400], 784, 256), ([512, 384], 320, 640),
+                                         ([512, 256], 256, 512)])     # the last: whole 256 x 256 tiles (gemm_v3.h)
 @pytest.mark.parametrize("fuse_kl", [False, True])
 def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidden, I0, N, fuse_kl):
     """The bf16 fused step against float64 math that rounds to bf16 at exactly the engine's rounding points
@@ -361,11 +362,12 @@ def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidd
     close(eng.gradBias3, gb3, "final gradBias")
 
 
-@pytest.fixture(params=[(1, 0), (2, 256), (2, 128), (2, 64)],
-                ids=["general-kernel", "pipelined-256x128", "pipelined-128x128", "pipelined-128x128-pairs"])
+@pytest.fixture(params=[(1, 0), (2, 256), (2, 128), (2, 64), (3, 0)],
+                ids=["general-kernel", "pipelined-256x128", "pipelined-128x128", "pipelined-128x128-pairs",
+                     "two-pass-256x256"])
 def gemm_kernel(request, nnmod):
-    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in both block tiles), whatever the shape
-    heuristics say."""
+    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in its block tiles / gemm_v3.h), whatever the
+    shape heuristics say."""
     from vbnn_amd import _lib as L
     kernel, tile = request.param
     L.check(L.lib().vbnn_debug_set(0, kernel))
@@ -375,7 +377,8 @@ def gemm_kernel(request, nnmod):
     L.check(L.lib().vbnn_debug_set(2, 0))
 
 
-@pytest.mark.parametrize("N,I,O", [(1, 8, 8), (37, 70, 50), (300, 200, 260), (512, 448, 384), (200, 4096, 130)])
+@pytest.mark.parametrize("N,I,O", [(1, 8, 8), (37, 70, 50), (300, 200, 260), (512, 448, 384), (200, 4096, 130),
+                                   (512, 256, 768)])
 def test_bf16_gemm_exact_on_integers(nnmod, gemm_kernel, N, I, O):
     """Layout / race screen: small-integer operands are exact in bf16 and their sums exact in fp32, so
     y = x W^T + b, gradInput = g W and gradWeight = g^T x must equal the integer results EXACTLY, for both

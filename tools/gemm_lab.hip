@@ -12,6 +12,7 @@
 #include "../vbnn_amd/csrc/common.h"
 void vbnn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 #include "../vbnn_amd/csrc/gemm_v2.h"
+#include "../vbnn_amd/csrc/gemm_v3.h"
 
 struct EpiSum {          // keeps both accumulators live with one 16-byte store per four outputs
     typedef bf16_t elem_t;
@@ -83,6 +84,29 @@ int main(int argc, char** argv) {
 #endif
             printf("\n");
         }
+    {   // the two-pass 256 x 256 kernel (gemm_v3.h)
+        vbnn_ctx ctx{};
+        ctx.stream = st;
+        for (int dual = 0; dual < 2; ++dual) {
+            auto launch = [&] {
+                if (dual) launch_gemm_v3<bf16_t, true, EpiSum>(&ctx, A, A2, K, B, B2, K, M, N, K, epi);
+                else launch_gemm_v3<bf16_t, false, EpiSum>(&ctx, A, nullptr, K, B, nullptr, K, M, N, K, epi);
+            };
+            for (int i = 0; i < 3; ++i) launch();
+            CK(hipDeviceSynchronize());
+            std::vector<float> ts;
+            for (int r = 0; r < 5; ++r) {
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < 10; ++i) launch();
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / 10 * 1e3f);
+            }
+            std::sort(ts.begin(), ts.end());
+            const double fl = 2.0 * M * N * K * (dual ? 2 : 1);
+            printf("M=%d N=%d K=%d %s v3 (256x256%s): median %.1f us  %.0f TF\n", M, N, K, dual ? "dual  " : "single",
+                   dual ? ", two passes" : "", ts[2], fl / ts[2] / 1e6);
+        }
+    }
     return lab_half(M, N, K, A, A2, B, B2, out);
 }
 
@@ -120,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lab_half(const bf16_t* __restrict
         constexpr int P = decltype(pair_c)::value;
         constexpr int IDX = decltype(idx_c)::value;
         const int64_t koff = (int64_t)(u >> 1) * V2_BK;
-        unsigned char* base = lds + (u % V2_STAGES) * STAGE;
+        unsigned char* base = lds + (u % 3) * STAGE;
         if constexpr (IDX < 8)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (lw + 4 * IDX) * 1024), 16, 0, 0);
         else
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lab_half(const bf16_t* __restrict
         }
         __builtin_amdgcn_s_barrier();
         const bool more = loader && (u + 2 < U);
-        const unsigned char* stage = lds + (u % V2_STAGES) * STAGE;
+        const unsigned char* stage = lds + (u % 3) * STAGE;
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
             bf16x8 af[4], bf[4];

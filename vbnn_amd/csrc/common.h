@@ -18,6 +18,8 @@ struct vbnn_ctx {
     bool own_stream;
     double* scratch;       // device scratch for block partial sums (prior / KL reductions)
     size_t scratch_doubles;
+    float* park;           // gemm_v3's parking tiles (pass 1 of a GEMM pair), grown on demand
+    size_t park_bytes;
     unsigned* counters;    // arrival tickets of the in-launch second stages (vbnn_last_arriver); zero between launches
 };
 // ticket slots

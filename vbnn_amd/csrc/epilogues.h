@@ -13,8 +13,24 @@
 // (STORE_T = true: 2-byte stores, the general kernel) or handed back to the kernel, which transposes
 // them through LDS and writes whole rows (STORE_T = false: the pipelined kernel).
 // Four consecutive m are also exactly one Philox block (4 normals) of the RNG contract.
+//
+// The FAST protocol (gemm_v3.h): `apply` guards every access (ragged edges, optional outputs), and its loads sit in
+// lane-dependent control flow, so a kernel that calls it 8 or 16 times in a row pays the load latency 8 or 16
+// times in sequence. When fast_ok() holds (the fused bf16 configuration: vector-aligned operands, only the packed
+// outputs) and a tile lies fully inside the matrix, the kernel instead calls
+//     Lane ln = epi.lane_init(nl, ml)                once: the lane's position (n = un + nl, m = um + ml) as 32-bit
+//                                                    element offsets into each tensor it touches,
+//     Pre pre[k] = epi.load_fast(um, un_k, ln)       for a batch of FAST_BATCH positions -- unconditional vector loads,
+//     epi.apply_fast(um, un_k, ln, a1, a2, pre[k], t1, t2)                  all in flight before the first use.
+// (um, un) are WAVE-UNIFORM: every address is (scalar base) + (one per-lane 32-bit offset), so the global accesses
+// take the SGPR-base form and a whole unrolled tile needs a handful of address registers instead of a 64-bit pair per
+// access (which spilled). Same arithmetic, same stores.
 #pragma once
 #include "common.h"
+
+template <typename T> struct V4;                 // four consecutive elements as one register-resident vector
+template <> struct V4<float> { typedef f32x4 type; };
+template <> struct V4<bf16_t> { typedef bf16x4 type; };
 
 // ---- FWD: M = output units o, N = minibatch rows n ---------------------------------------------
 // WN/MAP: y = acc1 + b                      (inherited nn.Linear:updateOutput, VBLinear.lua:7)
@@ -32,9 +48,9 @@ struct EpiFwd {
     T* hT; T* h2T; int64_t ld_hT;
     int O, N;
 
-    __device__ __forceinline__ T* t1_ptr() const { return hT; }
-    __device__ __forceinline__ T* t2_ptr() const { return h2T; }
-    __device__ __forceinline__ int64_t t_ld() const { return ld_hT; }
+    __host__ __device__ __forceinline__ T* t1_ptr() const { return hT; }
+    __host__ __device__ __forceinline__ T* t2_ptr() const { return h2T; }
+    __host__ __device__ __forceinline__ int64_t t_ld() const { return ld_hT; }
     __device__ __forceinline__ int m_dim() const { return O; }
     __device__ __forceinline__ int n_dim() const { return N; }
 
@@ -94,6 +110,54 @@ struct EpiFwd {
         float t1[4], t2[4];
         apply<true>(m, n, a1, a2, t1, t2);
     }
+
+    // ---- fast protocol
+    static constexpr int FAST_BATCH = 8;
+    struct Pre { f32x4 b; };
+    struct Lane { int nl, ml; unsigned oh, orr; };
+    __host__ __device__ bool fast_ok() const {
+        return !y && !r && h && (ld_h % 4 == 0) && (!r_t || (r_vec && ld_r % 4 == 0)) &&
+               (!bias || (((uintptr_t)bias & 15u) == 0)) && (int64_t)N * ld_h < (1ll << 31) && (int64_t)N * ld_r < (1ll << 31);
+    }
+    __device__ __forceinline__ Lane lane_init(int nl, int ml) const {
+        return Lane{nl, ml, (unsigned)(nl * (int)ld_h + ml), (unsigned)(nl * (int)ld_r + ml)};
+    }
+    __device__ __forceinline__ Pre load_fast(int um, int un, const Lane& ln) const {
+        (void)un;
+        Pre p;
+        p.b = bias ? *reinterpret_cast<const f32x4*>(bias + um + ln.ml) : f32x4{0.f, 0.f, 0.f, 0.f};
+        return p;
+    }
+    __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre& pre, float (&t1)[4],
+                                               float (&t2)[4]) const {
+        float yv[4], rv[4];
+        vbnn_f32x4 z;
+        if (noise) z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mb = a1[j] + pre.b[j];
+            if (noise) {
+                const bool pos = a2[j] > 0.f;
+                const float rs = __builtin_amdgcn_rsqf(a2[j]);
+                const float sd = pos ? a2[j] * rs : 0.f;
+                yv[j] = fmaf(sd, z.v[j], mb);
+                rv[j] = pos ? 0.5f * z.v[j] * rs : 0.f;
+            } else {
+                yv[j] = mb;
+                rv[j] = 0.f;
+            }
+        }
+        if (r_t) store4<T>(r_t + ((int64_t)un * ld_r + um) + ln.orr, rv[0], rv[1], rv[2], rv[3], 4, true);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t1[j] = relu ? fmaxf(yv[j], 0.f) : yv[j];
+            const float hr = Elt<T>::from(Elt<T>::to(t1[j]));
+            t2[j] = hr * hr;
+        }
+        const int64_t ub = (int64_t)un * ld_h + um;
+        store4<T>(h + ub + ln.oh, t1[0], t1[1], t1[2], t1[3], 4, true);
+        if (h2) store4<T>(h2 + ub + ln.oh, t2[0], t2[1], t2[2], t2[3], 4, true);
+    }
 };
 
 // ---- DX: M = input units i, N = minibatch rows n ------------------------------------------------
@@ -112,9 +176,9 @@ struct EpiDx {
     T* gT_prev; T* gvT_prev; int64_t ld_gpT;
     int I, N;
 
-    __device__ __forceinline__ T* t1_ptr() const { return gT_prev; }
-    __device__ __forceinline__ T* t2_ptr() const { return gvT_prev; }
-    __device__ __forceinline__ int64_t t_ld() const { return ld_gpT; }
+    __host__ __device__ __forceinline__ T* t1_ptr() const { return gT_prev; }
+    __host__ __device__ __forceinline__ T* t2_ptr() const { return gvT_prev; }
+    __host__ __device__ __forceinline__ int64_t t_ld() const { return ld_gpT; }
     __device__ __forceinline__ int m_dim() const { return I; }
     __device__ __forceinline__ int n_dim() const { return N; }
 
@@ -155,6 +219,40 @@ struct EpiDx {
         float t1[4], t2[4];
         apply<true>(m, n, a1, a2, t1, t2);
     }
+
+    // ---- fast protocol: the hand-off form (packed g_prev / gv_prev, packed r) of the fused engine
+    static constexpr int FAST_BATCH = 8;
+    struct Pre { typename V4<T>::type x, r; };
+    struct Lane { unsigned ox, orp, ogp; };
+    __host__ __device__ bool fast_ok() const {
+        return x && !gx && g_prev && !r_prev && (ld_x % 4 == 0) && (ld_gp % 4 == 0) &&
+               (!r_prev_t || (r_vec && ld_r_prev % 4 == 0)) && (!gv_prev || r_prev_t) &&
+               ((((uintptr_t)x | (uintptr_t)g_prev | (uintptr_t)gv_prev | (uintptr_t)r_prev_t) & 7u) == 0) &&
+               (int64_t)N * ld_x < (1ll << 31) && (int64_t)N * ld_gp < (1ll << 31) && (int64_t)N * ld_r_prev < (1ll << 31);
+    }
+    __device__ __forceinline__ Lane lane_init(int nl, int ml) const {
+        return Lane{(unsigned)(nl * (int)ld_x + ml), (unsigned)(nl * (int)ld_r_prev + ml), (unsigned)(nl * (int)ld_gp + ml)};
+    }
+    __device__ __forceinline__ Pre load_fast(int um, int un, const Lane& ln) const {
+        Pre p;
+        p.x = *reinterpret_cast<const typename V4<T>::type*>(x + ((int64_t)un * ld_x + um) + ln.ox);
+        if (r_prev_t) p.r = *reinterpret_cast<const typename V4<T>::type*>(r_prev_t + ((int64_t)un * ld_r_prev + um) + ln.orp);
+        else p.r = typename V4<T>::type{};
+        return p;
+    }
+    __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre& pre, float (&t1)[4],
+                                               float (&t2)[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xv = Elt<T>::from(pre.x[j]);
+            const float gv = dual ? fmaf(2.0f * xv, a2[j], a1[j]) : a1[j];
+            t1[j] = (relu_mask && !(xv > 0.f)) ? 0.f : gv;
+            t2[j] = t1[j] * Elt<T>::from(pre.r[j]);
+        }
+        const int64_t ub = (int64_t)un * ld_gp + um;
+        store4<T>(g_prev + ub + ln.ogp, t1[0], t1[1], t1[2], t1[3], 4, true);
+        if (gv_prev) store4<T>(gv_prev + ub + ln.ogp, t2[0], t2[1], t2[2], t2[3], 4, true);
+    }
 };
 
 // ---- DW: M = input units i, N = output units o --------------------------------------------------
@@ -170,9 +268,9 @@ struct EpiDw {
     const float* means; const double* stats; float B, S, kl_scale;
     int I, O;
 
-    __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
-    __device__ __forceinline__ bf16_t* t2_ptr() const { return nullptr; }
-    __device__ __forceinline__ int64_t t_ld() const { return 0; }
+    __host__ __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
+    __host__ __device__ __forceinline__ bf16_t* t2_ptr() const { return nullptr; }
+    __host__ __device__ __forceinline__ int64_t t_ld() const { return 0; }
     __device__ __forceinline__ int m_dim() const { return I; }
     __device__ __forceinline__ int n_dim() const { return O; }
 
@@ -245,5 +343,43 @@ struct EpiDw {
             if (grad_mu) store4<float>(grad_mu + base, gm[0], gm[1], gm[2], gm[3], valid, vec);
             if (grad_lv) store4<float>(grad_lv + base, gl[0], gl[1], gl[2], gl[3], valid, vec);
         }
+    }
+
+    // ---- fast protocol: the fused total gradients of an LRT layer, first draw of the minibatch (the S = 1 step)
+    static constexpr int FAST_BATCH = 4;
+    struct Pre { f32x4 lv, mu; };
+    struct Lane { unsigned o; };
+    __host__ __device__ bool fast_ok() const {
+        return lrt && vec && !accumulate && grad_mu && grad_lv && means && lvars && !gradWeight && !gradSum &&
+               (int64_t)O * I < (1ll << 31);
+    }
+    __device__ __forceinline__ Lane lane_init(int nl, int ml) const { return Lane{(unsigned)(nl * I + ml)}; }
+    __device__ __forceinline__ Pre load_fast(int um, int un, const Lane& ln) const {
+        const int64_t ub = (int64_t)un * I + um;
+        Pre p;
+        p.lv = *reinterpret_cast<const f32x4*>(lvars + ub + ln.o);
+        p.mu = *reinterpret_cast<const f32x4*>(means + ub + ln.o);
+        return p;
+    }
+    __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre& pre, float (&t1)[4],
+                                               float (&t2)[4]) const {
+        (void)t1; (void)t2;
+        const int64_t ub = (int64_t)un * I + um;
+        const float var_hat = (float)stats[2];
+        const float invS = 1.0f / S;
+        const float k_mu = kl_scale / (B * var_hat);
+        const float k_lv = kl_scale / (2.0f * B);
+        const float inv_vh = 1.0f / var_hat;
+        f32x4 gm, gl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float var = expf(pre.lv[j]);
+            const float lm = scale * a1[j] * invS;
+            const float ll = a2[j] * var * invS;
+            gm[j] = fmaf(k_mu, pre.mu[j], lm);
+            gl[j] = fmaf(k_lv, fmaf(var, inv_vh, -1.0f), ll);
+        }
+        *reinterpret_cast<f32x4*>(grad_mu + ub + ln.o) = gm;
+        *reinterpret_cast<f32x4*>(grad_lv + ub + ln.o) = gl;
     }
 };

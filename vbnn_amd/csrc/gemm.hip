@@ -3,15 +3,17 @@
 #include "epilogues.h"
 #include "gemm_v1.h"
 #include "gemm_v2.h"
+#include "gemm_v3.h"
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 // 0 = choose by shape, 1 = always the general kernel (gemm_v1.h), 2 = the pipelined bf16 kernel
-// (gemm_v2.h) whenever the operands allow it. Test / A-B hook: vbnn_debug_set(VBNN_DEBUG_GEMM_KERNEL, ..).
+// (gemm_v2.h) whenever the operands allow it, 3 = its 256 x 256 two-pass variant (gemm_v3.h) whenever they do.
+// Test / A-B hook: vbnn_debug_set(VBNN_DEBUG_GEMM_KERNEL, ..).
 static int g_force_kernel = 0;
 
 extern "C" int vbnn_debug_set(int key, int value) {
-    if (key == VBNN_DEBUG_GEMM_KERNEL && value >= 0 && value <= 2) { g_force_kernel = value; return VBNN_OK; }
+    if (key == VBNN_DEBUG_GEMM_KERNEL && value >= 0 && value <= 3) { g_force_kernel = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_SCHEDULE && (value == -1 || value == 0 || value == 2 || value == 4)) { g_v2_sched = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_TILE && (value == 0 || value == 64 || value == 128 || value == 256)) { g_v2_tile = value; return VBNN_OK; }
     vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
@@ -22,6 +24,11 @@ template <typename T, bool DUAL, class Epi>
 static int launch_gemm(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda, const void* B, const void* B2,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, const Epi& epi) {
     const bool v2_ok = gemm_v2_possible<T>(lda, ldb);
+    if (v2_ok && sizeof(T) == 2 &&
+        ((g_force_kernel == 3 && gemm_v3_possible(M, N, lda, ldb, epi)) ||
+         (g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_eligible(M, N, K, lda, ldb, epi))))
+        return launch_gemm_v3<T, DUAL, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb, (int)M, (int)N,
+                                            (int)K, epi);
     if (v2_ok && g_force_kernel != 1 && (g_force_kernel == 2 || gemm_v2_eligible<T>(M, N, K, lda, ldb)))
         return launch_gemm_v2<T, DUAL, Epi>(ctx->stream, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
                                             (int)M, (int)N, (int)K, epi);

@@ -1,0 +1,365 @@
+// gemm_v3.h -- the 256 x 256 two-pass variant of the pipelined bf16 GEMM (gfx950 only), for outputs with at least
+// ~one such tile per CU (the 4096^2 layers of the wide configuration).
+//
+//   pass 1   C1[m][n] = sum_k A [m][k] Bt [n][k]      (the mean GEMM of the pair)
+//   pass 2   C2[m][n] = sum_k A2[m][k] Bt2[n][k]      (the variance GEMM; DUAL only)
+//
+// Why: gemm_v2's dual 256 x 128 tile needs 47.7 B/clk/CU of LDS-DMA at full MFMA rate (two accumulators per output
+// cap its tile). One accumulator per output allows 256 x 256: 32 B/clk/CU, a third fewer DMAs and a quarter fewer
+// ds_reads per MFMA -- what the vendor library's 256x256x64 macro-tile runs on. The pair's two GEMMs then run one
+// after the other in the SAME workgroup: pass 1's tile is re-laid into output rows (the epilogue's layout) and parked
+// in a per-workgroup fp32 scratch tile (256 KiB, written and read back by the same thread: stays in L2/MALL), pass 2
+// accumulates the second GEMM, and the fused epilogue (epilogues.h, unchanged) sees both.
+//
+//   workgroup   8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = acc[8][4] (128 accumulator registers)
+//   K step      64 bf16 (128-B rows, the swizzle of gemm_v2.h), two PHASES of 32 MFMAs per wave:
+//               phase P uses the wave's A rows 64 P .. 64 P + 63 and all of its B rows (B fragments stay in registers)
+//   LDS         160 KiB = A parts [2 K steps][2 phases] x 16 KiB + B tiles [3 K steps] x 32 KiB.
+//               A part P holds the 2 x 64 rows the two wave rows use in phase P, so it is free for refill after that
+//               phase: A is double-buffered at PHASE granularity, B triple-buffered at K-step granularity.
+//   per phase   s_waitcnt vmcnt(8 | 10) -> s_barrier -> 8 (16 in phase 0) ds_read_b128 + 32 MFMA, with 4 DMAs issued
+//               between the MFMAs:  phase 0 of step t: A part 1 of t+1 (x2), B of t+2 (x2)
+//                                   phase 1 of step t: A part 0 of t+2 (x2), B of t+2 (x2)
+//               every DMA is in flight for at least two phases (64 MFMAs per wave) before its data is needed.
+#pragma once
+#include "gemm_v2.h"
+
+constexpr int V3_BM = 256, V3_BN = 256;
+constexpr int V3_APART = 128 * 128;                  // bytes: 128 rows x 128 B
+constexpr int V3_BTILE = 256 * 128;
+constexpr int V3_LDS = 4 * V3_APART + 3 * V3_BTILE;  // 163840: all of the CU's LDS
+constexpr int V3_SCRATCH_FLOATS = V3_BM * V3_BN;     // per workgroup
+
+template <> __device__ __forceinline__ void v2_wait_vmcnt<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+template <> __device__ __forceinline__ void v2_wait_vmcnt<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+
+template <bool DUAL, class Epi>
+__global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
+                                                     const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
+                                                     int M, int N, int nk, int tiles_m, int tiles_n, float* mscratch, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform on the scalar side
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- block -> tile mapping: as gemm_v2.h (blocks that share an XCD get a compact 4 x 8 group of tiles)
+    const int nblk = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm, tn;
+    {
+        constexpr int GM = 4, GN = 8;
+        const int per_band = GM * tiles_n;
+        const int band = bid / per_band;
+        const int in_band = bid - band * per_band;
+        const int band_rows = min(GM, tiles_m - band * GM);
+        const int full = band_rows * GN;
+        const int grp = in_band / full;
+        const int in_grp = in_band - grp * full;
+        const int grp_cols = min(GN, tiles_n - grp * GN);
+        tm = min(band * GM + in_grp / grp_cols, tiles_m - 1);
+        tn = grp * GN + in_grp % grp_cols;
+    }
+    const int m0 = tm * V3_BM, n0 = tn * V3_BN;
+
+    // ---- LDS-DMA source offsets (elements), shared by both passes. A part P, DMA d: 8-row group g = wave + 8 d of
+    // the part's 128 rows; part row s belongs to wave row s >> 6 and is tile row (s >> 6) * 128 + 64 P + (s & 63).
+    int a_off[2][2], b_off[4];                 // 32-bit: the launcher checks rows x ld < 2^31
+#pragma unroll
+    for (int P = 0; P < 2; ++P)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int s = 8 * (wave + 8 * d) + (lane >> 3);
+            const int row = (s >> 6) * 128 + 64 * P + (s & 63);
+            const int chunk = (lane & 7) ^ ((s >> 1) & 7);
+            a_off[P][d] = min(m0 + row, M - 1) * (int)lda + chunk * 8;
+        }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int row = 8 * (wave + 8 * d) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        b_off[d] = min(n0 + row, N - 1) * (int)ldb + chunk * 8;
+    }
+    const bf16_t* Ap = A;
+    const bf16_t* Bp = B;
+    auto dma_a = [&](int t, auto P_c, auto d_c) {
+        constexpr int P = decltype(P_c)::value, D = decltype(d_c)::value;
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ap + (a_off[P][D] + t * V2_BK)),
+                                         (lptr_t)(lds + ((t & 1) * 2 + P) * V3_APART + (wave + 8 * D) * 1024), 16, 0, 0);
+    };
+    auto dma_b = [&](int t, int slot, auto d_c) {
+        constexpr int D = decltype(d_c)::value;
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bp + (b_off[D] + t * V2_BK)),
+                                         (lptr_t)(lds + 4 * V3_APART + slot * V3_BTILE + (wave + 8 * D) * 1024), 16, 0, 0);
+    };
+    std::integral_constant<int, 0> c0;
+    std::integral_constant<int, 1> c1;
+    std::integral_constant<int, 2> c2;
+    std::integral_constant<int, 3> c3;
+
+    // ---- fragment read offsets (bytes inside an A part / a B tile); swizzle as in gemm_v2.h
+    const int rsw = (lane & 15) >> 1;
+    const int q = lane >> 4;
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int csw = ((4 * s + q) ^ rsw) * 16;
+        a_rd[s] = (wr * 64 + (lane & 15)) * 128 + csw;
+        b_rd[s] = (wc * 64 + (lane & 15)) * 128 + csw;
+    }
+
+    f32x4 acc[8][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- one pass: acc = sum over the nk K steps of (Ap tile) x (Bp tile)^T
+    auto run_pass = [&]() {
+        // prologue, in the steady state's issue order: B(0) half, A part 0 (0), B(0) half, A part 1 (0), then step 1
+        dma_b(0, 0, c0); dma_b(0, 0, c1); dma_a(0, c0, c0); dma_a(0, c0, c1);
+        dma_b(0, 0, c2); dma_b(0, 0, c3); dma_a(0, c1, c0); dma_a(0, c1, c1);
+        if (nk > 1) {
+            dma_b(1, 1, c0); dma_b(1, 1, c1); dma_a(1, c0, c0); dma_a(1, c0, c1);
+            dma_b(1, 1, c2); dma_b(1, 1, c3);
+        }
+        int bs = 0;                                           // B slot of step t (t % 3)
+        for (int t = 0; t < nk; ++t) {
+            const int bs2 = bs == 0 ? 2 : bs - 1;             // (t + 2) % 3
+            const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+            const unsigned char* sb = lds + 4 * V3_APART + bs * V3_BTILE;
+            bf16x8 bf[2][4];
+            // ------------------------------------------------ phase 0: A rows 0..63 of the wave
+            if (t == nk - 1) v2_wait_vmcnt<2>(); else v2_wait_vmcnt<8>();
+            __builtin_amdgcn_s_barrier();
+            {
+                const unsigned char* sa = lds + ((t & 1) * 2 + 0) * V3_APART;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 af[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[s] + i * 2048);
+                        bf[s][i] = *reinterpret_cast<const bf16x8*>(sb + b_rd[s] + i * 2048);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s][j], acc[i][j], 0, 0, 0);
+                        if (s == 0 && i == 1 && n1) dma_a(t + 1, c1, c0);
+                        if (s == 0 && i == 3 && n1) dma_a(t + 1, c1, c1);
+                        if (s == 1 && i == 1 && n2) dma_b(t + 2, bs2, c0);
+                        if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c1);
+                        if (i & 1) __builtin_amdgcn_sched_barrier(0);      // keep each DMA where it was put
+                    }
+                }
+            }
+            // ------------------------------------------------ phase 1: A rows 64..127 of the wave, B from registers
+            if (t == nk - 1) v2_wait_vmcnt<0>(); else if (t == nk - 2) v2_wait_vmcnt<8>(); else v2_wait_vmcnt<10>();
+            __builtin_amdgcn_s_barrier();
+            {
+                const unsigned char* sa = lds + ((t & 1) * 2 + 1) * V3_APART;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 af[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[s] + i * 2048);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s][j], acc[4 + i][j], 0, 0, 0);
+                        if (s == 0 && i == 1 && n2) dma_a(t + 2, c0, c0);
+                        if (s == 0 && i == 3 && n2) dma_a(t + 2, c0, c1);
+                        if (s == 1 && i == 1 && n2) dma_b(t + 2, bs2, c2);
+                        if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c3);
+                        if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            bs = bs == 2 ? 0 : bs + 1;
+        }
+    };
+
+    // ---- epilogue: the LDS re-layout of gemm_v2.h, one QUARTER of the wave tile (64 m x 32 n) at a time -- a whole
+    // 128 x 64 tile's rows plus the parked pass-1 rows would not fit the register file beside the accumulators.
+    // Quarter qq = (hh, jj): m-blocks 4 hh .. 4 hh + 3, n-blocks 2 jj, 2 jj + 1. Per wave 18944 B of LDS:
+    // fp32 rows [32 n][SP] + two transposed staging tiles [64 m][TQ] in the operand type.
+    typedef typename Epi::elem_t ET;
+    constexpr int SP = 68;                                    // fp32 staging pitch (floats)
+    constexpr int TQ = 40;                                    // transposed staging pitch (elements): 32 n + pad, 16-B rows
+    constexpr int WAVE_LDS = 32 * SP * 4 + 2 * 64 * TQ * 2;   // 18944
+    static_assert(8 * WAVE_LDS <= V3_LDS, "epilogue staging must fit the allocation");
+    float* st = reinterpret_cast<float*>(lds + wave * WAVE_LDS);
+    ET* tl1 = reinterpret_cast<ET*>(lds + wave * WAVE_LDS + 32 * SP * 4);
+    ET* tl2 = tl1 + 64 * TQ;
+    const int c16 = lane & 15, q4 = lane >> 4;
+    auto relayout = [&](auto hh_c, auto jj_c, f32x4 (&rows)[8]) {      // MFMA layout -> rows of n, 4 consecutive m per lane
+        constexpr int HH = decltype(hh_c)::value, JJ = decltype(jj_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl)
+                *reinterpret_cast<f32x4*>(st + (jl * 16 + c16) * SP + i * 16 + q4 * 4) = acc[4 * HH + i][2 * JJ + jl];
+        // same-wave LDS operations complete in order: the reads below see the writes above
+#pragma unroll
+        for (int p = 0; p < 8; ++p) rows[p] = *reinterpret_cast<const f32x4*>(st + (4 * p + q4) * SP + 4 * c16);
+    };
+    f32x4* park = reinterpret_cast<f32x4*>(mscratch + (size_t)blockIdx.x * V3_SCRATCH_FLOATS);   // [4 qq][8 p][512] f32x4
+    const typename Epi::Lane eln = epi.lane_init(q4, 4 * c16);
+
+    auto for_quarters = [&](auto&& fn) {
+        fn(c0, c0, 0); fn(c0, c1, 1); fn(c1, c0, 2); fn(c1, c1, 3);
+    };
+
+    zero_acc();
+    run_pass();
+    if (DUAL) {
+        // park pass 1's tile, already in the epilogue's row layout, in this workgroup's scratch tile
+        __syncthreads();                                      // every wave is done reading the last K step
+        for_quarters([&](auto hh_c, auto jj_c, int qq) {
+            f32x4 rows[8];
+            relayout(hh_c, jj_c, rows);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) (park + (qq * 8 + p) * 512)[tid] = rows[p];
+        });
+        zero_acc();
+        Ap = A2; Bp = B2;
+        v2_wait_vmcnt<0>();                                   // the parking stores must not be counted as pass 2's DMAs
+        __syncthreads();                                      // the staging reads are done: the ring may be refilled
+        run_pass();
+    }
+    __syncthreads();
+
+    ET* tp1 = epi.t1_ptr();
+    ET* tp2 = epi.t2_ptr();
+    const bool any_t = (tp1 != nullptr) || (tp2 != nullptr);
+    for_quarters([&](auto hh_c, auto jj_c, int qq) {
+        constexpr int HH = decltype(hh_c)::value, JJ = decltype(jj_c)::value;
+        const int wm0 = m0 + wr * 128 + HH * 64, wn0 = n0 + wc * 64 + JJ * 32;
+        f32x4 r1[8], r2[8];
+        if (DUAL) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) r1[p] = (park + (qq * 8 + p) * 512)[tid];
+            relayout(hh_c, jj_c, r2);
+        } else {
+            relayout(hh_c, jj_c, r1);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) r2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // the functor's FAST protocol (epilogues.h): every tile of this kernel is interior and vector-aligned (the
+        // launcher checks), so the epilogue's global loads are issued a batch at a time, ahead of their first use
+        constexpr int FB = Epi::FAST_BATCH;
+#pragma unroll
+        for (int p0 = 0; p0 < 8; p0 += FB) {
+            typename Epi::Pre pre[FB];
+#pragma unroll
+            for (int b = 0; b < FB; ++b) pre[b] = epi.load_fast(wm0, wn0 + 4 * (p0 + b), eln);
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int p = p0 + b;
+                float t1[4], t2[4];
+                epi.apply_fast(wm0, wn0 + 4 * p, eln, r1[p], r2[p], pre[b], t1, t2);
+                if (any_t) {
+                    // 8-element chunks XOR-swizzled by the row's c16 & 3 (rows 4 apart would otherwise share banks)
+                    const int nl = 4 * p + q4;
+                    const int col = ((nl >> 3) ^ (c16 & 3)) * 8 + (nl & 7);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        tl1[(4 * c16 + j) * TQ + col] = Elt<ET>::to(t1[j]);
+                        tl2[(4 * c16 + j) * TQ + col] = Elt<ET>::to(t2[j]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);        // one position at a time: interleaving them all spills
+            }
+        }
+        if (any_t) {
+            // rows of the transposed outputs: lane (row = lane >> 2 (+16 per pass), 8 consecutive n = 8 (lane & 3) ..)
+            const int64_t ldt = epi.t_ld();               // a multiple of 8, 16-byte aligned rows (the launcher checks)
+            const unsigned lo = (unsigned)((lane >> 2) * (int)ldt + 8 * (lane & 3));      // scalar base + lane offset
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int ml = 16 * pp + (lane >> 2);
+                const int64_t ub = (int64_t)(wm0 + 16 * pp) * ldt + wn0;
+                if (tp1)
+                    *reinterpret_cast<bf16x8*>(tp1 + ub + lo) =
+                        *reinterpret_cast<const bf16x8*>(tl1 + ml * TQ + 8 * ((lane & 3) ^ ((ml >> 2) & 3)));
+                if (tp2)
+                    *reinterpret_cast<bf16x8*>(tp2 + ub + lo) =
+                        *reinterpret_cast<const bf16x8*>(tl2 + ml * TQ + 8 * ((lane & 3) ^ ((ml >> 2) & 3)));
+            }
+        }
+    });
+}
+
+// The kernel has no ragged-edge or general-output path: whole 256 x 256 tiles, 32-bit element offsets, the functor's
+// fast protocol and 16-byte rows of the transposed outputs. Everything else stays with gemm_v2.h.
+template <class Epi>
+static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t lda, int64_t ldb, const Epi& epi) {
+    Epi e = epi;
+    const bool t_ok = (!e.t1_ptr() && !e.t2_ptr()) ||
+                      ((e.t_ld() % 8 == 0) && ((((uintptr_t)e.t1_ptr() | (uintptr_t)e.t2_ptr()) & 15u) == 0));
+    return (M % V3_BM == 0) && (N % V3_BN == 0) && M * lda < (1ll << 31) && N * ldb < (1ll << 31) && epi.fast_ok() && t_ok &&
+           M * e.t_ld() < (1ll << 31);
+}
+// worth it when the tiling gives (almost) every CU one tile, no more than one round of them, and K is long enough
+// to amortise the second prologue and the parking of pass 1 (measured: 4096^3 -16 us on the forward; K = 784 +12 us)
+template <class Epi>
+static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, const Epi& epi) {
+    const int64_t t = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
+    return gemm_v3_possible(M, N, lda, ldb, epi) && t >= 192 && t <= 256 && K >= 1536;
+}
+
+template <typename T, bool DUAL, class Epi>
+static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, const T* B, const T* B2, int64_t ldb, int M, int N,
+                          int K, const Epi& epi) {
+    if constexpr (sizeof(T) != 2) {
+        vbnn_set_error("gemm_v3 is bf16 only");
+        return VBNN_ERR_UNSUPPORTED;
+    } else {
+        if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15u) != 0) {
+            vbnn_set_error("gemm_v3 operands must be 16-byte aligned");
+            return VBNN_ERR_INVALID;
+        }
+        const int nk = (K + V2_BK - 1) / V2_BK;
+        if (lda < (int64_t)nk * V2_BK || ldb < (int64_t)nk * V2_BK) {
+            vbnn_set_error("packed leading dimension too small for K=%d", K);
+            return VBNN_ERR_INVALID;
+        }
+        if (!gemm_v3_possible(M, N, lda, ldb, epi)) { vbnn_set_error("gemm_v3: shape / outputs outside its fast path"); return VBNN_ERR_UNSUPPORTED; }
+        const int tiles_m = (M + V3_BM - 1) / V3_BM, tiles_n = (N + V3_BN - 1) / V3_BN;
+        const size_t need = DUAL ? (size_t)tiles_m * tiles_n * V3_SCRATCH_FLOATS * sizeof(float) : 0;
+        if (need > ctx->park_bytes) {                        // the parking tiles of pass 1 (grown on demand, kept)
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->park) (void)hipFree(ctx->park);
+            ctx->park = nullptr; ctx->park_bytes = 0;
+            hipError_t e = hipMalloc((void**)&ctx->park, need);
+            if (e != hipSuccess) { vbnn_set_error("hipMalloc(gemm_v3 scratch, %zu bytes): %s", need, hipGetErrorString(e)); return VBNN_ERR_NOMEM; }
+            ctx->park_bytes = need;
+        }
+        const void* kern = (const void*)gemm_nt_v3<DUAL, Epi>;
+        static bool configured = false;                      // per instantiation
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+            if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+            configured = true;
+        }
+        const bf16_t* a = (const bf16_t*)A; const bf16_t* a2 = (const bf16_t*)A2;
+        const bf16_t* b = (const bf16_t*)B; const bf16_t* b2 = (const bf16_t*)B2;
+        int nk_ = nk, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
+        int64_t lda_ = lda, ldb_ = ldb;
+        float* park = ctx->park;
+        Epi epi_ = epi;
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &park, &epi_};
+        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n), dim3(512), args, V3_LDS, ctx->stream);
+        if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v3 failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+        return vbnn_check_launch("gemm_nt_v3");
+    }
+}
