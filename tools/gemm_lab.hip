@@ -26,6 +26,15 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
     __device__ __forceinline__ void apply(int m, int n, f32x4 a1, f32x4 a2, float (&t1)[4], float (&t2)[4]) const {
         if (m < M && n < N) *reinterpret_cast<f32x4*>(out + (size_t)n * M + m) = a1 + a2;
     }
+    static constexpr int FAST_BATCH = 8;
+    struct Pre {};
+    struct Lane { unsigned o; };
+    __host__ __device__ bool fast_ok() const { return true; }
+    __device__ __forceinline__ Lane lane_init(int nl, int ml) const { return Lane{(unsigned)(nl * M + ml)}; }
+    __device__ __forceinline__ Pre load_fast(int, int, const Lane&) const { return Pre{}; }
+    __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre&, float (&)[4], float (&)[4]) const {
+        *reinterpret_cast<f32x4*>(out + ((size_t)un * M + um) + ln.o) = a1 + a2;
+    }
 };
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 

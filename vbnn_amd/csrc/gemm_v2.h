@@ -291,19 +291,41 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     const bool any_t = (tp1 != nullptr) || (tp2 != nullptr);
     ET* tl1 = reinterpret_cast<ET*>(st);                      // [64 m][TP] each, reusing the staging region
     ET* tl2 = tl1 + 64 * TP;
+    // 8-element chunks XOR-swizzled by (row >> 2) & 7: without it the 16 lanes of a quarter-wave hit two
+    // banks (rows 4 apart are 576 B apart: 8-way conflict, 8.1 M conflict cycles per 4096^2 launch measured)
+    auto stage_t = [&](int p, const float (&t1)[4], const float (&t2)[4]) {
+        const int col = (((4 * p + q4) >> 3) ^ (c16 & 7)) * 8 + ((4 * p + q4) & 7);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        float t1[4], t2[4];
-        epi.template apply<false>(wm0 + 4 * c16, wn0 + 4 * p + q4, r1[p], r2[p], t1, t2);
-        if (any_t) {
-            // 8-element chunks XOR-swizzled by (row >> 2) & 7: without it the 16 lanes of a quarter-wave hit two
-            // banks (rows 4 apart are 576 B apart: 8-way conflict, 8.1 M conflict cycles per 4096^2 launch measured)
-            const int col = (((4 * p + q4) >> 3) ^ (c16 & 7)) * 8 + ((4 * p + q4) & 7);
+        for (int j = 0; j < 4; ++j) {
+            tl1[(4 * c16 + j) * TP + col] = Elt<ET>::to(t1[j]);
+            tl2[(4 * c16 + j) * TP + col] = Elt<ET>::to(t2[j]);
+        }
+    };
+    // A wave tile that lies fully inside the matrix takes the functor's FAST protocol when it applies (epilogues.h):
+    // the epilogue's global loads go out a batch at a time instead of one guarded, waited-for load per position.
+    const bool fast = epi.fast_ok() && (wm0 + 64 <= epi.m_dim()) && (wn0 + 64 <= epi.n_dim());     // wave-uniform
+    if (fast) {
+        const int um = __builtin_amdgcn_readfirstlane(wm0), un = __builtin_amdgcn_readfirstlane(wn0);
+        const typename Epi::Lane eln = epi.lane_init(q4, 4 * c16);
+        constexpr int FB = Epi::FAST_BATCH / 2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tl1[(4 * c16 + j) * TP + col] = Elt<ET>::to(t1[j]);
-                tl2[(4 * c16 + j) * TP + col] = Elt<ET>::to(t2[j]);
+        for (int p0 = 0; p0 < 16; p0 += FB) {
+            typename Epi::Pre pre[FB];
+#pragma unroll
+            for (int b = 0; b < FB; ++b) pre[b] = epi.load_fast(um, un + 4 * (p0 + b), eln);
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                float t1[4], t2[4];
+                epi.apply_fast(um, un + 4 * (p0 + b), eln, r1[p0 + b], r2[p0 + b], pre[b], t1, t2);
+                if (any_t) stage_t(p0 + b, t1, t2);
             }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            float t1[4], t2[4];
+            epi.template apply<false>(wm0 + 4 * c16, wn0 + 4 * p + q4, r1[p], r2[p], t1, t2);
+            if (any_t) stage_t(p, t1, t2);
         }
     }
     if (any_t) {
