@@ -7,8 +7,8 @@
 // Why: gemm_v2's dual 256 x 128 tile needs 47.7 B/clk/CU of LDS-DMA at full MFMA rate (two accumulators per output
 // cap its tile). One accumulator per output allows 256 x 256: 32 B/clk/CU, a third fewer DMAs and a quarter fewer
 // ds_reads per MFMA -- what the vendor library's 256x256x64 macro-tile runs on. The pair's two GEMMs then run one
-// after the other in the SAME workgroup: pass 1's tile is re-laid into output rows (the epilogue's layout) and parked
-// in a per-workgroup fp32 scratch tile (256 KiB, written and read back by the same thread: stays in L2/MALL), pass 2
+// after the other in the SAME workgroup: pass 1's tile is parked as it stands (MFMA register layout) in a
+// per-workgroup fp32 scratch tile (256 KiB, written and read back by the same thread: stays in L2/MALL), pass 2
 // accumulates the second GEMM, and the fused epilogue (epilogues.h, unchanged) sees both.
 //
 //   workgroup   8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = acc[8][4] (128 accumulator registers)
@@ -201,18 +201,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     ET* tl1 = reinterpret_cast<ET*>(lds + wave * WAVE_LDS + 32 * SP * 4);
     ET* tl2 = tl1 + 64 * TQ;
     const int c16 = lane & 15, q4 = lane >> 4;
-    auto relayout = [&](auto hh_c, auto jj_c, f32x4 (&rows)[8]) {      // MFMA layout -> rows of n, 4 consecutive m per lane
-        constexpr int HH = decltype(hh_c)::value, JJ = decltype(jj_c)::value;
+    // a quarter in the MFMA layout, v[2 i + jl] = block (m-block i, n-block jl) -> rows of n, 4 consecutive m per lane
+    auto relayout = [&](const f32x4 (&v)[8], f32x4 (&rows)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl)
-                *reinterpret_cast<f32x4*>(st + (jl * 16 + c16) * SP + i * 16 + q4 * 4) = acc[4 * HH + i][2 * JJ + jl];
+                *reinterpret_cast<f32x4*>(st + (jl * 16 + c16) * SP + i * 16 + q4 * 4) = v[2 * i + jl];
         // same-wave LDS operations complete in order: the reads below see the writes above
 #pragma unroll
         for (int p = 0; p < 8; ++p) rows[p] = *reinterpret_cast<const f32x4*>(st + (4 * p + q4) * SP + 4 * c16);
     };
-    f32x4* park = reinterpret_cast<f32x4*>(mscratch + (size_t)blockIdx.x * V3_SCRATCH_FLOATS);   // [4 qq][8 p][512] f32x4
+    f32x4* park = reinterpret_cast<f32x4*>(mscratch + (size_t)blockIdx.x * V3_SCRATCH_FLOATS);   // [8 i][4 j][512] f32x4
     const typename Epi::Lane eln = epi.lane_init(q4, 4 * c16);
 
     auto for_quarters = [&](auto&& fn) {
@@ -222,18 +222,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     zero_acc();
     run_pass();
     if (DUAL) {
-        // park pass 1's tile, already in the epilogue's row layout, in this workgroup's scratch tile
-        __syncthreads();                                      // every wave is done reading the last K step
-        for_quarters([&](auto hh_c, auto jj_c, int qq) {
-            f32x4 rows[8];
-            relayout(hh_c, jj_c, rows);
+        // Pass 1's tile parks in this workgroup's scratch tile as it stands (MFMA layout, one coalesced 16-byte store
+        // per accumulator quad): no LDS, so nothing but one barrier separates the passes. The stores are older than
+        // pass 2's DMAs on the in-order vmcnt counter: the counted waits of run_pass only get stricter.
+        __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
 #pragma unroll
-            for (int p = 0; p < 8; ++p) (park + (qq * 8 + p) * 512)[tid] = rows[p];
-        });
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) (park + (i * 4 + j) * 512)[tid] = acc[i][j];
         zero_acc();
         Ap = A2; Bp = B2;
-        v2_wait_vmcnt<0>();                                   // the parking stores must not be counted as pass 2's DMAs
-        __syncthreads();                                      // the staging reads are done: the ring may be refilled
         run_pass();
     }
     __syncthreads();
@@ -244,13 +242,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     for_quarters([&](auto hh_c, auto jj_c, int qq) {
         constexpr int HH = decltype(hh_c)::value, JJ = decltype(jj_c)::value;
         const int wm0 = m0 + wr * 128 + HH * 64, wn0 = n0 + wc * 64 + JJ * 32;
-        f32x4 r1[8], r2[8];
-        if (DUAL) {
+        (void)qq;
+        f32x4 r1[8], r2[8], av[8];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) r1[p] = (park + (qq * 8 + p) * 512)[tid];
-            relayout(hh_c, jj_c, r2);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl) av[2 * i + jl] = acc[4 * HH + i][2 * JJ + jl];
+        if (DUAL) {
+            f32x4 mv[8];                                      // the parked pass-1 quarter: loads fly during the first trip
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) mv[2 * i + jl] = (park + ((4 * HH + i) * 4 + 2 * JJ + jl) * 512)[tid];
+            relayout(av, r2);
+            relayout(mv, r1);
         } else {
-            relayout(hh_c, jj_c, r1);
+            relayout(av, r1);
 #pragma unroll
             for (int p = 0; p < 8; ++p) r2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
