@@ -46,12 +46,15 @@ int vbnn_abi_version(void);
 const char* vbnn_last_error(void);
 
 /* test / A-B hook. VBNN_DEBUG_GEMM_KERNEL: 0 = pick by shape (default), 1 = always the general MFMA
- * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it. */
+ * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it, 3 = its two-pass 256 x 256 variant
+ * whenever the shape and outputs allow it (whole tiles, the fused configuration). */
 #define VBNN_DEBUG_GEMM_KERNEL 0
 #define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel DMA schedule: -1 = by tile (default), 0 = burst after the barrier,
                                       2 = interleaved with the MFMAs, 4 = 2 with skewed SIMD partners (gemm_v2.h) */
 #define VBNN_DEBUG_V2_TILE 2       /* pipelined kernel block tile: 0 = by shape (default), 256 = 256 x 128, 128 = 128 x 128,
                                       64 = 128 x 128 with a 2-stage ring, two workgroups per CU */
+#define VBNN_DEBUG_V2_SPLITK 3     /* pipelined kernel split-K (two K halves per 256 x 128 tile): -1 = by shape (default),
+                                      0 = never, 1 = whenever possible */
 int vbnn_debug_set(int key, int value);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream

@@ -362,19 +362,21 @@ def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidd
     close(eng.gradBias3, gb3, "final gradBias")
 
 
-@pytest.fixture(params=[(1, 0), (2, 256), (2, 128), (2, 64), (3, 0)],
+@pytest.fixture(params=[(1, 0, -1), (2, 256, 0), (2, 128, 0), (2, 64, 0), (3, 0, -1), (2, 256, 1)],
                 ids=["general-kernel", "pipelined-256x128", "pipelined-128x128", "pipelined-128x128-pairs",
-                     "two-pass-256x256"])
+                     "two-pass-256x256", "pipelined-256x128-splitK"])
 def gemm_kernel(request, nnmod):
-    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in its block tiles / gemm_v3.h), whatever the
-    shape heuristics say."""
+    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in its block tiles and with split-K / gemm_v3.h),
+    whatever the shape heuristics say."""
     from vbnn_amd import _lib as L
-    kernel, tile = request.param
+    kernel, tile, split = request.param
     L.check(L.lib().vbnn_debug_set(0, kernel))
     L.check(L.lib().vbnn_debug_set(2, tile))
+    L.check(L.lib().vbnn_debug_set(3, split))
     yield request.param
     L.check(L.lib().vbnn_debug_set(0, 0))
     L.check(L.lib().vbnn_debug_set(2, 0))
+    L.check(L.lib().vbnn_debug_set(3, -1))
 
 
 @pytest.mark.parametrize("N,I,O", [(1, 8, 8), (37, 70, 50), (300, 200, 260), (512, 448, 384), (200, 4096, 130),

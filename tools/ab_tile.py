@@ -30,12 +30,13 @@ def run(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-scheds = [int(a) for a in sys.argv[1:]] or [256, 128, 64]      # 3 = the two-pass 256 x 256 kernel (gemm_v3.h)
+scheds = [int(a) for a in sys.argv[1:]] or [256, 128, 64]      # 3 = the two-pass 256 x 256 kernel (gemm_v3.h); 2562 = 256 x 128 with split-K
 res = {}
 for rnd in range(5):
     for s in scheds:
         L.check(lib.vbnn_debug_set(0, 3 if s == 3 else 0))
-        L.check(lib.vbnn_debug_set(2, 0 if s == 3 else s))
+        L.check(lib.vbnn_debug_set(2, 0 if s == 3 else (256 if s == 2562 else s)))
+        L.check(lib.vbnn_debug_set(3, 1 if s == 2562 else 0))
         for k, fn in calls.items():
             res.setdefault((k, s), []).append(run(fn))
 for k in calls:

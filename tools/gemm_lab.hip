@@ -60,13 +60,16 @@ int main(int argc, char** argv) {
 #endif
     EpiSum epi{out, M, N};
     hipStream_t st = 0;
+    vbnn_ctx lab_ctx{};
+    lab_ctx.stream = st;
+    CK(hipMalloc((void**)&lab_ctx.counters, VBNN_CNT_TOTAL * 4)); CK(hipMemset(lab_ctx.counters, 0, VBNN_CNT_TOTAL * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int dual = 0; dual < 2; ++dual)
         for (int sched = 0; sched < 5; sched += 2) {
             g_v2_sched = sched;
             auto launch = [&] {
-                if (dual) launch_gemm_v2<bf16_t, true, EpiSum>(st, A, A2, K, B, B2, K, M, N, K, epi);
-                else launch_gemm_v2<bf16_t, false, EpiSum>(st, A, nullptr, K, B, nullptr, K, M, N, K, epi);
+                if (dual) launch_gemm_v2<bf16_t, true, EpiSum>(&lab_ctx, A, A2, K, B, B2, K, M, N, K, epi);
+                else launch_gemm_v2<bf16_t, false, EpiSum>(&lab_ctx, A, nullptr, K, B, nullptr, K, M, N, K, epi);
             };
             for (int i = 0; i < 3; ++i) launch();
             CK(hipDeviceSynchronize());

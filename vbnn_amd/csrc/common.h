@@ -23,7 +23,7 @@ struct vbnn_ctx {
     unsigned* counters;    // arrival tickets of the in-launch second stages (vbnn_last_arriver); zero between launches
 };
 // ticket slots
-constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TOTAL = 64;
+constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TILES = 16, VBNN_CNT_TILES_MAX = 1008, VBNN_CNT_TOTAL = 1024;   // [16, 1024): one ticket per split-K tile
 
 void vbnn_set_error(const char* fmt, ...);
 

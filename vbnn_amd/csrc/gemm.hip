@@ -16,6 +16,7 @@ extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_GEMM_KERNEL && value >= 0 && value <= 3) { g_force_kernel = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_SCHEDULE && (value == -1 || value == 0 || value == 2 || value == 4)) { g_v2_sched = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_TILE && (value == 0 || value == 64 || value == 128 || value == 256)) { g_v2_tile = value; return VBNN_OK; }
+    if (key == VBNN_DEBUG_V2_SPLITK && value >= -1 && value <= 1) { g_v2_split = value; return VBNN_OK; }
     vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
     return VBNN_ERR_INVALID;
 }
@@ -30,7 +31,7 @@ static int launch_gemm(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda
         return launch_gemm_v3<T, DUAL, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb, (int)M, (int)N,
                                             (int)K, epi);
     if (v2_ok && g_force_kernel != 1 && (g_force_kernel == 2 || gemm_v2_eligible<T>(M, N, K, lda, ldb)))
-        return launch_gemm_v2<T, DUAL, Epi>(ctx->stream, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
+        return launch_gemm_v2<T, DUAL, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
                                             (int)M, (int)N, (int)K, epi);
     return launch_gemm_v1<T, DUAL, Epi>(ctx->stream, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
                                         (int)M, (int)N, (int)K, epi);

@@ -39,7 +39,7 @@ constexpr int V2_B_BYTES = V2_BN * V2_BK * 2;           // 16384
 constexpr int v2_a_bytes(int WM) { return 64 * WM * V2_BK * 2; }
 constexpr int v2_stage(int WM) { return v2_a_bytes(WM) + V2_B_BYTES; }
 // LDS per workgroup: the ring, or the epilogue's 18 KiB-per-wave staging if that is larger (2 stages, 4 waves)
-constexpr int v2_lds(int WM, int ST) { return v2_stage(WM) * ST > 2 * WM * 18432 ? v2_stage(WM) * ST : 2 * WM * 18432; }   // 147456 / 98304 / 73728
+constexpr int v2_lds(int WM, int ST) { return (v2_stage(WM) * ST > 2 * WM * 18432 ? v2_stage(WM) * ST : 2 * WM * 18432) + 16; }   // 147456 / 98304 / 73728, + the split-K flag word
 
 // Diagnostic stamps (tools/gemm_lab.hip builds with -DV2_DIAG; the library never does): per-wave cycle
 // sums of the segments of schedule 0, written to a buffer of their own, never to an output.
@@ -68,6 +68,7 @@ __device__ unsigned long long* g_v2_diag = nullptr;
 // 128 x 128 tile (one wave per SIMD has no partner to cover an interleaved DMA issue: 0 is 8 % faster there).
 static int g_v2_sched = -1;
 static int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
+static int g_v2_split = -1;       // split-K of the 256 x 128 tiling: -1 by shape, 0 never, 1 whenever possible (key 3)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -80,7 +81,8 @@ template <> __device__ __forceinline__ void v2_wait_vmcnt<8>() { asm volatile("s
 template <bool DUAL, int SCHED, int WM, int ST, class Epi>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                           const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
-                                                          int M, int N, int nk, int tiles_m, int tiles_n, Epi epi) {
+                                                          int M, int N, int nk, int tiles_m, int tiles_n, int ksplit, float* exch,
+                                                          unsigned* tickets, Epi epi) {
     constexpr int NW = 2 * WM;                 // waves per workgroup
     constexpr int BM = 64 * WM;
     constexpr int A_BYTES = v2_a_bytes(WM), STAGE = v2_stage(WM);
@@ -98,12 +100,20 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     // the tile list; inside it tiles are walked in 4 (M) x 8 (N) groups so the ~32 blocks running
     // together on an XCD share 4 A panels and 8 B panels in its L2 (measured hit rate 81 % = the ideal
     // 1 - 12/64 of that grouping).
-    const int nblk = tiles_m * tiles_n;
+    // Split-K (ksplit = 2: outputs too few to give every CU a tile, K long): the grid is tiles x 2, a tile's two
+    // K halves sit on neighbouring remapped ids (same XCD), and the half that finishes LAST adds the other's partial
+    // tile and runs the epilogue (see the hand-off before the epilogue).
+    const int nblk = tiles_m * tiles_n * ksplit;
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective remap
     }
+    const int kslice = ksplit > 1 ? (bid & 1) : 0;
+    if (ksplit > 1) bid >>= 1;
+    const int tile_id = bid;
+    const int kt0 = kslice * (nk / 2);                    // first K step of this block
+    if (ksplit > 1) nk = kslice ? nk - nk / 2 : nk / 2;   // K steps of this block
     int tm, tn;
     {
         constexpr int GM = 4, GN = 8;
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     auto issue_one = [&](int u, auto pair_c, auto idx_c) {      // DMA number IDX (0..AG-1: A groups, then B groups) of tile u
         constexpr int P = decltype(pair_c)::value;
         constexpr int IDX = decltype(idx_c)::value;
-        const int64_t koff = (int64_t)(DUAL ? (u >> 1) : u) * V2_BK;
+        const int64_t koff = (int64_t)(kt0 + (DUAL ? (u >> 1) : u)) * V2_BK;
         unsigned char* base = lds + (u % ST) * STAGE;
         if constexpr (IDX < AG)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + NW * IDX) * 1024), 16, 0, 0);
@@ -285,6 +295,45 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
 #pragma unroll
         for (int p = 0; p < 16; ++p) r2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (ksplit > 1) {
+        // ---- split-K hand-off (cdna_hip_programming.md Guideline 16 R1 in its ticket form; vbnn_last_arriver's
+        // protocol with 16-byte write-through stores, so no release fence): BOTH halves store their partial tile (row
+        // layout, thread-private slots), drain, and take a ticket; ticket 0 is finished; ticket 1 acquires, adds the
+        // other half's partial (a + b is commutative: the result does not depend on which half came last) and runs
+        // the epilogue. Nobody waits for anybody. (Measured on the 784 x 4096 gradient: 92 us; letting only ticket 0
+        // store and ticket 1 wait for its flag halves the traffic but serialises store and load: 100 us.)
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        f32x4* mine = reinterpret_cast<f32x4*>(exch) + ((size_t)(tile_id * 2 + kslice) * 32) * (64 * NW);
+        f32x4* other = reinterpret_cast<f32x4*>(exch) + ((size_t)(tile_id * 2 + (kslice ^ 1)) * 32) * (64 * NW);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 32 * 64 * NW * 16, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, r1[p]), rs, (p * 64 * NW + tid) * 16, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, r2[p]), rs, ((16 + p) * 64 * NW + tid) * 16, 0, 16);
+        }
+        int* flag = reinterpret_cast<int*>(lds + v2_lds(WM, ST) - 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, then the barrier, then ONE ticket
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 1u) {
+                __hip_atomic_store(tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flag = (int)t;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+#pragma unroll
+        for (int p0 = 0; p0 < 16; p0 += 8) {
+            f32x4 o1[8], o2[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { o1[b] = other[(p0 + b) * 64 * NW + tid]; o2[b] = other[(16 + p0 + b) * 64 * NW + tid]; }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { r1[p0 + b] += o1[b]; r2[p0 + b] += o2[b]; }
+        }
+    }
     const int wm0 = m0 + wm * 64, wn0 = n0 + wn * 64;
     ET* tp1 = epi.t1_ptr();
     ET* tp2 = epi.t2_ptr();
@@ -369,8 +418,9 @@ static inline bool gemm_v2_eligible(int64_t M, int64_t N, int64_t K, int64_t lda
 }
 
 template <typename T, bool DUAL, class Epi>
-static int launch_gemm_v2(hipStream_t stream, const T* A, const T* A2, int64_t lda, const T* B, const T* B2, int64_t ldb,
+static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, const T* B, const T* B2, int64_t ldb,
                           int M, int N, int K, const Epi& epi) {
+    hipStream_t stream = ctx->stream;
     if constexpr (sizeof(T) != 2) {
         vbnn_set_error("gemm_v2 is bf16 only");
         return VBNN_ERR_UNSUPPORTED;
@@ -392,7 +442,13 @@ static int launch_gemm_v2(hipStream_t stream, const T* A, const T* A2, int64_t l
         // of layer 1 (26 tile steps, then an epilogue as long as the main loop); measured 113 us against 110 us for
         // the 256 x 128 tile there (and 291 vs 257 us at K = 4096), so it is never picked automatically.
         const bool pairs = g_v2_tile == 64;
-        const bool small = pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256);
+        // Split-K: when the 256 x 128 tiling gives at most half the CUs a block and K is long, each tile is computed
+        // by TWO blocks, one per K half (the 784 x 4096 gradient: 128 tiles -> 256 blocks of 32 K steps; measured
+        // against the 128 x 128 tiling that was used before: see DESIGN.md). g_v2_split: -1 auto, 0 never, 1 whenever possible.
+        const bool can_split = t256 <= VBNN_CNT_TILES_MAX && nk >= 2;
+        const bool split = !pairs && g_v2_tile != 128 && can_split &&
+                           (g_v2_split == 1 || (g_v2_split == -1 && g_v2_tile == 0 && t256 <= 128 && nk >= 32));
+        const bool small = !split && (pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256));
         const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small && !pairs ? 0 : 2);
         const int vi = pairs ? 2 : small ? 1 : 0;        // variant: 256 x 128 / 128 x 128 / 128 x 128 co-resident
         const int si = sched >> 1;                       // 0, 1, 2
@@ -416,13 +472,27 @@ static int launch_gemm_v2(hipStream_t stream, const T* A, const T* A2, int64_t l
             configured[vi][si] = true;
         }
         const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + V2_BN - 1) / V2_BN;
+        int ksplit_ = split ? 2 : 1;
+        if (split) {                                          // two partial tiles per tile: 2 x 32 f32x4 per thread
+            const size_t need = (size_t)tiles_m * tiles_n * 2 * 32 * threads * 16;
+            if (need > ctx->park_bytes) {
+                (void)hipStreamSynchronize(stream);
+                if (ctx->park) (void)hipFree(ctx->park);
+                ctx->park = nullptr; ctx->park_bytes = 0;
+                hipError_t e2 = hipMalloc((void**)&ctx->park, need);
+                if (e2 != hipSuccess) { vbnn_set_error("hipMalloc(split-K scratch, %zu bytes): %s", need, hipGetErrorString(e2)); return VBNN_ERR_NOMEM; }
+                ctx->park_bytes = need;
+            }
+        }
         const bf16_t* a = (const bf16_t*)A; const bf16_t* a2 = (const bf16_t*)A2;
         const bf16_t* b = (const bf16_t*)B; const bf16_t* b2 = (const bf16_t*)B2;
         int nk_ = nk, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
         int64_t lda_ = lda, ldb_ = ldb;
+        float* exch_ = ctx->park;
+        unsigned* tickets_ = ctx->counters + VBNN_CNT_TILES;
         Epi epi_ = epi;
-        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &epi_};
-        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n), dim3(threads), args, lds_bytes, stream);
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &ksplit_, &exch_, &tickets_, &epi_};
+        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * ksplit_), dim3(threads), args, lds_bytes, stream);
         if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v2 failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
         return vbnn_check_launch("gemm_nt_v2");
     }
