@@ -27,7 +27,15 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
         if (m < M && n < N) *reinterpret_cast<f32x4*>(out + (size_t)n * M + m) = a1 + a2;
     }
     static constexpr int FAST_BATCH = 8;
+    static constexpr bool PARK = false;
     struct Pre {};
+    struct FPre {};
+    __device__ __forceinline__ FPre fold_load(int, int, const Lane&) const { return FPre{}; }
+    __device__ __forceinline__ f32x4 fold(int, int, const Lane&, f32x4 a2, const FPre&) const { return a2; }
+    __device__ __forceinline__ Pre load_folded(int, int, const Lane&) const { return Pre{}; }
+    __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre&, float (&)[4], float (&)[4]) const {
+        *reinterpret_cast<f32x4*>(out + ((size_t)un * M + um) + ln.o) = a;
+    }
     struct Lane { unsigned o; };
     __host__ __device__ bool fast_ok() const { return true; }
     __device__ __forceinline__ Lane lane_init(int nl, int ml) const { return Lane{(unsigned)(nl * M + ml)}; }

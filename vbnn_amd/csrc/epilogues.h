@@ -25,6 +25,17 @@
 // (um, un) are WAVE-UNIFORM: every address is (scalar base) + (one per-lane 32-bit offset), so the global accesses
 // take the SGPR-base form and a whole unrolled tile needs a handful of address registers instead of a 64-bit pair per
 // access (which spilled). Same arithmetic, same stores.
+//
+// The FOLD protocol (gemm_v3.h, the GEMM pair as two passes over ONE accumulator): the pair's second GEMM (acc2) runs
+// first; between the passes each accumulator quad, still in the MFMA register layout, goes through
+//     FPre fp = epi.fold_load(um, un, ln);   acc = epi.fold(um, un, ln, acc, fp);
+// which turns acc2 into the term the first GEMM is then accumulated ON TOP of (FWD: b + sqrt(v) z, storing r;
+// DX: 2 x . acc2; DW: stores the finished d/dlvars and returns 0), and the final epilogue calls
+//     Pre pre = epi.load_folded(um, un, ln);   epi.apply_folded(um, un, ln, acc, pre, t1, t2)
+// on the single accumulator (`side` = 0). Nothing is parked between the passes. The sums are the same up to fp32
+// association (the term enters the accumulation chain first instead of last). A functor with PARK = true (FWD: the
+// term needs a Philox block per quad, and 32 of those beside 128 live accumulators spill) instead has the kernel park
+// the raw acc2 quads in a scratch tile, folds only the bias, and gets acc2 back as `side` in apply_folded.
 #pragma once
 #include "common.h"
 
@@ -158,6 +169,22 @@ struct EpiFwd {
         store4<T>(h + ub + ln.oh, t1[0], t1[1], t1[2], t1[3], 4, true);
         if (h2) store4<T>(h2 + ub + ln.oh, t2[0], t2[1], t2[2], t2[3], 4, true);
     }
+
+    // ---- fold protocol (LRT only: acc2 = v). PARK: the kernel keeps v aside, the accumulator continues from the bias
+    static constexpr bool PARK = true;
+    struct FPre { f32x4 b; };
+    __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
+        (void)un;
+        FPre p;
+        p.b = bias ? *reinterpret_cast<const f32x4*>(bias + um + ln.ml) : f32x4{0.f, 0.f, 0.f, 0.f};
+        return p;
+    }
+    __device__ __forceinline__ f32x4 fold(int, int, const Lane&, f32x4, const FPre& fp) const { return fp.b; }
+    __device__ __forceinline__ Pre load_folded(int, int, const Lane&) const { return Pre{f32x4{0.f, 0.f, 0.f, 0.f}}; }
+    __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4 v, const Pre& pre, float (&t1)[4],
+                                                 float (&t2)[4]) const {
+        apply_fast(um, un, ln, a, v, pre, t1, t2);           // a = m + b already: pre.b is 0
+    }
 };
 
 // ---- DX: M = input units i, N = minibatch rows n ------------------------------------------------
@@ -247,6 +274,34 @@ struct EpiDx {
             const float xv = Elt<T>::from(pre.x[j]);
             const float gv = dual ? fmaf(2.0f * xv, a2[j], a1[j]) : a1[j];
             t1[j] = (relu_mask && !(xv > 0.f)) ? 0.f : gv;
+            t2[j] = t1[j] * Elt<T>::from(pre.r[j]);
+        }
+        const int64_t ub = (int64_t)un * ld_gp + um;
+        store4<T>(g_prev + ub + ln.ogp, t1[0], t1[1], t1[2], t1[3], 4, true);
+        if (gv_prev) store4<T>(gv_prev + ub + ln.ogp, t2[0], t2[1], t2[2], t2[3], 4, true);
+    }
+
+    // ---- fold protocol (LRT only: acc2 = gv sigma^2): the accumulator continues from 2 x . acc2
+    static constexpr bool PARK = false;
+    struct FPre { typename V4<T>::type x; };
+    __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
+        FPre p;
+        p.x = *reinterpret_cast<const typename V4<T>::type*>(x + ((int64_t)un * ld_x + um) + ln.ox);
+        return p;
+    }
+    __device__ __forceinline__ f32x4 fold(int, int, const Lane&, f32x4 a2, const FPre& fp) const {
+        f32x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = 2.0f * Elt<T>::from(fp.x[j]) * a2[j];
+        return out;
+    }
+    __device__ __forceinline__ Pre load_folded(int um, int un, const Lane& ln) const { return load_fast(um, un, ln); }
+    __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre& pre, float (&t1)[4],
+                                                 float (&t2)[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xv = Elt<T>::from(pre.x[j]);
+            t1[j] = (relu_mask && !(xv > 0.f)) ? 0.f : a[j];
             t2[j] = t1[j] * Elt<T>::from(pre.r[j]);
         }
         const int64_t ub = (int64_t)un * ld_gp + um;
@@ -381,5 +436,46 @@ struct EpiDw {
         }
         *reinterpret_cast<f32x4*>(grad_mu + ub + ln.o) = gm;
         *reinterpret_cast<f32x4*>(grad_lv + ub + ln.o) = gl;
+    }
+
+    // ---- fold protocol: the two outputs depend on one accumulator each, so d/dlvars is FINISHED between the passes
+    // (its stores drain under the second pass) and the second pass starts from zero
+    static constexpr bool PARK = false;
+    struct FPre { f32x4 lv; };
+    __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
+        FPre p;
+        p.lv = *reinterpret_cast<const f32x4*>(lvars + ((int64_t)un * I + um) + ln.o);
+        return p;
+    }
+    __device__ __forceinline__ f32x4 fold(int um, int un, const Lane& ln, f32x4 a2, const FPre& fp) const {
+        const float var_hat = (float)stats[2];
+        const float invS = 1.0f / S;
+        const float k_lv = kl_scale / (2.0f * B);
+        const float inv_vh = 1.0f / var_hat;
+        f32x4 gl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float var = expf(fp.lv[j]);
+            gl[j] = fmaf(k_lv, fmaf(var, inv_vh, -1.0f), a2[j] * var * invS);
+        }
+        *reinterpret_cast<f32x4*>(grad_lv + ((int64_t)un * I + um) + ln.o) = gl;
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ Pre load_folded(int um, int un, const Lane& ln) const {
+        Pre p;
+        p.mu = *reinterpret_cast<const f32x4*>(means + ((int64_t)un * I + um) + ln.o);
+        p.lv = f32x4{0.f, 0.f, 0.f, 0.f};
+        return p;
+    }
+    __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre& pre, float (&t1)[4],
+                                                 float (&t2)[4]) const {
+        (void)t1; (void)t2;
+        const float var_hat = (float)stats[2];
+        const float invS = 1.0f / S;
+        const float k_mu = kl_scale / (B * var_hat);
+        f32x4 gm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gm[j] = fmaf(k_mu, pre.mu[j], scale * a[j] * invS);
+        *reinterpret_cast<f32x4*>(grad_mu + ((int64_t)un * I + um) + ln.o) = gm;
     }
 };

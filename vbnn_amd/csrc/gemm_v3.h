@@ -1,15 +1,19 @@
 // gemm_v3.h -- the 256 x 256 two-pass variant of the pipelined bf16 GEMM (gfx950 only), for outputs with at least
 // ~one such tile per CU (the 4096^2 layers of the wide configuration).
 //
-//   pass 1   C1[m][n] = sum_k A [m][k] Bt [n][k]      (the mean GEMM of the pair)
-//   pass 2   C2[m][n] = sum_k A2[m][k] Bt2[n][k]      (the variance GEMM; DUAL only)
+//   pass 1   C2[m][n] = sum_k A2[m][k] Bt2[n][k]      (the variance GEMM of the pair; DUAL only)
+//   fold     acc := f(C2)  in registers              (FWD: b + sqrt(v) z; DX: 2 x . C2; DW: stores d/dlvars, 0)
+//   pass 2   acc += sum_k A [m][k] Bt [n][k]         (the mean GEMM, accumulated ON TOP of the folded term)
 //
 // Why: gemm_v2's dual 256 x 128 tile needs 47.7 B/clk/CU of LDS-DMA at full MFMA rate (two accumulators per output
 // cap its tile). One accumulator per output allows 256 x 256: 32 B/clk/CU, a third fewer DMAs and a quarter fewer
-// ds_reads per MFMA -- what the vendor library's 256x256x64 macro-tile runs on. The pair's two GEMMs then run one
-// after the other in the SAME workgroup: pass 1's tile is parked as it stands (MFMA register layout) in a
-// per-workgroup fp32 scratch tile (256 KiB, written and read back by the same thread: stays in L2/MALL), pass 2
-// accumulates the second GEMM, and the fused epilogue (epilogues.h, unchanged) sees both.
+// ds_reads per MFMA -- what the vendor library's 256x256x64 macro-tile runs on. Every output of the three epilogues
+// is LINEAR in the mean GEMM once the variance GEMM is known (y = m + [b + sqrt(v) z], gx = g mu + [2 x . gv s2],
+// d/dmeans and d/dlvars depend on one GEMM each), so the pair runs as two passes of the SAME workgroup over the same
+// accumulator registers and, for DX and DW, nothing is parked in between. (FWD's term needs a Philox block per quad;
+// 32 of them beside 128 live accumulators spill, so FWD parks the variance tile as it stands in a per-workgroup
+// scratch tile -- 256 KiB, written and read back by the same thread, served by L2/MALL -- and applies the noise in
+// the final epilogue: 128 MB per launch of extra cache traffic, 10-15 us.)
 //
 //   workgroup   8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = acc[8][4] (128 accumulator registers)
 //   K step      64 bf16 (128-B rows, the swizzle of gemm_v2.h), two PHASES of 32 MFMAs per wave:
@@ -28,7 +32,6 @@ constexpr int V3_BM = 256, V3_BN = 256;
 constexpr int V3_APART = 128 * 128;                  // bytes: 128 rows x 128 B
 constexpr int V3_BTILE = 256 * 128;
 constexpr int V3_LDS = 4 * V3_APART + 3 * V3_BTILE;  // 163840: all of the CU's LDS
-constexpr int V3_SCRATCH_FLOATS = V3_BM * V3_BN;     // per workgroup
 
 template <> __device__ __forceinline__ void v2_wait_vmcnt<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 template <> __device__ __forceinline__ void v2_wait_vmcnt<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     };
 
     // ---- epilogue: the LDS re-layout of gemm_v2.h, one QUARTER of the wave tile (64 m x 32 n) at a time -- a whole
-    // 128 x 64 tile's rows plus the parked pass-1 rows would not fit the register file beside the accumulators.
+    // 128 x 64 tile's rows would not fit the register file beside the accumulators.
     // Quarter qq = (hh, jj): m-blocks 4 hh .. 4 hh + 3, n-blocks 2 jj, 2 jj + 1. Per wave 18944 B of LDS:
     // fp32 rows [32 n][SP] + two transposed staging tiles [64 m][TQ] in the operand type.
     typedef typename Epi::elem_t ET;
@@ -212,26 +215,48 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
 #pragma unroll
         for (int p = 0; p < 8; ++p) rows[p] = *reinterpret_cast<const f32x4*>(st + (4 * p + q4) * SP + 4 * c16);
     };
-    f32x4* park = reinterpret_cast<f32x4*>(mscratch + (size_t)blockIdx.x * V3_SCRATCH_FLOATS);   // [8 i][4 j][512] f32x4
     const typename Epi::Lane eln = epi.lane_init(q4, 4 * c16);
 
+    // PARK functors only: this workgroup's scratch tile, [8 i][4 j][512 threads] f32x4, written and read by the same thread
+    f32x4* park = reinterpret_cast<f32x4*>(mscratch + (size_t)blockIdx.x * (V3_BM * V3_BN));
     auto for_quarters = [&](auto&& fn) {
         fn(c0, c0, 0); fn(c0, c1, 1); fn(c1, c0, 2); fn(c1, c1, 3);
     };
 
-    zero_acc();
-    run_pass();
     if (DUAL) {
-        // Pass 1's tile parks in this workgroup's scratch tile as it stands (MFMA layout, one coalesced 16-byte store
-        // per accumulator quad): no LDS, so nothing but one barrier separates the passes. The stores are older than
-        // pass 2's DMAs on the in-order vmcnt counter: the counted waits of run_pass only get stricter.
-        __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) (park + (i * 4 + j) * 512)[tid] = acc[i][j];
-        zero_acc();
+        // The pair as two passes over ONE accumulator (the functor's FOLD protocol, epilogues.h): the pair's second GEMM
+        // first; then every accumulator quad, as it stands in the MFMA layout (lane (q4, c16): 4 consecutive m at one n),
+        // is turned into the term the first GEMM accumulates on top of -- in registers, no LDS, nothing parked.
         Ap = A2; Bp = B2;
+        zero_acc();
+        run_pass();
+        // opaque to the optimiser from here on: otherwise the fold's address / counter arithmetic is hoisted above
+        // pass 1 and held live through its loop, which is already at the register limit (it spilled)
+        int fc16 = c16, fq4 = q4, fm0 = m0 + wr * 128, fn0 = n0 + wc * 64;
+        asm volatile("" : "+v"(fc16), "+v"(fq4), "+s"(fm0), "+s"(fn0));
+        const typename Epi::Lane fln = epi.lane_init(fc16, 4 * fq4);
+        if (Epi::PARK) {                                      // acc2 as it stands: one coalesced 16-byte store per quad
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) (park + (i * 4 + j) * 512)[tid] = acc[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                         // one m-block (4 quads) at a time: its loads fly together
+            typename Epi::FPre fp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fp[j] = epi.fold_load(fm0 + 16 * i, fn0 + 16 * j, fln);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = epi.fold(fm0 + 16 * i, fn0 + 16 * j, fln, acc[i][j], fp[j]);
+                __builtin_amdgcn_sched_barrier(0);            // one quad at a time: 32 interleaved Philox blocks spill
+            }
+        }
+        __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
+        Ap = A; Bp = B;
+        run_pass();                                           // fold's stores are older than these DMAs: the counted
+    } else {                                                  // waits only get stricter
+        zero_acc();
         run_pass();
     }
     __syncthreads();
@@ -243,19 +268,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         constexpr int HH = decltype(hh_c)::value, JJ = decltype(jj_c)::value;
         const int wm0 = m0 + wr * 128 + HH * 64, wn0 = n0 + wc * 64 + JJ * 32;
         (void)qq;
-        f32x4 r1[8], r2[8], av[8];
+        f32x4 r1[8], av[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl) av[2 * i + jl] = acc[4 * HH + i][2 * JJ + jl];
-        if (DUAL) {
-            f32x4 mv[8];                                      // the parked pass-1 quarter: loads fly during the first trip
+        f32x4 r2[8];
+        if (DUAL && Epi::PARK) {
+            f32x4 sv[8];                                      // the parked acc2 quarter: its loads fly during the first trip
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jl = 0; jl < 2; ++jl) mv[2 * i + jl] = (park + ((4 * HH + i) * 4 + 2 * JJ + jl) * 512)[tid];
-            relayout(av, r2);
-            relayout(mv, r1);
+                for (int jl = 0; jl < 2; ++jl) sv[2 * i + jl] = (park + ((4 * HH + i) * 4 + 2 * JJ + jl) * 512)[tid];
+            relayout(av, r1);
+            relayout(sv, r2);
         } else {
             relayout(av, r1);
 #pragma unroll
@@ -268,12 +294,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         for (int p0 = 0; p0 < 8; p0 += FB) {
             typename Epi::Pre pre[FB];
 #pragma unroll
-            for (int b = 0; b < FB; ++b) pre[b] = epi.load_fast(wm0, wn0 + 4 * (p0 + b), eln);
+            for (int b = 0; b < FB; ++b)
+                pre[b] = DUAL ? epi.load_folded(wm0, wn0 + 4 * (p0 + b), eln) : epi.load_fast(wm0, wn0 + 4 * (p0 + b), eln);
 #pragma unroll
             for (int b = 0; b < FB; ++b) {
                 const int p = p0 + b;
                 float t1[4], t2[4];
-                epi.apply_fast(wm0, wn0 + 4 * p, eln, r1[p], r2[p], pre[b], t1, t2);
+                if (DUAL) epi.apply_folded(wm0, wn0 + 4 * p, eln, r1[p], r2[p], pre[b], t1, t2);
+                else epi.apply_fast(wm0, wn0 + 4 * p, eln, r1[p], f32x4{0.f, 0.f, 0.f, 0.f}, pre[b], t1, t2);
                 if (any_t) {
                     // 8-element chunks XOR-swizzled by the row's c16 & 3 (rows 4 apart would otherwise share banks)
                     const int nl = 4 * p + q4;
@@ -317,7 +345,7 @@ static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t lda, int64_t l
            M * e.t_ld() < (1ll << 31);
 }
 // worth it when the tiling gives (almost) every CU one tile, no more than one round of them, and K is long enough
-// to amortise the second prologue and the parking of pass 1 (measured: 4096^3 -16 us on the forward; K = 784 +12 us)
+// to amortise the second prologue and the fold between the passes (measured: 4096^3 -16 us on the forward; K = 784 +12 us)
 template <class Epi>
 static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, const Epi& epi) {
     const int64_t t = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
@@ -342,8 +370,8 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         }
         if (!gemm_v3_possible(M, N, lda, ldb, epi)) { vbnn_set_error("gemm_v3: shape / outputs outside its fast path"); return VBNN_ERR_UNSUPPORTED; }
         const int tiles_m = (M + V3_BM - 1) / V3_BM, tiles_n = (N + V3_BN - 1) / V3_BN;
-        const size_t need = DUAL ? (size_t)tiles_m * tiles_n * V3_SCRATCH_FLOATS * sizeof(float) : 0;
-        if (need > ctx->park_bytes) {                        // the parking tiles of pass 1 (grown on demand, kept)
+        const size_t need = (DUAL && Epi::PARK) ? (size_t)tiles_m * tiles_n * V3_BM * V3_BN * sizeof(float) : 0;
+        if (need > ctx->park_bytes) {                        // the parking tiles (grown on demand, kept)
             (void)hipStreamSynchronize(ctx->stream);
             if (ctx->park) (void)hipFree(ctx->park);
             ctx->park = nullptr; ctx->park_bytes = 0;
@@ -351,6 +379,7 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
             if (e != hipSuccess) { vbnn_set_error("hipMalloc(gemm_v3 scratch, %zu bytes): %s", need, hipGetErrorString(e)); return VBNN_ERR_NOMEM; }
             ctx->park_bytes = need;
         }
+        float* park = ctx->park;
         const void* kern = (const void*)gemm_nt_v3<DUAL, Epi>;
         static bool configured = false;                      // per instantiation
         if (!configured) {
@@ -362,7 +391,6 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         const bf16_t* b = (const bf16_t*)B; const bf16_t* b2 = (const bf16_t*)B2;
         int nk_ = nk, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
         int64_t lda_ = lda, ldb_ = ldb;
-        float* park = ctx->park;
         Epi epi_ = epi;
         void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &park, &epi_};
         hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n), dim3(512), args, V3_LDS, ctx->stream);
