@@ -189,6 +189,22 @@ int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, const float* l
                     void* mu_s, void* var_s, int64_t ld_w, void* muT_s, void* varT_s, int64_t ld_wT,
                     double* stats);
 
+/* The same sweep for every VB layer of a model in ONE call (n_layers <= 8), plus optionally the plain packing of one
+ * more small f32 matrix (the final nn.Linear's weight, mlp.lua:29: dst rows x ld_dst and its transpose cols x
+ * ld_dstT, either may be NULL): one sweep kernel per layer and a single finish kernel for all the statistics and the
+ * extra matrix -- two launches fewer per step than n_layers x vbnn_prep_layer + vbnn_pack. */
+typedef struct vbnn_prep_desc {
+    const float* means; const float* lvars; int64_t O, I;
+    void* mu_s; void* var_s; int64_t ld_w;
+    void* muT_s; void* varT_s; int64_t ld_wT;      /* NULL / 0: no transposed shadows */
+    double* stats;
+} vbnn_prep_desc;
+typedef struct vbnn_pack_desc {
+    const float* src; int64_t rows, cols, ld_src;
+    void* dst; int64_t ld_dst; void* dstT; int64_t ld_dstT;
+} vbnn_pack_desc;
+int vbnn_prepare(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_prep_desc* layers, const vbnn_pack_desc* extra);
+
 /* ---- KL ("LC") terms ------------------------------------------------------------------------ */
 
 /* VBLinear:compute_mugrads (VBLinear.lua:90-93): gradWeight /= S in place; lcg = means / (B var_hat).

@@ -88,6 +88,17 @@ int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, in
 int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, const float* lvars, int64_t O, int64_t I,
                     void* mu_s, void* var_s, int64_t ld_w, void* muT_s, void* varT_s, int64_t ld_wT,
                     double* stats);
+typedef struct vbnn_prep_desc {
+    const float* means; const float* lvars; int64_t O, I;
+    void* mu_s; void* var_s; int64_t ld_w;
+    void* muT_s; void* varT_s; int64_t ld_wT;
+    double* stats;
+} vbnn_prep_desc;
+typedef struct vbnn_pack_desc {
+    const float* src; int64_t rows, cols, ld_src;
+    void* dst; int64_t ld_dst; void* dstT; int64_t ld_dstT;
+} vbnn_pack_desc;
+int vbnn_prepare(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_prep_desc* layers, const vbnn_pack_desc* extra);
 int vbnn_compute_mugrads(vbnn_ctx* ctx, const float* means, const double* stats, float B, float S,
                          float* gradWeight, float* lcg, int64_t W);
 int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, const float* stdv,

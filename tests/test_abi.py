@@ -59,9 +59,10 @@ def test_product_path_does_not_import_the_oracle():
 
 
 def test_ctypes_structs_match_the_header():
-    """Compile a C program against the header that prints sizeof/offsetof of the three argument blocks."""
+    """Compile a C program against the header that prints sizeof/offsetof of every argument block."""
     from vbnn_amd import _lib as L
-    structs = {"vbnn_fwd_args": L.FwdArgs, "vbnn_dx_args": L.DxArgs, "vbnn_dw_args": L.DwArgs}
+    structs = {"vbnn_fwd_args": L.FwdArgs, "vbnn_dx_args": L.DxArgs, "vbnn_dw_args": L.DwArgs,
+               "vbnn_prep_desc": L.PrepDesc, "vbnn_pack_desc": L.PackDesc}
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -40,6 +40,16 @@ class DxArgs(C.Structure):
                 ("gT_prev", _vp), ("gvT_prev", _vp), ("ld_gpT", _i64)]
 
 
+class PrepDesc(C.Structure):          # vbnn_prep_desc
+    _fields_ = [("means", _vp), ("lvars", _vp), ("O", _i64), ("I", _i64), ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64),
+                ("muT_s", _vp), ("varT_s", _vp), ("ld_wT", _i64), ("stats", _vp)]
+
+
+class PackDesc(C.Structure):          # vbnn_pack_desc
+    _fields_ = [("src", _vp), ("rows", _i64), ("cols", _i64), ("ld_src", _i64), ("dst", _vp), ("ld_dst", _i64),
+                ("dstT", _vp), ("ld_dstT", _i64)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [("xT", _vp), ("x2T", _vp), ("gT", _vp), ("gvT", _vp), ("ld_n", _i64),
                 ("N", _i64), ("I", _i64), ("O", _i64), ("scale", _f), ("accumulate", _i),
@@ -79,6 +89,7 @@ _SIGS = {
     "vbnn_relu_forward": ([_vp, _vp, _vp, _i64], _i),
     "vbnn_relu_backward": ([_vp, _vp, _vp, _vp, _i64], _i),
     "vbnn_logsoftmax_nll": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp], _i),
+    "vbnn_prepare": ([_vp, _i, _i, _vp, _vp], _i),
     "vbnn_head_forward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _f, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "vbnn_head_backward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp,
                            _vp, _i64, _vp, _vp, _i64], _i),

@@ -91,13 +91,17 @@ __global__ __launch_bounds__(256) void k_prior_partial(const float* __restrict__
     const double r2 = block_sum(s2, sh);
     if (threadIdx.x == 0) { partial[blockIdx.x * 2] = r1; partial[blockIdx.x * 2 + 1] = r2; }
 }
-__global__ __launch_bounds__(256) void k_prior_finish(const double* partial, int nblocks, int64_t W, double* stats) {
-    __shared__ double sh[4];
+// the deterministic finish of the prior sums: one block adds the block partials in a fixed order
+__device__ __forceinline__ void prior_finish(const double* partial, int nblocks, int64_t W, double* stats, double* sh) {
     double s1 = 0.0, s2 = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) { s1 += partial[b * 2]; s2 += partial[b * 2 + 1]; }
     const double r1 = block_sum(s1, sh);
     const double r2 = block_sum(s2, sh);
     if (threadIdx.x == 0) { stats[0] = r1; stats[1] = r2; stats[2] = (1.0 / (double)W) * r1; stats[3] = (double)W; }
+}
+__global__ __launch_bounds__(256) void k_prior_finish(const double* partial, int nblocks, int64_t W, double* stats) {
+    __shared__ double sh[4];
+    prior_finish(partial, nblocks, W, stats, sh);
 }
 
 extern "C" int vbnn_compute_prior(vbnn_ctx* ctx, const float* means, const float* lvars, int64_t W, float* vars,
@@ -614,6 +618,71 @@ extern "C" int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, con
     else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_prior_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->scratch, nb, O * I, stats);
     return vbnn_check_launch("k_prep_layer");
+    VBNN_API_END
+}
+
+// vbnn_prepare: every layer's sweep, then ONE finish kernel: block l < n finishes layer l's statistics, the blocks
+// after them copy-pack the extra matrix (and its transpose).
+struct PrepFinishArgs {
+    const double* partial[8]; int nb[8]; int64_t W[8]; double* stats[8]; int n;
+    const float* src; int64_t rows, cols, ld_src; void* dst; int64_t ld_dst; void* dstT; int64_t ld_dstT;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_prepare_finish(PrepFinishArgs a) {
+    __shared__ double sh[4];
+    if ((int)blockIdx.x < a.n) {
+        prior_finish(a.partial[blockIdx.x], a.nb[blockIdx.x], a.W[blockIdx.x], a.stats[blockIdx.x], sh);
+        return;
+    }
+    T* dst = (T*)a.dst;
+    T* dstT = (T*)a.dstT;
+    const int64_t total = a.rows * a.cols;
+    for (int64_t t = (int64_t)(blockIdx.x - a.n) * 256 + threadIdx.x; t < total; t += (int64_t)(gridDim.x - a.n) * 256) {
+        const int64_t r = t / a.cols, c = t - r * a.cols;
+        const T v = Elt<T>::to(a.src[r * a.ld_src + c]);
+        if (dst) dst[r * a.ld_dst + c] = v;
+        if (dstT) dstT[c * a.ld_dstT + r] = v;
+    }
+}
+
+extern "C" int vbnn_prepare(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_prep_desc* layers, const vbnn_pack_desc* extra) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && (layers || n_layers == 0), "null argument");
+    VBNN_REQUIRE(n_layers >= 0 && n_layers <= 8, "n_layers (0..8)");
+    VBNN_REQUIRE(dtype == VBNN_F32 || dtype == VBNN_BF16, "dtype");
+    VBNN_REQUIRE((size_t)n_layers * 4096 <= ctx->scratch_doubles, "scratch");
+    PrepFinishArgs fa{};
+    fa.n = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        const vbnn_prep_desc& d = layers[l];
+        VBNN_REQUIRE(d.means && d.lvars && d.mu_s && d.var_s && d.stats, "null layer argument");
+        VBNN_REQUIRE((d.muT_s == nullptr) == (d.varT_s == nullptr), "muT_s and varT_s go together");
+        VBNN_REQUIRE(d.O > 0 && d.I > 0 && d.ld_w >= d.I && (!d.muT_s || d.ld_wT >= d.O), "layer shape");
+        const int64_t ntiles = ((d.O + 63) / 64) * ((d.I + 63) / 64);
+        const int nb = (int)(ntiles < 2048 ? ntiles : 2048);
+        double* partial = ctx->scratch + (size_t)l * 4096;
+        if (dtype == VBNN_F32)
+            hipLaunchKernelGGL(k_prep_layer<float>, dim3(nb), dim3(256), 0, ctx->stream, d.means, d.lvars, d.O, d.I, (float*)d.mu_s,
+                               (float*)d.var_s, d.ld_w, (float*)d.muT_s, (float*)d.varT_s, d.ld_wT, partial);
+        else
+            hipLaunchKernelGGL(k_prep_layer<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, d.means, d.lvars, d.O, d.I,
+                               (bf16_t*)d.mu_s, (bf16_t*)d.var_s, d.ld_w, (bf16_t*)d.muT_s, (bf16_t*)d.varT_s, d.ld_wT, partial);
+        fa.partial[l] = partial; fa.nb[l] = nb; fa.W[l] = d.O * d.I; fa.stats[l] = d.stats;
+    }
+    int pack_blocks = 0;
+    if (extra) {
+        VBNN_REQUIRE(extra->src && extra->rows > 0 && extra->cols > 0 && extra->ld_src >= extra->cols, "extra matrix");
+        VBNN_REQUIRE(!extra->dst || extra->ld_dst >= extra->cols, "extra ld_dst");
+        VBNN_REQUIRE(!extra->dstT || extra->ld_dstT >= extra->rows, "extra ld_dstT");
+        fa.src = extra->src; fa.rows = extra->rows; fa.cols = extra->cols; fa.ld_src = extra->ld_src;
+        fa.dst = extra->dst; fa.ld_dst = extra->ld_dst; fa.dstT = extra->dstT; fa.ld_dstT = extra->ld_dstT;
+        pack_blocks = grid_for(extra->rows * extra->cols, 1024);
+    }
+    if (n_layers + pack_blocks > 0) {
+        if (dtype == VBNN_F32) hipLaunchKernelGGL(k_prepare_finish<float>, dim3(n_layers + pack_blocks), dim3(256), 0, ctx->stream, fa);
+        else hipLaunchKernelGGL(k_prepare_finish<bf16_t>, dim3(n_layers + pack_blocks), dim3(256), 0, ctx->stream, fa);
+    }
+    return vbnn_check_launch("vbnn_prepare");
     VBNN_API_END
 }
 

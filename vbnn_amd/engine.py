@@ -145,15 +145,19 @@ class FusedMLP:
     # fused with the packing of the GEMM shadows.
     def prepare(self):
         lib = L.lib()
+        if self.mode == "lrt":                                # one call: a sweep per layer + ONE finish kernel
+            descs = (L.PrepDesc * len(self.vb))()
+            for k, v in enumerate(self.vb):
+                descs[k] = L.PrepDesc(means=_p(v.means), lvars=_p(v.lvars), O=v.O, I=v.I, mu_s=v.mu_s.ptr, var_s=v.var_s.ptr,
+                                      ld_w=v.mu_s.ld, muT_s=v.muT_s.ptr if v.muT_s else None,
+                                      varT_s=v.varT_s.ptr if v.varT_s else None, ld_wT=v.muT_s.ld if v.muT_s else 0,
+                                      stats=_p(v.stats))
+            w3 = L.PackDesc(src=_p(self.weight3), rows=self.n_classes, cols=self.sizes[-1], ld_src=self.sizes[-1],
+                            dst=self.w3_s.ptr, ld_dst=self.w3_s.ld, dstT=self.w3T_s.ptr, ld_dstT=self.w3T_s.ld)
+            L.check(lib.vbnn_prepare(self.ctx.h, self.code, len(self.vb), descs, C.byref(w3)))
+            return
         for v in self.vb:
-            if self.mode == "lrt":
-                L.check(lib.vbnn_prep_layer(self.ctx.h, self.code, _p(v.means), _p(v.lvars), v.O, v.I, v.mu_s.ptr,
-                                            v.var_s.ptr, v.mu_s.ld, v.muT_s.ptr if v.muT_s else None,
-                                            v.varT_s.ptr if v.varT_s else None, v.muT_s.ld if v.muT_s else 0,
-                                            _p(v.stats)))
-            else:
-                L.check(lib.vbnn_compute_prior(self.ctx.h, _p(v.means), _p(v.lvars), v.O * v.I, None, None, None,
-                                               _p(v.stats)))
+            L.check(lib.vbnn_compute_prior(self.ctx.h, _p(v.means), _p(v.lvars), v.O * v.I, None, None, None, _p(v.stats)))
         L.check(lib.vbnn_pack(self.ctx.h, self.code, L.PACK_COPY, _p(self.weight3), None, self.sizes[-1],
                               self.n_classes, self.sizes[-1], self.w3_s.ptr, self.w3_s.ld, self.w3T_s.ptr, self.w3T_s.ld))
 
