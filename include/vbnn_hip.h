@@ -172,6 +172,10 @@ typedef struct vbnn_dw_args {
      * VBLinear.lua:90-98 folded into the epilogue; NULL to skip. Needs means, lvars, stats. */
     float* grad_mu; float* grad_lv;
     const float* means; const double* stats; float B; float S; float kl_scale;
+    /* optional: the bias gradient from the same GEMM. xT (and x2T) then have I + 1 rows, row I of xT all ones (row I
+     * of x2T anything finite): output row I of the first GEMM is sum_n g[n][o], written as
+     * gradBias[o] (+)= scale * that -- what vbnn_acc_grad_bias(g) gives, without another pass over g. NULL: off. */
+    float* gradBias;
 } vbnn_dw_args;
 
 /* accGradParameters (VBLinear.lua:112-118), one GEMM instead of the reference's two. */

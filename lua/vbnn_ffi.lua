@@ -81,6 +81,7 @@ typedef struct vbnn_dw_args {
     const float* lvars;
     float* grad_mu; float* grad_lv;
     const float* means; const double* stats; float B; float S; float kl_scale;
+    float* gradBias;
 } vbnn_dw_args;
 int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
 int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O,

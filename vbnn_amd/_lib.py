@@ -55,7 +55,7 @@ class DwArgs(C.Structure):
                 ("N", _i64), ("I", _i64), ("O", _i64), ("scale", _f), ("accumulate", _i),
                 ("gradWeight", _vp), ("gradSum", _vp), ("seed", _u64), ("layer", _u32), ("draw", _u32),
                 ("lvars", _vp), ("grad_mu", _vp), ("grad_lv", _vp), ("means", _vp), ("stats", _vp),
-                ("B", _f), ("S", _f), ("kl_scale", _f)]
+                ("B", _f), ("S", _f), ("kl_scale", _f), ("gradBias", _vp)]
 
 
 _SIGS = {

@@ -321,6 +321,7 @@ struct EpiDw {
     const float* lvars;
     float* grad_mu; float* grad_lv;
     const float* means; const double* stats; float B, S, kl_scale;
+    float* gradBias;         // optional: the GEMM has one more A row (all ones) whose output row is the bias gradient
     int I, O;
 
     __host__ __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
@@ -337,6 +338,10 @@ struct EpiDw {
 
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a1, f32x4 a2) const {
         const int valid = min(4, I - m);
+        if (gradBias && n < O && m <= I && I < m + 4) {      // the quad that holds the ones row m = I
+            const float s = scale * a1[I - m];
+            gradBias[n] = accumulate ? gradBias[n] + s : s;
+        }
         if (valid <= 0 || n >= O) return;
         const int64_t base = (int64_t)n * I + m;
         float e[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f}, var[4] = {0.f, 0.f, 0.f, 0.f};

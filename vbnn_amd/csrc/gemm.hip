@@ -85,9 +85,11 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
     e.lvars = a->lvars;
     e.grad_mu = a->grad_mu; e.grad_lv = a->grad_lv;
     e.means = a->means; e.stats = a->stats; e.B = a->B; e.S = a->S; e.kl_scale = a->kl_scale;
+    e.gradBias = a->gradBias;
     e.I = (int)a->I; e.O = (int)a->O;
-    if (a->x2T) return launch_gemm<T, true>(ctx, a->xT, a->x2T, a->ld_n, a->gT, a->gvT, a->ld_n, a->I, a->O, a->N, e);
-    return launch_gemm<T, false>(ctx, a->xT, nullptr, a->ld_n, a->gT, nullptr, a->ld_n, a->I, a->O, a->N, e);
+    const int64_t M = a->I + (a->gradBias ? 1 : 0);          // the ones row of xT rides along as one more output row
+    if (a->x2T) return launch_gemm<T, true>(ctx, a->xT, a->x2T, a->ld_n, a->gT, a->gvT, a->ld_n, M, a->O, a->N, e);
+    return launch_gemm<T, false>(ctx, a->xT, nullptr, a->ld_n, a->gT, nullptr, a->ld_n, M, a->O, a->N, e);
 }
 
 extern "C" int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a) {

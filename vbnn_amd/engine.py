@@ -123,7 +123,15 @@ class FusedMLP:
         dev, tdt = self.device, self.tdt
         for v in self.vb:
             v.x_s, v.x2_s = _Packed(N, v.I, tdt, dev), _Packed(N, v.I, tdt, dev)
-            v.xT_s, v.x2T_s = _Packed(v.I, N, tdt, dev), _Packed(v.I, N, tdt, dev)
+            # Layers whose parameter-gradient GEMM is not the whole-tile 256 x 256 kernel anyway (I % 256 != 0: the
+            # 784-wide input layer) get their bias gradient from that GEMM: x^T carries one more row, all ones, whose
+            # output row is sum_n g[n][o] (vbnn_dw_args.gradBias). Written once here: the packers only touch rows < I.
+            last_fused = (v is self.vb[-1]) and self.n_classes <= 16
+            v.bias_from_dw = (v.I % 256 != 0) and not last_fused
+            extra = 1 if v.bias_from_dw else 0
+            v.xT_s, v.x2T_s = _Packed(v.I + extra, N, tdt, dev), _Packed(v.I + extra, N, tdt, dev)
+            if v.bias_from_dw:
+                v.xT_s.t[v.I, :N] = 1.0
             v.g_s, v.gv_s = _Packed(N, v.O, tdt, dev), _Packed(N, v.O, tdt, dev)
             v.gT_s, v.gvT_s = _Packed(v.O, N, tdt, dev), _Packed(v.O, N, tdt, dev)
             v.r = torch.zeros(N, v.O, dtype=tdt, device=dev)          # z / (2 sqrt(v)), stored in the operand type
@@ -287,6 +295,7 @@ class FusedMLP:
             d.B, d.S, d.kl_scale = self.B, self.S, 1.0 / self.world
         else:
             d.gradWeight, d.gradSum = _p(v.gradWeight), _p(v.gradSum)
+        d.gradBias = _p(v.gradBias) if v.bias_from_dw else None
         return d
 
     def _dx_args(self, li, N):
@@ -349,7 +358,8 @@ class FusedMLP:
                 d = self._dw_args(li, N, accumulate)
                 with self._probed("accGradParameters", li):
                     L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
-                if not (fused_head and li == nl - 1):        # the fused head already summed the last layer's g columns
+                # the fused head already summed the last layer's g columns; ones-row layers got theirs from the GEMM
+                if not (fused_head and li == nl - 1) and not v.bias_from_dw:
                     L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
                 self._reduce(v.bucket)
                 if li > 0:
@@ -365,7 +375,7 @@ class FusedMLP:
                 side.wait_event(ready)
                 d = self._dw_args(li, N, accumulate)
                 L.check(lib.vbnn_acc_grad_parameters(ctx2, code, C.byref(d)))
-                if not (fused_head and li == nl - 1):
+                if not (fused_head and li == nl - 1) and not v.bias_from_dw:
                     L.check(lib.vbnn_acc_grad_bias(ctx2, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
                 with torch.cuda.stream(side):
                     self._reduce(v.bucket)                   # RCCL orders itself after the side stream
