@@ -52,6 +52,9 @@ typedef struct { float v[4]; } vbnn_f32x4;
 /* Philox4x32-10: 10 rounds, key bumped by the Weyl constants between rounds. */
 VBNN_HD vbnn_u32x4 vbnn_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                       uint32_t k0, uint32_t k1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)VBNN_PHILOX_M0 * (uint64_t)c0;
         const uint64_t p1 = (uint64_t)VBNN_PHILOX_M1 * (uint64_t)c2;

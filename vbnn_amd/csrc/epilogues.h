@@ -170,7 +170,47 @@ struct EpiFwd {
         if (h2) store4<T>(h2 + ub + ln.oh, t2[0], t2[1], t2[2], t2[3], 4, true);
     }
 
-    // ---- fold protocol (LRT only: acc2 = v). PARK: the kernel keeps v aside, the accumulator continues from the bias
+    // ---- fold protocol (LRT only: acc2 = v)
+#ifndef VBNN_FWD_PARK           // default: the noise term b + sqrt(v) z (and r) is formed between the passes
+    static constexpr bool PARK = false;
+    struct FPre { f32x4 b; };
+    __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
+        (void)un;
+        FPre p;
+        p.b = bias ? *reinterpret_cast<const f32x4*>(bias + um + ln.ml) : f32x4{0.f, 0.f, 0.f, 0.f};
+        return p;
+    }
+    __device__ __forceinline__ f32x4 fold(int um, int un, const Lane& ln, f32x4 v, const FPre& fp) const {
+        const vbnn_f32x4 z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        f32x4 out;
+        float rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = v[j] > 0.f;
+            const float rs = __builtin_amdgcn_rsqf(v[j]);
+            const float sd = pos ? v[j] * rs : 0.f;
+            out[j] = fmaf(sd, z.v[j], fp.b[j]);
+            rv[j] = pos ? 0.5f * z.v[j] * rs : 0.f;
+        }
+        if (r_t) store4<T>(r_t + ((int64_t)un * ld_r + um) + ln.orr, rv[0], rv[1], rv[2], rv[3], 4, true);
+        return out;
+    }
+    __device__ __forceinline__ Pre load_folded(int, int, const Lane&) const { return Pre{f32x4{0.f, 0.f, 0.f, 0.f}}; }
+    __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre&, float (&t1)[4],
+                                                 float (&t2)[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t1[j] = relu ? fmaxf(a[j], 0.f) : a[j];
+            const float hr = Elt<T>::from(Elt<T>::to(t1[j]));
+            t2[j] = hr * hr;
+        }
+        const int64_t ub = (int64_t)un * ld_h + um;
+        store4<T>(h + ub + ln.oh, t1[0], t1[1], t1[2], t1[3], 4, true);
+        if (h2) store4<T>(h2 + ub + ln.oh, t2[0], t2[1], t2[2], t2[3], 4, true);
+    }
+#else
+    // -DVBNN_FWD_PARK (A/B only): the kernel parks the raw variance tile in a scratch tile, the accumulator continues
+    // from the bias, the noise is applied in the final epilogue (+128 MB of L2/MALL traffic per launch)
     static constexpr bool PARK = true;
     struct FPre { f32x4 b; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
@@ -185,6 +225,7 @@ struct EpiFwd {
                                                  float (&t2)[4]) const {
         apply_fast(um, un, ln, a, v, pre, t1, t2);           // a = m + b already: pre.b is 0
     }
+#endif
 };
 
 // ---- DX: M = input units i, N = minibatch rows n ------------------------------------------------

@@ -241,17 +241,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) (park + (i * 4 + j) * 512)[tid] = acc[i][j];
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {                         // one m-block (4 quads) at a time: its loads fly together
+        // (indices as compile-time constants, not `#pragma unroll`: a loop the optimiser declines to unroll would
+        // index the accumulators dynamically and send all of them to scratch memory)
+        auto fold_block = [&](auto i_c) {                     // one m-block (4 quads) at a time: its loads fly together
+            constexpr int i = decltype(i_c)::value;
             typename Epi::FPre fp[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) fp[j] = epi.fold_load(fm0 + 16 * i, fn0 + 16 * j, fln);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[i][j] = epi.fold(fm0 + 16 * i, fn0 + 16 * j, fln, acc[i][j], fp[j]);
-                __builtin_amdgcn_sched_barrier(0);            // one quad at a time: 32 interleaved Philox blocks spill
+                // one quad at a time, also for the optimiser: the next quad's coordinates "depend" on this result
+                asm volatile("" : "+s"(fn0), "+s"(fm0) : "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
             }
-        }
+        };
+        fold_block(std::integral_constant<int, 0>()); fold_block(std::integral_constant<int, 1>());
+        fold_block(std::integral_constant<int, 2>()); fold_block(std::integral_constant<int, 3>());
+        fold_block(std::integral_constant<int, 4>()); fold_block(std::integral_constant<int, 5>());
+        fold_block(std::integral_constant<int, 6>()); fold_block(std::integral_constant<int, 7>());
         __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
         Ap = A; Bp = B;
         run_pass();                                           // fold's stores are older than these DMAs: the counted
@@ -345,11 +352,12 @@ static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t lda, int64_t l
            M * e.t_ld() < (1ll << 31);
 }
 // worth it when the tiling gives (almost) every CU one tile, no more than one round of them, and K is long enough
-// to amortise the second prologue and the fold between the passes (measured: 4096^3 -16 us on the forward; K = 784 +12 us)
+// to amortise the second pipeline fill and the fold between the passes (measured against gemm_v2's dual tile on
+// 4096 x 4096 outputs: K = 4096 forward 212 vs 252 us, K = 784 forward 93 vs 99 us)
 template <class Epi>
 static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, const Epi& epi) {
     const int64_t t = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
-    return gemm_v3_possible(M, N, lda, ldb, epi) && t >= 192 && t <= 256 && K >= 1536;
+    return gemm_v3_possible(M, N, lda, ldb, epi) && t >= 192 && t <= 256 && K >= 704;
 }
 
 template <typename T, bool DUAL, class Epi>
