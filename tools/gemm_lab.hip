@@ -28,6 +28,8 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
     }
     static constexpr int FAST_BATCH = 8;
     static constexpr bool PARK = false;
+    static constexpr int FOLD_BATCH = 8;
+    static constexpr bool FOLD_SERIAL = false;
     struct Pre {};
     struct FPre {};
     __device__ __forceinline__ FPre fold_load(int, int, const Lane&) const { return FPre{}; }

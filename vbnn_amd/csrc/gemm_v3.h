@@ -241,24 +241,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) (park + (i * 4 + j) * 512)[tid] = acc[i][j];
         }
-        // (indices as compile-time constants, not `#pragma unroll`: a loop the optimiser declines to unroll would
-        // index the accumulators dynamically and send all of them to scratch memory)
-        auto fold_block = [&](auto i_c) {                     // one m-block (4 quads) at a time: its loads fly together
-            constexpr int i = decltype(i_c)::value;
-            typename Epi::FPre fp[4];
+        // Quads are folded in batches of Epi::FOLD_BATCH m-blocks (4 quads each): a batch's loads fly together, ahead of
+        // their first use. (Indices are compile-time constants, not `#pragma unroll` loops over the m-blocks: a loop
+        // the optimiser declines to unroll would index the accumulators dynamically and send them all to scratch.)
+        auto fold_batch = [&](auto i0_c) {
+            constexpr int i0 = decltype(i0_c)::value;
+            constexpr int NB = Epi::FOLD_BATCH;
+            typename Epi::FPre fp[NB][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fp[j] = epi.fold_load(fm0 + 16 * i, fn0 + 16 * j, fln);
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = epi.fold(fm0 + 16 * i, fn0 + 16 * j, fln, acc[i][j], fp[j]);
-                // one quad at a time, also for the optimiser: the next quad's coordinates "depend" on this result
-                asm volatile("" : "+s"(fn0), "+s"(fm0) : "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
-            }
+                for (int j = 0; j < 4; ++j) fp[b][j] = epi.fold_load(fm0 + 16 * (i0 + b), fn0 + 16 * j, fln);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i0 + b][j] = epi.fold(fm0 + 16 * (i0 + b), fn0 + 16 * j, fln, acc[i0 + b][j], fp[b][j]);
+                    if (Epi::FOLD_SERIAL)       // one quad at a time, also for the optimiser: the next quad's coordinates
+                        asm volatile("" : "+s"(fn0), "+s"(fm0)          // "depend" on this result (32 interleaved Philox
+                                     : "v"(acc[i0 + b][j][0]), "v"(acc[i0 + b][j][1]),       // blocks beside 128 live
+                                       "v"(acc[i0 + b][j][2]), "v"(acc[i0 + b][j][3]));      // accumulators spill)
+                }
         };
-        fold_block(std::integral_constant<int, 0>()); fold_block(std::integral_constant<int, 1>());
-        fold_block(std::integral_constant<int, 2>()); fold_block(std::integral_constant<int, 3>());
-        fold_block(std::integral_constant<int, 4>()); fold_block(std::integral_constant<int, 5>());
-        fold_block(std::integral_constant<int, 6>()); fold_block(std::integral_constant<int, 7>());
+        static_assert(8 % Epi::FOLD_BATCH == 0, "FOLD_BATCH divides the 8 m-blocks of a wave tile");
+        fold_batch(std::integral_constant<int, 0>());
+        if constexpr (Epi::FOLD_BATCH < 8) fold_batch(std::integral_constant<int, Epi::FOLD_BATCH>());
+        if constexpr (Epi::FOLD_BATCH < 4) {
+            fold_batch(std::integral_constant<int, 2 * Epi::FOLD_BATCH>()); fold_batch(std::integral_constant<int, 3 * Epi::FOLD_BATCH>());
+        }
+        if constexpr (Epi::FOLD_BATCH < 2) {
+            fold_batch(std::integral_constant<int, 4>()); fold_batch(std::integral_constant<int, 5>());
+            fold_batch(std::integral_constant<int, 6>()); fold_batch(std::integral_constant<int, 7>());
+        }
         __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
         Ap = A; Bp = B;
         run_pass();                                           // fold's stores are older than these DMAs: the counted
