@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run accGradParameters on a second stream (A/B; slower)")
     ap.add_argument("--mode", default="lrt", choices=["lrt", "wn"])
+    ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +171,9 @@ def main():
     opt = dict(var_init=1e-3, B=1e6, S=1, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
                hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap)
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
+    for kv in filter(None, args.debug_set.split(",")):
+        k, v = kv.split("=")
+        L.check(L.lib().vbnn_debug_set(int(k), int(v)))
     # synthetic minibatch, resident in HBM: x ~ N(0,1) addressed by GLOBAL row, targets uniform in 0..9
     x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
     fill_normal(x, 3, L.STREAM_DATA, 0, 0, row0=rank * N)

@@ -53,8 +53,8 @@ const char* vbnn_last_error(void);
                                       2 = interleaved with the MFMAs, 4 = 2 with skewed SIMD partners (gemm_v2.h) */
 #define VBNN_DEBUG_V2_TILE 2       /* pipelined kernel block tile: 0 = by shape (default), 256 = 256 x 128, 128 = 128 x 128,
                                       64 = 128 x 128 with a 2-stage ring, two workgroups per CU */
-#define VBNN_DEBUG_V2_SPLITK 3     /* pipelined kernel split-K (two K halves per 256 x 128 tile): -1 = by shape (default),
-                                      0 = never, 1 = whenever possible */
+#define VBNN_DEBUG_V2_SPLITK 3     /* pipelined kernel split-K (two K halves per 256 x 128 tile): -1 / 0 = off (default: it
+                                      lost inside the step), 1 = whenever possible */
 int vbnn_debug_set(int key, int value);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream

@@ -442,12 +442,14 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         // of layer 1 (26 tile steps, then an epilogue as long as the main loop); measured 113 us against 110 us for
         // the 256 x 128 tile there (and 291 vs 257 us at K = 4096), so it is never picked automatically.
         const bool pairs = g_v2_tile == 64;
-        // Split-K: when the 256 x 128 tiling gives at most half the CUs a block and K is long, each tile is computed
-        // by TWO blocks, one per K half (the 784 x 4096 gradient: 128 tiles -> 256 blocks of 32 K steps; measured
-        // against the 128 x 128 tiling that was used before: see DESIGN.md). g_v2_split: -1 auto, 0 never, 1 whenever possible.
+        // Split-K: each 256 x 128 tile is computed by TWO blocks, one per K half. Meant for outputs that give at most
+        // half the CUs a block (the 784 x 4096 gradient: 128 tiles -> 256 blocks of 32 K steps). Measured against the
+        // 128 x 128 tiling: 92 vs 103 us back to back in isolation, but 10 us SLOWER inside the step (1.110 vs 1.098
+        // ms/step, twice each: the 96 MB partial-tile exchange meets cold caches there) -- so it is never picked by
+        // shape; vbnn_debug_set(VBNN_DEBUG_V2_SPLITK, 1) turns it on. g_v2_split: -1 / 0 off, 1 whenever possible.
         const bool can_split = t256 <= VBNN_CNT_TILES_MAX && nk >= 2;
         const bool split = !pairs && g_v2_tile != 128 && can_split &&
-                           (g_v2_split == 1 || (g_v2_split == -1 && g_v2_tile == 0 && t256 <= 128 && nk >= 32));
+                           g_v2_split == 1;
         const bool small = !split && (pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256));
         const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small && !pairs ? 0 : 2);
         const int vi = pairs ? 2 : small ? 1 : 0;        // variant: 256 x 128 / 128 x 128 / 128 x 128 co-resident
