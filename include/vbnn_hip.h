@@ -55,6 +55,7 @@ const char* vbnn_last_error(void);
                                       64 = 128 x 128 with a 2-stage ring, two workgroups per CU */
 #define VBNN_DEBUG_V2_SPLITK 3     /* pipelined kernel split-K (two K halves per 256 x 128 tile): -1 / 0 = off (default: it
                                       lost inside the step), 1 = whenever possible */
+#define VBNN_DEBUG_V3_MIN_K 4      /* shortest K for which shape selection picks the two-pass 256 x 256 kernel (default 704) */
 int vbnn_debug_set(int key, int value);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream

@@ -33,6 +33,8 @@ constexpr int V3_APART = 128 * 128;                  // bytes: 128 rows x 128 B
 constexpr int V3_BTILE = 256 * 128;
 constexpr int V3_LDS = 4 * V3_APART + 3 * V3_BTILE;  // 163840: all of the CU's LDS
 
+static int g_v3_min_k = 704;        // shortest K the shape selection gives to this kernel (vbnn_debug_set key 4)
+
 template <> __device__ __forceinline__ void v2_wait_vmcnt<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 template <> __device__ __forceinline__ void v2_wait_vmcnt<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
 
@@ -371,7 +373,7 @@ static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t lda, int64_t l
 template <class Epi>
 static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, const Epi& epi) {
     const int64_t t = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
-    return gemm_v3_possible(M, N, lda, ldb, epi) && t >= 192 && t <= 256 && K >= 704;
+    return gemm_v3_possible(M, N, lda, ldb, epi) && t >= 192 && t <= 256 && K >= g_v3_min_k;
 }
 
 template <typename T, bool DUAL, class Epi>
