@@ -213,7 +213,10 @@ __device__ __forceinline__ void head_load(HeadRaw<T>& o, const T* __restrict__ h
     }
 }
 
-template <typename T, bool VEC>
+// FULL: every tile is whole and vector-accessible (H % 64 == 0, N % 64 == 0, aligned operands): no bounds checks at
+// all, and every global access is (block-uniform base) + (one 32-bit lane offset) -- the guarded general form spent
+// most of its VALU issue slots on 64-bit address arithmetic and exec-mask bookkeeping (it was issue-bound, not HBM-bound).
+template <typename T, bool VEC, bool FULL>
 __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
                                                        const float* __restrict__ g, int64_t N, int64_t H, int C, int relu_mask,
                                                        const float* __restrict__ r_prev, const T* __restrict__ r_prev_t, int64_t ld_r,
@@ -246,19 +249,44 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
 #pragma unroll
     for (int e = 0; e < CE; ++e) ones[e] = Elt<T>::to(c16 == 0 ? 1.f : 0.f);
     HeadRaw<T> cur[2] = {}, nxt[2] = {};
+    // FULL addressing: lane offsets (elements) of the thread's row (tid >> 3) and 8-column chunk inside a tile
+    const unsigned lo_h = (unsigned)((tid >> 3) * (int)ld_h + ch * 8), lo_r = (unsigned)((tid >> 3) * (int)ld_r + ch * 8);
+    const unsigned lo_g = (unsigned)((tid >> 3) * (int)ld_gp + ch * 8), lo_t = (unsigned)((tid >> 3) * (int)ld_gpT + ch * 8);
+    auto load_tile = [&](HeadRaw<T> (&dst)[2], int64_t r0) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) head_load<T, VEC>(cur[p], h, ld_h, r_prev, r_prev_t, ld_r, n_lo + (tid >> 3) + 32 * p, n_hi, i8, H);
+        for (int p = 0; p < 2; ++p) {
+            if constexpr (FULL) {
+                dst[p].h = Vec8<T>::load_raw(h + ((r0 + 32 * p) * ld_h + c0) + lo_h);
+                if (r_prev_t) dst[p].rt = Vec8<T>::load_raw(r_prev_t + ((r0 + 32 * p) * ld_r + c0) + lo_r);
+                if (r_prev) dst[p].rf = Vec8<float>::load_raw(r_prev + ((r0 + 32 * p) * ld_r + c0) + lo_r);
+            } else {
+                head_load<T, VEC>(dst[p], h, ld_h, r_prev, r_prev_t, ld_r, r0 + (tid >> 3) + 32 * p, n_hi, i8, H);
+            }
+        }
+    };
+    load_tile(cur, n_lo);
+    // the tile's rows of g are staged through registers one tile ahead as well: a load + barrier at the top of every
+    // tile put ~2 us of latency on each block's critical path (the kernel ran at 2 TB/s)
+    float gcur[4], gnxt[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_g = [&](int64_t r0, float (&q)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k, rr = idx >> 4, cc = idx & 15;
+            q[k] = (cc < C && r0 + rr < n_hi) ? g[(r0 + rr) * C + cc] : 0.f;
+        }
+    };
+    load_g(n_lo, gcur);
     int buf = 0;
     for (int64_t r0 = n_lo; r0 < n_hi; r0 += 64, buf ^= 1) {
-        for (int k = tid; k < 64 * HEAD_CMAX; k += 256) {
-            const int rr = k >> 4, cc = k & 15;
-            gs[buf][rr][cc] = (cc < C && r0 + rr < n_hi) ? Elt<T>::from(Elt<T>::to(g[(r0 + rr) * C + cc])) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k;
+            gs[buf][idx >> 4][idx & 15] = Elt<T>::from(Elt<T>::to(gcur[k]));
         }
         const bool more = r0 + 64 < n_hi;                   // block-uniform
         if (more) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-                head_load<T, VEC>(nxt[p], h, ld_h, r_prev, r_prev_t, ld_r, r0 + 64 + (tid >> 3) + 32 * p, n_hi, i8, H);
+            load_g(r0 + 64, gnxt);
+            load_tile(nxt, r0 + 64);
         }
         __syncthreads();         // gs[buf] (and ws) visible; every read of the previous tile's th / tg / tv is done
 #pragma unroll
@@ -283,7 +311,10 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
                 gp[e] = (relu_mask && !(hv[e] > 0.f)) ? 0.f : gx[e];
                 gvp[e] = has_r ? gp[e] * rv[e] : 0.f;
             }
-            if (n < n_hi && i8 < H) {
+            if constexpr (FULL) {
+                if (g_prev) Vec8<T>::store(g_prev + ((r0 + 32 * p) * ld_gp + c0) + lo_g, gp);
+                if (gv_prev) Vec8<T>::store(gv_prev + ((r0 + 32 * p) * ld_gp + c0) + lo_g, gvp);
+            } else if (n < n_hi && i8 < H) {
                 if (VEC && i8 + 8 <= H) {
                     if (g_prev) Vec8<T>::store(g_prev + n * ld_gp + i8, gp);
                     if (gv_prev) Vec8<T>::store(gv_prev + n * ld_gp + i8, gvp);
@@ -309,11 +340,14 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
             for (int p = 0; p < 2; ++p) {
                 const int cc = (tid >> 3) + 32 * p;          // hidden unit inside the tile
                 const int64_t i = c0 + cc, n = r0 + ch * 8;
-                if (i >= H || n >= n_hi) continue;
+                if (!FULL && (i >= H || n >= n_hi)) continue;
                 float a[8], b[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { a[e] = Elt<T>::from(tg[ch * 8 + e][cc]); b[e] = Elt<T>::from(tv[ch * 8 + e][cc]); }
-                if (VEC && n + 8 <= n_hi) {
+                if constexpr (FULL) {
+                    if (gT_prev) Vec8<T>::store(gT_prev + ((c0 + 32 * p) * ld_gpT + r0) + lo_t, a);
+                    if (gvT_prev) Vec8<T>::store(gvT_prev + ((c0 + 32 * p) * ld_gpT + r0) + lo_t, b);
+                } else if (VEC && n + 8 <= n_hi) {
                     if (gT_prev) Vec8<T>::store(gT_prev + i * ld_gpT + n, a);
                     if (gvT_prev) Vec8<T>::store(gvT_prev + i * ld_gpT + n, b);
                 } else {
@@ -345,7 +379,11 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
             const int rows = (int)min((int64_t)64, n_hi - r0);
             for (int rr = tid >> 4; rr < rows; rr += 16) accb += g[(r0 + rr) * C + c16];
         }
-        if (more) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
+        if (more) {
+            cur[0] = nxt[0]; cur[1] = nxt[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gcur[k] = gnxt[k];
+        }
     }
     if (partial_w) {                                         // lane (q, c16): classes 4q .. 4q+3 of hidden unit 16 w + c16
         const int64_t i = c0 + 16 * wave + c16;
@@ -440,13 +478,13 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
     const T* r_prev_t = r_prev_packed ? (const T*)r_prev_any : nullptr;
     const bool sums = gradWeight || gradBias || gradBias_prev;
     if (!sums && !g_prev && !gT_prev) return VBNN_OK;
-    // row chunks: about 2048 blocks (several per CU, so one's loads sit beside another's LDS work), bounded by the
+    // row chunks: about 1024 blocks (several per CU, so one's loads sit beside another's LDS work), bounded by the
     // reduction scratch: per chunk C x H + C + H partial sums
     const int64_t tiles_c = (H + 63) / 64, tiles_r = (N + 63) / 64;
     const int64_t per_chunk = C * H + C + H;
     const int64_t cap = (int64_t)(ctx->scratch_doubles * 2) / per_chunk;
     VBNN_REQUIRE(!sums || cap >= 1, "hidden size too large for the reduction scratch");
-    int64_t R = (2048 + tiles_c - 1) / tiles_c;
+    int64_t R = (1024 + tiles_c - 1) / tiles_c;
     if (R > tiles_r) R = tiles_r;
     if (sums && R > cap) R = cap;
     if (R < 1) R = 1;
@@ -464,12 +502,18 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
     float* pw = (gradWeight || gradBias_prev) ? partial_w : nullptr;
     float* pb = gradBias ? partial_b : nullptr;
     float* pbp = gradBias_prev ? partial_bp : nullptr;
-    if (vec)
-        hipLaunchKernelGGL((k_head_backward<T, true>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
+    const bool full = vec && (H % 64 == 0) && (N % 64 == 0) && N * ld_h < (1ll << 31) && N * ld_gp < (1ll << 31) &&
+                      H * ld_gpT < (1ll << 31) && (!r_prev_any || N * ld_r_prev < (1ll << 31));
+    if (full)
+        hipLaunchKernelGGL((k_head_backward<T, true, true>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
+                           relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
+                           pw, pb, pbp);
+    else if (vec)
+        hipLaunchKernelGGL((k_head_backward<T, true, false>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
                            relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
                            pw, pb, pbp);
     else
-        hipLaunchKernelGGL((k_head_backward<T, false>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
+        hipLaunchKernelGGL((k_head_backward<T, false, false>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
                            relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
                            pw, pb, pbp);
     if (sums) {
