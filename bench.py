@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run accGradParameters on a second stream (A/B; slower)")
     ap.add_argument("--mode", default="lrt", choices=["lrt", "wn"])
+    ap.add_argument("--probe-every", type=int, default=8, help="bracket the roofline kernels with HIP events on every n-th timed step")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
     args = ap.parse_args()
 
@@ -195,11 +196,14 @@ def main():
     # HIP events around every launch of the widest layer's three dual GEMMs, on the stream they are launched on,
     # DURING the timed steps (rank 0): the roofline kernel's average duration comes from these
     wide_li = max(range(len(eng.vb)), key=lambda k: eng.vb[k].I * eng.vb[k].O)
-    if rank == 0:
-        eng.probe = (wide_li, {})
+    # (every `--probe-every`-th step only: an event record is a marker packet between two kernels, six of them per
+    # step cost ~3 % of a 1.05 ms step)
+    probe = (wide_li, {}) if rank == 0 else None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        eng.probe = probe if (i % args.probe_every == 0) else None
         step()
+    eng.probe = probe
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
