@@ -28,6 +28,10 @@ CONFIGS = {
     # BASELINE.json configs[1]: the fp32 numerics configuration (launch-bound)
     "small": dict(input_size=784, hidden=[400, 400], n_classes=10, batch=256, dtype="f32",
                   name="784-400-400-10 VBLinear MLP, batch 256 per GPU, LRT, S=1"),
+    # BASELINE.json configs[4], with the reference's own criterion (10 classes) in place of a regression loss the
+    # reference does not have: the deep-stack KL / bandwidth stress
+    "deep": dict(input_size=4096, hidden=[4096] * 8, n_classes=10, batch=4096, dtype="bf16",
+                 name="4096-(4096 x 8)-10 VBLinear stack, batch 4096 per GPU, LRT, S=1"),
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md: dense MFMA peaks
 LIVE_NAMES = {"forward": "forward(dual GEMM + LRT epilogue)",
