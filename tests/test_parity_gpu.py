@@ -602,6 +602,44 @@ def test_module_update_matches_oracle(nnmod, oracle, mode):
         np.testing.assert_allclose(host(last.weight), onet.last.weight, rtol=0, atol=1e-7 * np.abs(onet.last.weight).max() + 1e-9)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_prepare_equals_per_layer_sweeps(nnmod, dtype):
+    """vbnn_prepare (all layers + the final weight in one call, one finish kernel) must leave exactly what
+    n x vbnn_prep_layer + vbnn_pack leave: bitwise equal shadows, transposes, statistics and packed final weight."""
+    import ctypes as C
+    import torch
+    from vbnn_amd import _lib as L
+    from vbnn_amd.engine import FusedMLP, _p
+    opt = opt_for("lrt", dtype, input_size=70, hidden=[130, 64, 50], fuse_kl=True)
+    eng = FusedMLP(opt)
+    for v in eng.vb:                                       # non-trivial parameters
+        v.lvars.uniform_(-9.0, -5.0)
+    lib = L.lib()
+    eng.prepare()                                          # the one-call form
+    torch.cuda.synchronize()
+    got = [(v.mu_s.t.clone(), v.var_s.t.clone(), v.muT_s.t.clone() if v.muT_s else None,
+            v.varT_s.t.clone() if v.varT_s else None, v.stats.clone()) for v in eng.vb]
+    got_w3, got_w3T = eng.w3_s.t.clone(), eng.w3T_s.t.clone()
+    for v in eng.vb:
+        for buf in (v.mu_s, v.var_s, v.muT_s, v.varT_s):
+            if buf is not None:
+                buf.t.zero_()
+        v.stats.zero_()
+        L.check(lib.vbnn_prep_layer(eng.ctx.h, eng.code, _p(v.means), _p(v.lvars), v.O, v.I, v.mu_s.ptr, v.var_s.ptr, v.mu_s.ld,
+                                    v.muT_s.ptr if v.muT_s else None, v.varT_s.ptr if v.varT_s else None,
+                                    v.muT_s.ld if v.muT_s else 0, _p(v.stats)))
+    eng.w3_s.t.zero_(); eng.w3T_s.t.zero_()
+    L.check(lib.vbnn_pack(eng.ctx.h, eng.code, L.PACK_COPY, _p(eng.weight3), None, eng.sizes[-1], eng.n_classes, eng.sizes[-1],
+                          eng.w3_s.ptr, eng.w3_s.ld, eng.w3T_s.ptr, eng.w3T_s.ld))
+    torch.cuda.synchronize()
+    for v, (mu, var, muT, varT, st) in zip(eng.vb, got):
+        assert torch.equal(mu, v.mu_s.t) and torch.equal(var, v.var_s.t)
+        if muT is not None:
+            assert torch.equal(muT, v.muT_s.t) and torch.equal(varT, v.varT_s.t)
+        assert torch.equal(st, v.stats)
+    assert torch.equal(got_w3, eng.w3_s.t) and torch.equal(got_w3T, eng.w3T_s.t)
+
+
 def test_engine_update_matches_oracle(oracle, nnmod):
     """FusedMLP.update (total gradients straight from the dW epilogue) == the reference's update sequence."""
     opt, eng, onet = _engine_pair(oracle, "lrt", "f32", [50, 34], 70, True, S=1)
