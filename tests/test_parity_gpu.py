@@ -603,6 +603,36 @@ def test_module_update_matches_oracle(nnmod, oracle, mode):
         np.testing.assert_allclose(host(last.weight), onet.last.weight, rtol=0, atol=1e-7 * np.abs(onet.last.weight).max() + 1e-9)
 
 
+@pytest.mark.parametrize("dtype,hidden,I0,N", [("f32", [50, 34], 70, 64), ("bf16", [512, 256], 256, 512)])
+def test_engine_two_rank_shards_sum_to_the_single_process_step(oracle, nnmod, dtype, hidden, I0, N):
+    """The data-parallel recipe on the REAL kernels, without a process group: two engines built as ranks 0 and 1 of a
+    world of 2 (their all-reduce switched off) each take half the rows; the sum of their gradient arenas must equal
+    the arena of one engine on the whole batch (criterion / global batch, KL gradient x 1/world, z by GLOBAL row),
+    and their losses must add up. fp32: summation-order tolerance; bf16: the same plus the operand rounding of the
+    per-half column sums."""
+    import torch
+    from vbnn_amd.engine import FusedMLP
+    opt = opt_for("lrt", dtype, input_size=I0, hidden=hidden, S=1, fuse_kl=True)
+    x = dev(oracle.fill_normal(N, I0, SEED, 4, 0, 0))
+    t = dev((np.arange(N) * 7 % 10).astype(np.int32))
+
+    def one(world, rank, xs, ts):
+        eng = FusedMLP(opt, world_size=world, rank=rank)
+        eng.reduce = False                                    # the exchange itself is torch.distributed's job
+        eng.resetGradients(); eng.prepare(); eng.sample()
+        eng.run(xs, ts)
+        loss, _ = eng.loss_and_accuracy()
+        return eng.grads.clone(), loss
+
+    g_full, loss_full = one(1, 0, x, t)
+    g0, l0 = one(2, 0, x[: N // 2].contiguous(), t[: N // 2].contiguous())
+    g1, l1 = one(2, 1, x[N // 2:].contiguous(), t[N // 2:].contiguous())
+    assert abs((l0 + l1) - loss_full) <= 1e-5 * abs(loss_full)
+    got, want = host(g0 + g1), host(g_full)
+    tol = 2e-5 if dtype == "f32" else 2e-3
+    assert np.linalg.norm(got - want) <= tol * np.linalg.norm(want), np.linalg.norm(got - want) / np.linalg.norm(want)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_prepare_equals_per_layer_sweeps(nnmod, dtype):
     """vbnn_prepare (all layers + the final weight in one call, one finish kernel) must leave exactly what
