@@ -56,6 +56,8 @@ const char* vbnn_last_error(void);
 #define VBNN_DEBUG_V2_SPLITK 3     /* pipelined kernel split-K (two K halves per 256 x 128 tile): -1 / 0 = off (default: it
                                       lost inside the step), 1 = whenever possible */
 #define VBNN_DEBUG_V3_MIN_K 4      /* shortest K for which shape selection picks the two-pass 256 x 256 kernel (default 704) */
+#define VBNN_DEBUG_V2_PSPLIT 5     /* pipelined kernel pair split (the pair's two GEMMs in different workgroups, parameter
+                                      gradients only): -1 = by shape (default), 0 = never, 1 = whenever possible */
 int vbnn_debug_set(int key, int value);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream

@@ -363,21 +363,23 @@ def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidd
     close(eng.gradBias3, gb3, "final gradBias")
 
 
-@pytest.fixture(params=[(1, 0, -1), (2, 256, 0), (2, 128, 0), (2, 64, 0), (3, 0, -1), (2, 256, 1)],
+@pytest.fixture(params=[(1, 0, -1, 0), (2, 256, 0, 0), (2, 128, 0, 0), (2, 64, 0, 0), (3, 0, -1, -1), (2, 256, 1, 0), (2, 256, 0, 1)],
                 ids=["general-kernel", "pipelined-256x128", "pipelined-128x128", "pipelined-128x128-pairs",
-                     "two-pass-256x256", "pipelined-256x128-splitK"])
+                     "two-pass-256x256", "pipelined-256x128-splitK", "pipelined-256x128-pairsplit"])
 def gemm_kernel(request, nnmod):
-    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in its block tiles and with split-K / gemm_v3.h),
-    whatever the shape heuristics say."""
+    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in its block tiles, with split-K and with the pair
+    split / gemm_v3.h), whatever the shape heuristics say."""
     from vbnn_amd import _lib as L
-    kernel, tile, split = request.param
+    kernel, tile, split, psplit = request.param
     L.check(L.lib().vbnn_debug_set(0, kernel))
     L.check(L.lib().vbnn_debug_set(2, tile))
     L.check(L.lib().vbnn_debug_set(3, split))
+    L.check(L.lib().vbnn_debug_set(5, psplit))
     yield request.param
     L.check(L.lib().vbnn_debug_set(0, 0))
     L.check(L.lib().vbnn_debug_set(2, 0))
     L.check(L.lib().vbnn_debug_set(3, -1))
+    L.check(L.lib().vbnn_debug_set(5, -1))
 
 
 @pytest.mark.parametrize("N,I,O", [(1, 8, 8), (37, 70, 50), (300, 200, 260), (512, 448, 384), (200, 4096, 130),

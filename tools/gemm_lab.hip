@@ -28,6 +28,8 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
     }
     static constexpr int FAST_BATCH = 8;
     static constexpr bool PARK = false;
+    static constexpr bool SPLITTABLE = false;
+    __device__ __forceinline__ void set_part(int) {}
     static constexpr int FOLD_BATCH = 8;
     static constexpr bool FOLD_SERIAL = false;
     struct Pre {};

@@ -59,6 +59,8 @@ struct EpiFwd {
     T* hT; T* h2T; int64_t ld_hT;
     int O, N;
 
+    static constexpr bool SPLITTABLE = false;     // every output needs both GEMMs of the pair
+    __device__ __forceinline__ void set_part(int) {}
     __host__ __device__ __forceinline__ T* t1_ptr() const { return hT; }
     __host__ __device__ __forceinline__ T* t2_ptr() const { return h2T; }
     __host__ __device__ __forceinline__ int64_t t_ld() const { return ld_hT; }
@@ -248,6 +250,8 @@ struct EpiDx {
     T* gT_prev; T* gvT_prev; int64_t ld_gpT;
     int I, N;
 
+    static constexpr bool SPLITTABLE = false;
+    __device__ __forceinline__ void set_part(int) {}
     __host__ __device__ __forceinline__ T* t1_ptr() const { return gT_prev; }
     __host__ __device__ __forceinline__ T* t2_ptr() const { return gvT_prev; }
     __host__ __device__ __forceinline__ int64_t t_ld() const { return ld_gpT; }
@@ -370,6 +374,13 @@ struct EpiDw {
     const float* means; const double* stats; float B, S, kl_scale;
     float* gradBias;         // optional: the GEMM has one more A row (all ones) whose output row is the bias gradient
     int I, O;
+    // d/dmeans depends on the first GEMM of the pair only and d/dlvars on the second only, so a kernel may compute the
+    // two GEMMs in DIFFERENT workgroups (gemm_v2.h, pair split): part 1 = this workgroup holds the first GEMM (in a1)
+    // and writes only what depends on it; part 2 = it holds the SECOND GEMM (also handed over in a1) and writes only
+    // what depends on that; 0 = both accumulators, as ever.
+    int part = 0;
+    static constexpr bool SPLITTABLE = true;
+    __device__ __forceinline__ void set_part(int p) { part = p; }
 
     __host__ __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
     __host__ __device__ __forceinline__ bf16_t* t2_ptr() const { return nullptr; }
@@ -384,15 +395,17 @@ struct EpiDw {
     }
 
     __device__ __forceinline__ void operator()(int m, int n, f32x4 a1, f32x4 a2) const {
+        if (part == 2) { a2 = a1; a1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const bool do_mu = part != 2, do_lv = part != 1;
         const int valid = min(4, I - m);
-        if (gradBias && n < O && m <= I && I < m + 4) {      // the quad that holds the ones row m = I
+        if (do_mu && gradBias && n < O && m <= I && I < m + 4) {      // the quad that holds the ones row m = I
             const float s = scale * a1[I - m];
             gradBias[n] = accumulate ? gradBias[n] + s : s;
         }
         if (valid <= 0 || n >= O) return;
         const int64_t base = (int64_t)n * I + m;
         float e[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f}, var[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool want_lv = gradSum || grad_lv;
+        const bool want_lv = do_lv && (gradSum || grad_lv);
         if (!lrt && want_lv) {
             const vbnn_f32x4 z = vbnn_normal4(seed, VBNN_STREAM_EPS, layer, draw, (uint32_t)n, (uint32_t)(m >> 2));
 #pragma unroll
@@ -408,14 +421,14 @@ struct EpiDw {
                 for (int j = 0; j < 4; ++j) sd[j] = sqrtf(var[j]);
             }
         }
-        if (gradWeight) {
+        if (gradWeight && do_mu) {
             float o4[4], old4[4] = {0.f, 0.f, 0.f, 0.f};
             if (accumulate) load4<float>(gradWeight + base, old4, valid, vec);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o4[j] = fmaf(scale, a1[j], old4[j]);
             store4<float>(gradWeight + base, o4[0], o4[1], o4[2], o4[3], valid, vec);
         }
-        if (gradSum) {
+        if (gradSum && do_lv) {
             float o4[4], old4[4] = {0.f, 0.f, 0.f, 0.f};
             if (accumulate) load4<float>(gradSum + base, old4, valid, vec);
 #pragma unroll
@@ -431,9 +444,9 @@ struct EpiDw {
             const float k_lv = kl_scale / (2.0f * B);               // d(KL/B)/dlvars  = (vars / var_hat - 1) / (2B)
             const float inv_vh = 1.0f / var_hat;
             float gm[4], gl[4], mu4[4] = {0.f, 0.f, 0.f, 0.f}, om4[4] = {0.f, 0.f, 0.f, 0.f}, ol4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (means && !accumulate) load4<float>(means + base, mu4, valid, vec);
-            if (accumulate && grad_mu) load4<float>(grad_mu + base, om4, valid, vec);
-            if (accumulate && grad_lv) load4<float>(grad_lv + base, ol4, valid, vec);
+            if (means && !accumulate && do_mu) load4<float>(means + base, mu4, valid, vec);
+            if (accumulate && grad_mu && do_mu) load4<float>(grad_mu + base, om4, valid, vec);
+            if (accumulate && grad_lv && do_lv) load4<float>(grad_lv + base, ol4, valid, vec);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float lm = scale * a1[j] * invS;
@@ -447,8 +460,8 @@ struct EpiDw {
                 }
                 gm[j] = lm; gl[j] = ll;
             }
-            if (grad_mu) store4<float>(grad_mu + base, gm[0], gm[1], gm[2], gm[3], valid, vec);
-            if (grad_lv) store4<float>(grad_lv + base, gl[0], gl[1], gl[2], gl[3], valid, vec);
+            if (grad_mu && do_mu) store4<float>(grad_mu + base, gm[0], gm[1], gm[2], gm[3], valid, vec);
+            if (grad_lv && do_lv) store4<float>(grad_lv + base, gl[0], gl[1], gl[2], gl[3], valid, vec);
         }
     }
 
@@ -464,13 +477,14 @@ struct EpiDw {
     __device__ __forceinline__ Pre load_fast(int um, int un, const Lane& ln) const {
         const int64_t ub = (int64_t)un * I + um;
         Pre p;
-        p.lv = *reinterpret_cast<const f32x4*>(lvars + ub + ln.o);
-        p.mu = *reinterpret_cast<const f32x4*>(means + ub + ln.o);
+        p.lv = part != 1 ? *reinterpret_cast<const f32x4*>(lvars + ub + ln.o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        p.mu = part != 2 ? *reinterpret_cast<const f32x4*>(means + ub + ln.o) : f32x4{0.f, 0.f, 0.f, 0.f};
         return p;
     }
     __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre& pre, float (&t1)[4],
                                                float (&t2)[4]) const {
         (void)t1; (void)t2;
+        if (part == 2) a2 = a1;
         const int64_t ub = (int64_t)un * I + um;
         const float var_hat = (float)stats[2];
         const float invS = 1.0f / S;
@@ -486,8 +500,8 @@ struct EpiDw {
             gm[j] = fmaf(k_mu, pre.mu[j], lm);
             gl[j] = fmaf(k_lv, fmaf(var, inv_vh, -1.0f), ll);
         }
-        *reinterpret_cast<f32x4*>(grad_mu + ub + ln.o) = gm;
-        *reinterpret_cast<f32x4*>(grad_lv + ub + ln.o) = gl;
+        if (part != 2) *reinterpret_cast<f32x4*>(grad_mu + ub + ln.o) = gm;
+        if (part != 1) *reinterpret_cast<f32x4*>(grad_lv + ub + ln.o) = gl;
     }
 
     // ---- fold protocol: the two outputs depend on one accumulator each, so d/dlvars is FINISHED between the passes

@@ -18,6 +18,7 @@ extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_V2_TILE && (value == 0 || value == 64 || value == 128 || value == 256)) { g_v2_tile = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_SPLITK && value >= -1 && value <= 1) { g_v2_split = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V3_MIN_K && value >= 64) { g_v3_min_k = value; return VBNN_OK; }
+    if (key == VBNN_DEBUG_V2_PSPLIT && value >= -1 && value <= 1) { g_v2_psplit = value; return VBNN_OK; }
     vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
     return VBNN_ERR_INVALID;
 }

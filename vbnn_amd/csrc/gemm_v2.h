@@ -68,7 +68,8 @@ __device__ unsigned long long* g_v2_diag = nullptr;
 // 128 x 128 tile (one wave per SIMD has no partner to cover an interleaved DMA issue: 0 is 8 % faster there).
 static int g_v2_sched = -1;
 static int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
-static int g_v2_split = -1;       // split-K of the 256 x 128 tiling: -1 by shape, 0 never, 1 whenever possible (key 3)
+static int g_v2_split = -1;       // split-K of the 256 x 128 tiling: -1 / 0 off, 1 whenever possible (key 3)
+static int g_v2_psplit = -1;      // pair split of the 256 x 128 tiling: -1 by shape, 0 never, 1 whenever the functor allows (key 5)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -82,7 +83,7 @@ template <bool DUAL, int SCHED, int WM, int ST, class Epi>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                           const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
                                                           int M, int N, int nk, int tiles_m, int tiles_n, int ksplit, float* exch,
-                                                          unsigned* tickets, Epi epi) {
+                                                          unsigned* tickets, int psplit, Epi epi_in) {
     constexpr int NW = 2 * WM;                 // waves per workgroup
     constexpr int BM = 64 * WM;
     constexpr int A_BYTES = v2_a_bytes(WM), STAGE = v2_stage(WM);
@@ -103,11 +104,22 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     // Split-K (ksplit = 2: outputs too few to give every CU a tile, K long): the grid is tiles x 2, a tile's two
     // K halves sit on neighbouring remapped ids (same XCD), and the half that finishes LAST adds the other's partial
     // tile and runs the epilogue (see the hand-off before the epilogue).
-    const int nblk = tiles_m * tiles_n * ksplit;
+    const int nblk = tiles_m * tiles_n * ksplit * ((!DUAL && psplit) ? 2 : 1);
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective remap
+    }
+    // Pair split (psplit = 1, non-DUAL instantiation, splittable functors only): the grid is tiles x 2 and a tile's two
+    // blocks compute ONE GEMM of the pair each -- (A, B) or (A2, B2) -- with the single-accumulator main loop; the
+    // functor is told which one it holds and writes only the outputs that depend on it (epilogues.h, EpiDw::part).
+    // For outputs too few to give every CU a dual tile this doubles the blocks with no exchange of partial sums.
+    Epi epi = epi_in;
+    const int part = (!DUAL && psplit) ? (bid & 1) : 0;
+    if (!DUAL && psplit) {
+        bid >>= 1;
+        epi.set_part(1 + part);
+        if (part) { A = A2; B = B2; }
     }
     const int kslice = ksplit > 1 ? (bid & 1) : 0;
     if (ksplit > 1) bid >>= 1;
@@ -450,9 +462,14 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         const bool can_split = t256 <= VBNN_CNT_TILES_MAX && nk >= 2;
         const bool split = !pairs && g_v2_tile != 128 && can_split &&
                            g_v2_split == 1;
-        const bool small = !split && (pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256));
+        // Pair split: see the kernel. By shape when the functor allows it, the dual 256 x 128 tiling gives at most half
+        // the CUs a block (the 784 x 4096 gradient: 128 tiles) and K is long; g_v2_psplit: -1 by shape, 0 never, 1 always.
+        bool psplit = false;
+        if constexpr (DUAL && Epi::SPLITTABLE)
+            psplit = !pairs && !split && g_v2_tile != 128 && (g_v2_psplit == 1 || (g_v2_psplit == -1 && g_v2_tile == 0 && t256 <= 128 && nk >= 16));
+        const bool small = !split && !psplit && (pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256));
         const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small && !pairs ? 0 : 2);
-        const int vi = pairs ? 2 : small ? 1 : 0;        // variant: 256 x 128 / 128 x 128 / 128 x 128 co-resident
+        const int vi0 = pairs ? 2 : small ? 1 : 0;       // variant: 256 x 128 / 128 x 128 / 128 x 128 co-resident / pair split
         const int si = sched >> 1;                       // 0, 1, 2
         const void* kern;
         int threads, lds_bytes, bm;
@@ -462,12 +479,17 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         } else if (small) {                              // four waves, one workgroup per CU: no SIMD partner
             kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 2, 3, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 2, 3, Epi>;
             threads = 256; lds_bytes = v2_lds(2, 3); bm = 128;
+        } else if (psplit) {                             // the single-accumulator instantiations, two blocks per tile
+            kern = sched == 0 ? (const void*)gemm_nt_v2<false, 0, 4, 3, Epi>
+                 : sched == 2 ? (const void*)gemm_nt_v2<false, 2, 4, 3, Epi> : (const void*)gemm_nt_v2<false, 4, 4, 3, Epi>;
+            threads = 512; lds_bytes = v2_lds(4, 3); bm = 256;
         } else {
             kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 4, 3, Epi>
                  : sched == 2 ? (const void*)gemm_nt_v2<DUAL, 2, 4, 3, Epi> : (const void*)gemm_nt_v2<DUAL, 4, 4, 3, Epi>;
             threads = 512; lds_bytes = v2_lds(4, 3); bm = 256;
         }
-        static bool configured[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};   // per instantiation
+        static bool configured[4][3] = {{false, false, false}, {false, false, false}, {false, false, false}, {false, false, false}};   // per instantiation
+        const int vi = psplit ? 3 : vi0;
         if (!configured[vi][si]) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
@@ -493,8 +515,9 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         float* exch_ = ctx->park;
         unsigned* tickets_ = ctx->counters + VBNN_CNT_TILES;
         Epi epi_ = epi;
-        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &ksplit_, &exch_, &tickets_, &epi_};
-        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * ksplit_), dim3(threads), args, lds_bytes, stream);
+        int psplit_ = psplit ? 1 : 0;
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &ksplit_, &exch_, &tickets_, &psplit_, &epi_};
+        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * ksplit_ * (psplit ? 2 : 1)), dim3(threads), args, lds_bytes, stream);
         if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v2 failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
         return vbnn_check_launch("gemm_nt_v2");
     }
