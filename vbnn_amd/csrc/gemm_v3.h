@@ -126,14 +126,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     };
 
     // ---- one pass: acc = sum over the nk K steps of (Ap tile) x (Bp tile)^T
-    auto run_pass = [&]() {
-        // prologue, in the steady state's issue order: B(0) half, A part 0 (0), B(0) half, A part 1 (0), then step 1
+    // pipeline fill, in the steady state's issue order: B(0) half, A part 0 (0), B(0) half, A part 1 (0), then step 1
+    auto prologue = [&]() {
         dma_b(0, 0, c0); dma_b(0, 0, c1); dma_a(0, c0, c0); dma_a(0, c0, c1);
         dma_b(0, 0, c2); dma_b(0, 0, c3); dma_a(0, c1, c0); dma_a(0, c1, c1);
         if (nk > 1) {
             dma_b(1, 1, c0); dma_b(1, 1, c1); dma_a(1, c0, c0); dma_a(1, c0, c1);
             dma_b(1, 1, c2); dma_b(1, 1, c3);
         }
+    };
+    auto run_pass = [&]() {
         int bs = 0;                                           // B slot of step t (t % 3)
         for (int t = 0; t < nk; ++t) {
             const int bs2 = bs == 0 ? 2 : bs - 1;             // (t + 2) % 3
@@ -231,7 +233,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         // is turned into the term the first GEMM accumulates on top of -- in registers, no LDS, nothing parked.
         Ap = A2; Bp = B2;
         zero_acc();
+        prologue();
         run_pass();
+        // Pass 2's pipeline fill is issued BEFORE the fold, so its DMAs land while the fold computes. (The fold's own
+        // loads and stores are younger than those DMAs on the in-order vmcnt counter: the counted waits of run_pass
+        // only get stricter.)
+        __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
+        Ap = A; Bp = B;
+        prologue();
         // opaque to the optimiser from here on: otherwise the fold's address / counter arithmetic is hoisted above
         // pass 1 and held live through its loop, which is already at the register limit (it spilled)
         int fc16 = c16, fq4 = q4, fm0 = m0 + wr * 128, fn0 = n0 + wc * 64;
@@ -275,11 +284,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             fold_batch(std::integral_constant<int, 4>()); fold_batch(std::integral_constant<int, 5>());
             fold_batch(std::integral_constant<int, 6>()); fold_batch(std::integral_constant<int, 7>());
         }
-        __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
-        Ap = A; Bp = B;
-        run_pass();                                           // fold's stores are older than these DMAs: the counted
-    } else {                                                  // waits only get stricter
+        run_pass();
+    } else {
         zero_acc();
+        prologue();
         run_pass();
     }
     __syncthreads();
