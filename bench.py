@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run accGradParameters on a second stream (A/B; slower)")
     ap.add_argument("--mode", default="lrt", choices=["lrt", "wn"])
+    ap.add_argument("--batch", type=int, default=0, help="exploration only: rows per GPU instead of the configuration's")
     ap.add_argument("--probe-every", type=int, default=8, help="bracket the roofline kernels with HIP events on every n-th timed step")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
     args = ap.parse_args()
@@ -171,7 +172,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
     L.lib()                                               # fail loudly if the HIP extension is missing
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.batch > 0:
+        cfg["batch"] = args.batch
+        cfg["name"] += f" [batch overridden: {args.batch}]"
     N = cfg["batch"]
     opt = dict(var_init=1e-3, B=1e6, S=1, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
                hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap)

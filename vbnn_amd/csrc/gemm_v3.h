@@ -375,13 +375,18 @@ static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t lda, int64_t l
     return (M % V3_BM == 0) && (N % V3_BN == 0) && M * lda < (1ll << 31) && N * ldb < (1ll << 31) && epi.fast_ok() && t_ok &&
            M * e.t_ld() < (1ll << 31);
 }
-// worth it when the tiling gives (almost) every CU one tile, no more than one round of them, and K is long enough
-// to amortise the second pipeline fill and the fold between the passes (measured against gemm_v2's dual tile on
-// 4096 x 4096 outputs: K = 4096 forward 212 vs 252 us, K = 784 forward 93 vs 99 us)
+// Worth it when K is long enough to amortise the second pipeline fill and the fold between the passes (measured against
+// gemm_v2's dual tile on 4096 x 4096 outputs: K = 4096 forward 212 vs 252 us, K = 784 forward 93 vs 99 us) and the
+// tile count fills whole rounds of CUs better than the half-size dual tiles would: a 256 x 256 two-pass tile costs about
+// 1.85x a 256 x 128 dual tile (235 vs 127 us at K = 4096), so compare rounds x cost on the device's CUs.
 template <class Epi>
 static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, const Epi& epi) {
-    const int64_t t = ((M + V3_BM - 1) / V3_BM) * ((N + V3_BN - 1) / V3_BN);
-    return gemm_v3_possible(M, N, lda, ldb, epi) && t >= 192 && t <= 256 && K >= g_v3_min_k;
+    if (!gemm_v3_possible(M, N, lda, ldb, epi) || K < g_v3_min_k) return false;
+    const int64_t cus = 256;
+    const int64_t t3 = (M / V3_BM) * (N / V3_BN), t2 = 2 * t3;
+    if (t3 < 192) return false;                               // fewer than 3/4 of the CUs busy: the half-size tiles win
+    const int64_t r3 = (t3 + cus - 1) / cus, r2 = (t2 + cus - 1) / cus;
+    return 185 * r3 <= 100 * r2;
 }
 
 template <typename T, bool DUAL, class Epi>
