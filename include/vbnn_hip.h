@@ -58,7 +58,14 @@ const char* vbnn_last_error(void);
 #define VBNN_DEBUG_V3_MIN_K 4      /* shortest K for which shape selection picks the two-pass 256 x 256 kernel (default 704) */
 #define VBNN_DEBUG_V2_PSPLIT 5     /* pipelined kernel pair split (the pair's two GEMMs in different workgroups, parameter
                                       gradients only): -1 = by shape (default), 0 = never, 1 = whenever possible */
+#define VBNN_DEBUG_KMAJOR 6        /* K-major operands (gemm_v3.h AK / BK): 1 = use when the shape allows (default), 0 = never */
 int vbnn_debug_set(int key, int value);
+
+/* 1 when a GEMM with an M x N output and contraction length K would take the K-major form of the two-pass kernel
+ * under the current selection (whole 256 x 256 tiles filling the CUs, K a multiple of 64, bf16): the host asks once
+ * per layer whether it needs the transposed copies at all (accGradParameters: M = I, N = O, K = minibatch rows;
+ * gradInput: M = I, N = minibatch rows, K = O). */
+int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
  * (which is also what PyTorch-ROCm's default stream is, so the two stay ordered). */
@@ -149,6 +156,9 @@ typedef struct vbnn_dx_args {
     const void* r_prev; int64_t ld_r_prev; int r_prev_packed;   /* the previous layer's `r`, same typing rule */
     void* g_prev; void* gv_prev; int64_t ld_gp;      /* N x ld_gp   */
     void* gT_prev; void* gvT_prev; int64_t ld_gpT;   /* I x ld_gpT  */
+    /* optional K-MAJOR weights: mu, sigma^2 as the forward holds them (O x ld_w). When vbnn_kmajor_supported(I, N, O)
+     * says so the GEMM reads these and wT / w2T may be NULL: the parameter sweep writes no transposed shadows. */
+    const void* w; const void* w2; int64_t ld_w;
 } vbnn_dx_args;
 
 /* updateGradInput. WN: gradInput = g w (inherited, VBLinear.lua:109-110).
@@ -179,6 +189,10 @@ typedef struct vbnn_dw_args {
      * of x2T anything finite): output row I of the first GEMM is sum_n g[n][o], written as
      * gradBias[o] (+)= scale * that -- what vbnn_acc_grad_bias(g) gives, without another pass over g. NULL: off. */
     float* gradBias;
+    /* optional K-MAJOR operands: the untransposed x, x.x (N x ld_x) and g, gv (N x ld_g) exactly as the forward and
+     * gradInput GEMMs hold them. When vbnn_kmajor_supported(I, O, N) says so the GEMM reads these (transpose reads in
+     * LDS) and xT / x2T / gT / gvT may be NULL: no epilogue has to write transposed copies. Otherwise xT.. are used. */
+    const void* x; const void* x2; const void* g; const void* gv; int64_t ld_x; int64_t ld_g;
 } vbnn_dw_args;
 
 /* accGradParameters (VBLinear.lua:112-118), one GEMM instead of the reference's two. */

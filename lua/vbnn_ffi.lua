@@ -15,6 +15,7 @@ typedef struct vbnn_ctx vbnn_ctx;
 int vbnn_abi_version(void);
 const char* vbnn_last_error(void);
 int vbnn_debug_set(int key, int value);
+int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K);
 int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);
 int vbnn_ctx_destroy(vbnn_ctx* ctx);
 int vbnn_ctx_set_stream(vbnn_ctx* ctx, void* hip_stream);
@@ -64,6 +65,7 @@ typedef struct vbnn_dx_args {
     const void* r_prev; int64_t ld_r_prev; int r_prev_packed;
     void* g_prev; void* gv_prev; int64_t ld_gp;
     void* gT_prev; void* gvT_prev; int64_t ld_gpT;
+    const void* w; const void* w2; int64_t ld_w;
 } vbnn_dx_args;
 int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a);
 typedef struct vbnn_dw_args {
@@ -82,6 +84,7 @@ typedef struct vbnn_dw_args {
     float* grad_mu; float* grad_lv;
     const float* means; const double* stats; float B; float S; float kl_scale;
     float* gradBias;
+    const void* x; const void* x2; const void* g; const void* gv; int64_t ld_x; int64_t ld_g;
 } vbnn_dw_args;
 int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
 int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O,

@@ -6,7 +6,7 @@ import torch
 from vbnn_amd import _lib as L
 from vbnn_amd.engine import FusedMLP, _p
 from vbnn_amd.nn import fill_normal
-opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype="bf16", seed=3, input_size=784, hidden=[4096, 4096], n_classes=10)
+opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype="bf16", seed=3, input_size=784, hidden=[4096, 4096], n_classes=10, keep_transposes=True)
 eng = FusedMLP(opt)
 N = 4096
 x = torch.empty(N, 784, dtype=torch.float32, device="cuda"); fill_normal(x, 3, 4, 0, 0)

@@ -17,9 +17,9 @@ void vbnn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfpri
 struct EpiSum {          // keeps both accumulators live with one 16-byte store per four outputs
     typedef bf16_t elem_t;
     float* out; int M, N;
-    __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
-    __device__ __forceinline__ bf16_t* t2_ptr() const { return nullptr; }
-    __device__ __forceinline__ int64_t t_ld() const { return 0; }
+    __host__ __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
+    __host__ __device__ __forceinline__ bf16_t* t2_ptr() const { return nullptr; }
+    __host__ __device__ __forceinline__ int64_t t_ld() const { return 0; }
     __device__ __forceinline__ int m_dim() const { return M; }
     __device__ __forceinline__ int n_dim() const { return N; }
     template <bool ST>
@@ -34,13 +34,13 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
     static constexpr bool FOLD_SERIAL = false;
     struct Pre {};
     struct FPre {};
+    struct Lane { unsigned o; };
     __device__ __forceinline__ FPre fold_load(int, int, const Lane&) const { return FPre{}; }
     __device__ __forceinline__ f32x4 fold(int, int, const Lane&, f32x4 a2, const FPre&) const { return a2; }
     __device__ __forceinline__ Pre load_folded(int, int, const Lane&) const { return Pre{}; }
     __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre&, float (&)[4], float (&)[4]) const {
         *reinterpret_cast<f32x4*>(out + ((size_t)un * M + um) + ln.o) = a;
     }
-    struct Lane { unsigned o; };
     __host__ __device__ bool fast_ok() const { return true; }
     __device__ __forceinline__ Lane lane_init(int nl, int ml) const { return Lane{(unsigned)(nl * M + ml)}; }
     __device__ __forceinline__ Pre load_fast(int, int, const Lane&) const { return Pre{}; }
@@ -112,9 +112,12 @@ int main(int argc, char** argv) {
         vbnn_ctx ctx{};
         ctx.stream = st;
         for (int dual = 0; dual < 2; ++dual) {
+            const int km = getenv("LAB_KMAJOR") ? atoi(getenv("LAB_KMAJOR")) : 0;      // 0 NT, 1 A K-major, 2 both (timing only)
             auto launch = [&] {
-                if (dual) launch_gemm_v3<bf16_t, true, EpiSum>(&ctx, A, A2, K, B, B2, K, M, N, K, epi);
-                else launch_gemm_v3<bf16_t, false, EpiSum>(&ctx, A, nullptr, K, B, nullptr, K, M, N, K, epi);
+                if (km == 1) launch_gemm_v3<bf16_t, true, true, false, EpiSum>(&ctx, A, A2, M, B, B2, K, M, N, K, epi);
+                else if (km == 2) launch_gemm_v3<bf16_t, true, true, true, EpiSum>(&ctx, A, A2, M, B, B2, N, M, N, K, epi);
+                else if (dual) launch_gemm_v3<bf16_t, true, false, false, EpiSum>(&ctx, A, A2, K, B, B2, K, M, N, K, epi);
+                else launch_gemm_v3<bf16_t, false, false, false, EpiSum>(&ctx, A, nullptr, K, B, nullptr, K, M, N, K, epi);
             };
             for (int i = 0; i < 3; ++i) launch();
             CK(hipDeviceSynchronize());

@@ -37,7 +37,8 @@ class DxArgs(C.Structure):
                 ("N", _i64), ("I", _i64), ("O", _i64), ("x", _vp), ("ld_x", _i64),
                 ("gx", _vp), ("ld_gx", _i64), ("relu_mask", _i), ("r_prev", _vp), ("ld_r_prev", _i64), ("r_prev_packed", _i),
                 ("g_prev", _vp), ("gv_prev", _vp), ("ld_gp", _i64),
-                ("gT_prev", _vp), ("gvT_prev", _vp), ("ld_gpT", _i64)]
+                ("gT_prev", _vp), ("gvT_prev", _vp), ("ld_gpT", _i64),
+                ("w", _vp), ("w2", _vp), ("ld_w", _i64)]
 
 
 class PrepDesc(C.Structure):          # vbnn_prep_desc
@@ -55,13 +56,15 @@ class DwArgs(C.Structure):
                 ("N", _i64), ("I", _i64), ("O", _i64), ("scale", _f), ("accumulate", _i),
                 ("gradWeight", _vp), ("gradSum", _vp), ("seed", _u64), ("layer", _u32), ("draw", _u32),
                 ("lvars", _vp), ("grad_mu", _vp), ("grad_lv", _vp), ("means", _vp), ("stats", _vp),
-                ("B", _f), ("S", _f), ("kl_scale", _f), ("gradBias", _vp)]
+                ("B", _f), ("S", _f), ("kl_scale", _f), ("gradBias", _vp),
+                ("x", _vp), ("x2", _vp), ("g", _vp), ("gv", _vp), ("ld_x", _i64), ("ld_g", _i64)]
 
 
 _SIGS = {
     "vbnn_abi_version": ([], _i),
     "vbnn_last_error": ([], C.c_char_p),
     "vbnn_debug_set": ([_i, _i], _i),
+    "vbnn_kmajor_supported": ([_i64, _i64, _i64], _i),
     "vbnn_ctx_create": ([_i, _vp, C.POINTER(_vp)], _i),
     "vbnn_ctx_destroy": ([_vp], _i),
     "vbnn_ctx_set_stream": ([_vp, _vp], _i),

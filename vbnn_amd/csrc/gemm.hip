@@ -11,6 +11,7 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; 
 // (gemm_v2.h) whenever the operands allow it, 3 = its 256 x 256 two-pass variant (gemm_v3.h) whenever they do.
 // Test / A-B hook: vbnn_debug_set(VBNN_DEBUG_GEMM_KERNEL, ..).
 static int g_force_kernel = 0;
+static int g_kmajor = 1;              // K-major operands when the shape allows (vbnn_debug_set key 6)
 
 extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_GEMM_KERNEL && value >= 0 && value <= 3) { g_force_kernel = value; return VBNN_OK; }
@@ -19,19 +20,48 @@ extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_V2_SPLITK && value >= -1 && value <= 1) { g_v2_split = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V3_MIN_K && value >= 64) { g_v3_min_k = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_PSPLIT && value >= -1 && value <= 1) { g_v2_psplit = value; return VBNN_OK; }
+    if (key == VBNN_DEBUG_KMAJOR && value >= 0 && value <= 1) { g_kmajor = value; return VBNN_OK; }
     vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
     return VBNN_ERR_INVALID;
+}
+
+// would a GEMM of this shape run on gemm_v3 in its K-major form right now? (shape and debug keys only; the functor's
+// fast-path conditions are checked at launch)
+static bool kmajor_selected(int64_t M, int64_t N, int64_t K) {
+    if (!g_kmajor || K % V2_BK != 0) return false;
+    if (g_force_kernel == 3) return M % V3_BM == 0 && N % V3_BN == 0;
+    return g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_shape_ok(M, N, K);
+}
+extern "C" int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K) { return kmajor_selected(M, N, K) ? 1 : 0; }
+
+// the K-major launch (A and / or B stored [K][rows]); false = this shape / configuration does not take it
+template <typename T, bool DUAL, bool AK, bool BK, class Epi>
+static bool try_kmajor(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda, const void* B, const void* B2, int64_t ldb,
+                       int64_t M, int64_t N, int64_t K, const Epi& epi, int* status) {
+    if constexpr (sizeof(T) != 2) {
+        return false;
+    } else {
+        if (!A || !B || (DUAL && (!A2 || !B2)) || !kmajor_selected(M, N, K) || !gemm_v3_possible(M, N, K, lda, ldb, AK, BK, epi))
+            return false;
+        *status = launch_gemm_v3<T, DUAL, AK, BK, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb, (int)M,
+                                                       (int)N, (int)K, epi);
+        return true;
+    }
 }
 
 template <typename T, bool DUAL, class Epi>
 static int launch_gemm(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda, const void* B, const void* B2,
                        int64_t ldb, int64_t M, int64_t N, int64_t K, const Epi& epi) {
+    if (!A || !B || (DUAL && (!A2 || !B2))) {
+        vbnn_set_error("the K-contiguous operands are required for this shape (vbnn_kmajor_supported says no)");
+        return VBNN_ERR_INVALID;
+    }
     const bool v2_ok = gemm_v2_possible<T>(lda, ldb);
     if (v2_ok && sizeof(T) == 2 &&
-        ((g_force_kernel == 3 && gemm_v3_possible(M, N, lda, ldb, epi)) ||
-         (g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_eligible(M, N, K, lda, ldb, epi))))
-        return launch_gemm_v3<T, DUAL, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb, (int)M, (int)N,
-                                            (int)K, epi);
+        ((g_force_kernel == 3 && gemm_v3_possible(M, N, K, lda, ldb, false, false, epi)) ||
+         (g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_eligible(M, N, K, lda, ldb, false, false, epi))))
+        return launch_gemm_v3<T, DUAL, false, false, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb, (int)M,
+                                                          (int)N, (int)K, epi);
     if (v2_ok && g_force_kernel != 1 && (g_force_kernel == 2 || gemm_v2_eligible<T>(M, N, K, lda, ldb)))
         return launch_gemm_v2<T, DUAL, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
                                             (int)M, (int)N, (int)K, epi);
@@ -60,7 +90,7 @@ static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
 template <typename T>
 static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
     EpiDx<T> e;
-    e.dual = a->w2T != nullptr;
+    e.dual = a->gv != nullptr;
     e.x = (const T*)a->x; e.ld_x = a->ld_x;
     e.gx = a->gx; e.ld_gx = a->ld_gx; e.gx_vec = a->gx && aligned16(a->gx) && (a->ld_gx % 4 == 0);
     e.relu_mask = a->relu_mask;
@@ -70,14 +100,19 @@ static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
     e.g_prev = (T*)a->g_prev; e.gv_prev = (T*)a->gv_prev; e.ld_gp = a->ld_gp;
     e.gT_prev = (T*)a->gT_prev; e.gvT_prev = (T*)a->gvT_prev; e.ld_gpT = a->ld_gpT;
     e.I = (int)a->I; e.N = (int)a->N;
-    if (a->w2T) return launch_gemm<T, true>(ctx, a->wT, a->w2T, a->ld_wT, a->g, a->gv, a->ld_g, a->I, a->N, a->O, e);
+    const bool dual = a->gv != nullptr;
+    int st = VBNN_OK;                                        // K-major weights first (no transposed shadows needed)
+    if (dual ? try_kmajor<T, true, true, false>(ctx, a->w, a->w2, a->ld_w, a->g, a->gv, a->ld_g, a->I, a->N, a->O, e, &st)
+             : try_kmajor<T, false, true, false>(ctx, a->w, nullptr, a->ld_w, a->g, nullptr, a->ld_g, a->I, a->N, a->O, e, &st))
+        return st;
+    if (dual) return launch_gemm<T, true>(ctx, a->wT, a->w2T, a->ld_wT, a->g, a->gv, a->ld_g, a->I, a->N, a->O, e);
     return launch_gemm<T, false>(ctx, a->wT, nullptr, a->ld_wT, a->g, nullptr, a->ld_g, a->I, a->N, a->O, e);
 }
 
 template <typename T>
 static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
     EpiDw e;
-    e.lrt = a->x2T != nullptr;
+    e.lrt = (a->x2T != nullptr) || (a->x2 != nullptr);
     e.scale = a->scale; e.accumulate = a->accumulate;
     e.gradWeight = a->gradWeight; e.gradSum = a->gradSum;
     e.vec = (a->I % 4 == 0) && (!a->lvars || aligned16(a->lvars)) && (!a->means || aligned16(a->means)) &&
@@ -90,7 +125,13 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
     e.gradBias = a->gradBias;
     e.I = (int)a->I; e.O = (int)a->O;
     const int64_t M = a->I + (a->gradBias ? 1 : 0);          // the ones row of xT rides along as one more output row
-    if (a->x2T) return launch_gemm<T, true>(ctx, a->xT, a->x2T, a->ld_n, a->gT, a->gvT, a->ld_n, M, a->O, a->N, e);
+    const bool dual = e.lrt != 0;
+    int st = VBNN_OK;                                        // K-major x, g first (no transposed copies needed)
+    if (!a->gradBias &&
+        (dual ? try_kmajor<T, true, true, true>(ctx, a->x, a->x2, a->ld_x, a->g, a->gv, a->ld_g, a->I, a->O, a->N, e, &st)
+              : try_kmajor<T, false, true, true>(ctx, a->x, nullptr, a->ld_x, a->g, nullptr, a->ld_g, a->I, a->O, a->N, e, &st)))
+        return st;
+    if (dual) return launch_gemm<T, true>(ctx, a->xT, a->x2T, a->ld_n, a->gT, a->gvT, a->ld_n, M, a->O, a->N, e);
     return launch_gemm<T, false>(ctx, a->xT, nullptr, a->ld_n, a->gT, nullptr, a->ld_n, M, a->O, a->N, e);
 }
 
@@ -117,9 +158,10 @@ extern "C" int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a) {
 extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && a, "null ctx/args");
-    VBNN_REQUIRE(a->wT && a->g, "wT and g are required");
-    VBNN_REQUIRE((a->w2T == nullptr) == (a->gv == nullptr), "w2T and gv go together (LRT pair)");
-    VBNN_REQUIRE(!a->w2T || a->x, "LRT gradInput needs the layer input x");
+    VBNN_REQUIRE((a->wT || a->w) && a->g, "wT (or the K-major w) and g are required");
+    VBNN_REQUIRE(!a->wT || ((a->w2T == nullptr) == (a->gv == nullptr)), "w2T and gv go together (LRT pair)");
+    VBNN_REQUIRE(!a->w || ((a->w2 == nullptr) == (a->gv == nullptr)), "w2 and gv go together (LRT pair)");
+    VBNN_REQUIRE(!a->gv || a->x, "LRT gradInput needs the layer input x");
     VBNN_REQUIRE(!a->relu_mask || a->x, "relu_mask needs the layer input x");
     VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
     VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
@@ -138,11 +180,12 @@ extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) 
 extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && a, "null ctx/args");
-    VBNN_REQUIRE(a->xT && a->gT, "xT and gT are required");
+    VBNN_REQUIRE((a->xT && a->gT) || (a->x && a->g), "xT and gT (or the K-major x and g) are required");
     VBNN_REQUIRE((a->x2T == nullptr) == (a->gvT == nullptr), "x2T and gvT go together (LRT pair)");
+    VBNN_REQUIRE((a->x2 == nullptr) == (a->gv == nullptr), "x2 and gv go together (LRT pair)");
     VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
     VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
-    VBNN_REQUIRE(!(a->x2T && (a->gradSum || a->grad_lv)) || a->lvars, "LRT gradSum/grad_lv need lvars");
+    VBNN_REQUIRE(!((a->x2T || a->x2) && (a->gradSum || a->grad_lv)) || a->lvars, "LRT gradSum/grad_lv need lvars");
     VBNN_REQUIRE(!(a->grad_mu || a->grad_lv) || (a->means && a->lvars && a->stats && a->B > 0 && a->S > 0),
                  "fused total gradients need means, lvars, stats, B, S");
     if (dtype == VBNN_F32) return acc_grad_t<float>(ctx, a);

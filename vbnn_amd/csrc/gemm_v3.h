@@ -38,7 +38,17 @@ static int g_v3_min_k = 704;        // shortest K the shape selection gives to t
 template <> __device__ __forceinline__ void v2_wait_vmcnt<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 template <> __device__ __forceinline__ void v2_wait_vmcnt<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
 
-template <bool DUAL, class Epi>
+// AK / BK: the operand is stored K-MAJOR -- element (row, k) at X[k * ld + row], i.e. the untransposed activation /
+// gradient / weight matrix -- instead of K-contiguous. Its tile then lies in LDS as [64 k][rows] and the MFMA fragments
+// (8 consecutive k of one row per lane) are read with ds_read_b64_tr_b16, the hardware 4 x 16 transpose read, two per
+// fragment. This is what lets accGradParameters consume x and g as the forward / gradInput GEMMs already hold them
+// (no transposed copies written by any epilogue) and gradInput consume mu, sigma^2 as stored (no transposed shadows).
+//   LDS image   A part: 64 k-rows x 256 B (the 64 m of wave row 0, then of wave row 1); B tile: 64 k-rows x 512 B
+//   swizzle     16-byte chunk index ^= 2 h(k), h(k) = (k & 3) | ((k >> 3) & 1) << 2, on the DMA source and on the read: the
+//               8 k-rows x 32 B a half-wave's tr read touches fall on 8 distinct 32-byte bank slots
+//   fragment    lane 4 r + p of a 16-lane group addresses (k-row r, columns 4 p .. 4 p + 3) of the 4 x 16 block and
+//               receives column (lane & 15) of its four rows: k = 32 s + 8 q + 0..3, then + 4..7 with the second read
+template <bool DUAL, bool AK, bool BK, class Epi>
 __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                      const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
                                                      int M, int N, int nk, int tiles_m, int tiles_n, float* mscratch, Epi epi) {
@@ -74,31 +84,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     // ---- LDS-DMA source offsets (elements), shared by both passes. A part P, DMA d: 8-row group g = wave + 8 d of
     // the part's 128 rows; part row s belongs to wave row s >> 6 and is tile row (s >> 6) * 128 + 64 P + (s & 63).
     int a_off[2][2], b_off[4];                 // 32-bit: the launcher checks rows x ld < 2^31
+    auto hk = [](int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); };
 #pragma unroll
     for (int P = 0; P < 2; ++P)
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-            const int s = 8 * (wave + 8 * d) + (lane >> 3);
-            const int row = (s >> 6) * 128 + 64 * P + (s & 63);
-            const int chunk = (lane & 7) ^ ((s >> 1) & 7);
-            a_off[P][d] = min(m0 + row, M - 1) * (int)lda + chunk * 8;
+            if (AK) {                          // instruction g = wave + 8 d: k-rows 4 g .. 4 g + 3, 16 chunks each
+                const int kr = 4 * (wave + 8 * d) + (lane >> 4);
+                const int cs = (lane & 15) ^ (hk(kr) << 1);
+                a_off[P][d] = kr * (int)lda + m0 + (cs >> 3) * 128 + 64 * P + (cs & 7) * 8;
+            } else {
+                const int s = 8 * (wave + 8 * d) + (lane >> 3);
+                const int row = (s >> 6) * 128 + 64 * P + (s & 63);
+                const int chunk = (lane & 7) ^ ((s >> 1) & 7);
+                a_off[P][d] = min(m0 + row, M - 1) * (int)lda + chunk * 8;
+            }
         }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const int row = 8 * (wave + 8 * d) + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        b_off[d] = min(n0 + row, N - 1) * (int)ldb + chunk * 8;
+        if (BK) {                              // instruction g = wave + 8 d: k-rows 2 g, 2 g + 1, 32 chunks each
+            const int kr = 2 * (wave + 8 * d) + (lane >> 5);
+            const int cs = (lane & 31) ^ (hk(kr) << 1);
+            b_off[d] = kr * (int)ldb + n0 + cs * 8;
+        } else {
+            const int row = 8 * (wave + 8 * d) + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            b_off[d] = min(n0 + row, N - 1) * (int)ldb + chunk * 8;
+        }
     }
+    const int a_kstep = AK ? V2_BK * (int)lda : V2_BK, b_kstep = BK ? V2_BK * (int)ldb : V2_BK;
     const bf16_t* Ap = A;
     const bf16_t* Bp = B;
     auto dma_a = [&](int t, auto P_c, auto d_c) {
         constexpr int P = decltype(P_c)::value, D = decltype(d_c)::value;
-        __builtin_amdgcn_global_load_lds((gptr_t)(Ap + (a_off[P][D] + t * V2_BK)),
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ap + (a_off[P][D] + t * a_kstep)),
                                          (lptr_t)(lds + ((t & 1) * 2 + P) * V3_APART + (wave + 8 * D) * 1024), 16, 0, 0);
     };
     auto dma_b = [&](int t, int slot, auto d_c) {
         constexpr int D = decltype(d_c)::value;
-        __builtin_amdgcn_global_load_lds((gptr_t)(Bp + (b_off[D] + t * V2_BK)),
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bp + (b_off[D] + t * b_kstep)),
                                          (lptr_t)(lds + 4 * V3_APART + slot * V3_BTILE + (wave + 8 * D) * 1024), 16, 0, 0);
     };
     std::integral_constant<int, 0> c0;
@@ -116,6 +140,60 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         a_rd[s] = (wr * 64 + (lane & 15)) * 128 + csw;
         b_rd[s] = (wc * 64 + (lane & 15)) * 128 + csw;
     }
+
+    // K-major operands: transpose reads. Lane j = lane & 15 of its group addresses k-row (j >> 2), columns 4 (j & 3) ..
+    typedef __attribute__((address_space(3))) bf16x4* lds4_t;
+    const int trq = (lane & 15) >> 2, trp = lane & 3;
+    const int thx = (trq | ((q & 1) << 2)) << 1;              // 2 h(k) of this lane's k-rows (same for both reads)
+    int a_tr[4], b_tr[4];                                     // byte offset of the lane's 8 bytes, per 16-row block
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_tr[i] = (8 * q + trq) * 256 + (((wr * 8 + 2 * i + (trp >> 1)) ^ thx) * 16) + (trp & 1) * 8;
+        b_tr[i] = (8 * q + trq) * 512 + (((wc * 8 + 2 * i + (trp >> 1)) ^ thx) * 16) + (trp & 1) * 8;
+    }
+    // The four fragments of one k-half. K-major: eight transpose reads and their wait in ONE asm statement -- through the
+    // builtin hipcc cannot tell that the read does not alias the LDS-DMA writes in flight and drains vmcnt(0) in front
+    // of every group (the whole pipeline, every half phase: 245 vs 191 us at 4096^3); inline asm is outside that
+    // bookkeeping, and the DMA -> read ordering is this kernel's own counted vmcnt + barrier, as for the plain reads.
+    typedef __attribute__((address_space(3))) unsigned char* ldsb_t;
+    auto tr_load4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x8 (&f)[4]) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI)
+                     : "memory");
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto load_a = [&](const unsigned char* sa, auto s_c, bf16x8 (&f)[4]) {
+        constexpr int S = decltype(s_c)::value;
+        if constexpr (AK) {
+            const unsigned base = (unsigned)(uintptr_t)(ldsb_t)sa;
+            tr_load4(base + a_tr[0], base + a_tr[1], base + a_tr[2], base + a_tr[3], std::integral_constant<int, S * 8192>(),
+                     std::integral_constant<int, S * 8192 + 1024>(), f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[S] + i * 2048);
+        }
+    };
+    auto load_b = [&](const unsigned char* sb, auto s_c, bf16x8 (&f)[4]) {
+        constexpr int S = decltype(s_c)::value;
+        if constexpr (BK) {
+            const unsigned base = (unsigned)(uintptr_t)(ldsb_t)sb;
+            tr_load4(base + b_tr[0], base + b_tr[1], base + b_tr[2], base + b_tr[3], std::integral_constant<int, S * 16384>(),
+                     std::integral_constant<int, S * 16384 + 2048>(), f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = *reinterpret_cast<const bf16x8*>(sb + b_rd[S] + j * 2048);
+        }
+    };
 
     f32x4 acc[8][4];
     auto zero_acc = [&]() {
@@ -147,14 +225,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             __builtin_amdgcn_s_barrier();
             {
                 const unsigned char* sa = lds + ((t & 1) * 2 + 0) * V3_APART;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                auto half = [&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
                     bf16x8 af[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[s] + i * 2048);
-                        bf[s][i] = *reinterpret_cast<const bf16x8*>(sb + b_rd[s] + i * 2048);
-                    }
+                    load_a(sa, s_c, af);
+                    load_b(sb, s_c, bf[s]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -166,18 +241,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                         if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c1);
                         if (i & 1) __builtin_amdgcn_sched_barrier(0);      // keep each DMA where it was put
                     }
-                }
+                };
+                half(c0); half(c1);
             }
             // ------------------------------------------------ phase 1: A rows 64..127 of the wave, B from registers
             if (t == nk - 1) v2_wait_vmcnt<0>(); else if (t == nk - 2) v2_wait_vmcnt<8>(); else v2_wait_vmcnt<10>();
             __builtin_amdgcn_s_barrier();
             {
                 const unsigned char* sa = lds + ((t & 1) * 2 + 1) * V3_APART;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                auto half = [&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
                     bf16x8 af[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[s] + i * 2048);
+                    load_a(sa, s_c, af);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -189,7 +264,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                         if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c3);
                         if (i & 1) __builtin_amdgcn_sched_barrier(0);
                     }
-                }
+                };
+                half(c0); half(c1);
             }
             bs = bs == 2 ? 0 : bs + 1;
         }
@@ -367,21 +443,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
 
 // The kernel has no ragged-edge or general-output path: whole 256 x 256 tiles, 32-bit element offsets, the functor's
 // fast protocol and 16-byte rows of the transposed outputs. Everything else stays with gemm_v2.h.
+// (K-major operands: lda / ldb are the pitches of the K rows; K must be whole 64-row steps -- there is no padding row to
+// clamp to -- and the row pitch a multiple of 8 elements for the 16-byte DMA chunks.)
 template <class Epi>
-static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t lda, int64_t ldb, const Epi& epi) {
+static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, bool ak, bool bk, const Epi& epi) {
     Epi e = epi;
     const bool t_ok = (!e.t1_ptr() && !e.t2_ptr()) ||
                       ((e.t_ld() % 8 == 0) && ((((uintptr_t)e.t1_ptr() | (uintptr_t)e.t2_ptr()) & 15u) == 0));
-    return (M % V3_BM == 0) && (N % V3_BN == 0) && M * lda < (1ll << 31) && N * ldb < (1ll << 31) && epi.fast_ok() && t_ok &&
-           M * e.t_ld() < (1ll << 31);
+    const bool a_ok = ak ? (K % V2_BK == 0 && lda % 8 == 0 && lda >= M && K * lda < (1ll << 31)) : M * lda < (1ll << 31);
+    const bool b_ok = bk ? (K % V2_BK == 0 && ldb % 8 == 0 && ldb >= N && K * ldb < (1ll << 31)) : N * ldb < (1ll << 31);
+    return (M % V3_BM == 0) && (N % V3_BN == 0) && a_ok && b_ok && epi.fast_ok() && t_ok && M * e.t_ld() < (1ll << 31);
 }
 // Worth it when K is long enough to amortise the second pipeline fill and the fold between the passes (measured against
 // gemm_v2's dual tile on 4096 x 4096 outputs: K = 4096 forward 212 vs 252 us, K = 784 forward 93 vs 99 us) and the
 // tile count fills whole rounds of CUs better than the half-size dual tiles would: a 256 x 256 two-pass tile costs about
 // 1.85x a 256 x 128 dual tile (235 vs 127 us at K = 4096), so compare rounds x cost on the device's CUs.
+// shape part of the choice (also answers vbnn_kmajor_supported: the host decides from it whether to keep transposed copies)
+static inline bool gemm_v3_shape_ok(int64_t M, int64_t N, int64_t K) {
+    if (M % V3_BM || N % V3_BN || K < g_v3_min_k) return false;
+    const int64_t cus = 256;
+    const int64_t t3 = (M / V3_BM) * (N / V3_BN), t2 = 2 * t3;
+    if (t3 < 192) return false;
+    const int64_t r3 = (t3 + cus - 1) / cus, r2 = (t2 + cus - 1) / cus;
+    return 185 * r3 <= 100 * r2;
+}
 template <class Epi>
-static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, const Epi& epi) {
-    if (!gemm_v3_possible(M, N, lda, ldb, epi) || K < g_v3_min_k) return false;
+static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, bool ak, bool bk, const Epi& epi) {
+    if (!gemm_v3_possible(M, N, K, lda, ldb, ak, bk, epi) || K < g_v3_min_k) return false;
     const int64_t cus = 256;
     const int64_t t3 = (M / V3_BM) * (N / V3_BN), t2 = 2 * t3;
     if (t3 < 192) return false;                               // fewer than 3/4 of the CUs busy: the half-size tiles win
@@ -389,7 +477,7 @@ static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda
     return 185 * r3 <= 100 * r2;
 }
 
-template <typename T, bool DUAL, class Epi>
+template <typename T, bool DUAL, bool AK, bool BK, class Epi>
 static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, const T* B, const T* B2, int64_t ldb, int M, int N,
                           int K, const Epi& epi) {
     if constexpr (sizeof(T) != 2) {
@@ -401,11 +489,11 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
             return VBNN_ERR_INVALID;
         }
         const int nk = (K + V2_BK - 1) / V2_BK;
-        if (lda < (int64_t)nk * V2_BK || ldb < (int64_t)nk * V2_BK) {
+        if ((!AK && lda < (int64_t)nk * V2_BK) || (!BK && ldb < (int64_t)nk * V2_BK)) {
             vbnn_set_error("packed leading dimension too small for K=%d", K);
             return VBNN_ERR_INVALID;
         }
-        if (!gemm_v3_possible(M, N, lda, ldb, epi)) { vbnn_set_error("gemm_v3: shape / outputs outside its fast path"); return VBNN_ERR_UNSUPPORTED; }
+        if (!gemm_v3_possible(M, N, K, lda, ldb, AK, BK, epi)) { vbnn_set_error("gemm_v3: shape / outputs outside its fast path"); return VBNN_ERR_UNSUPPORTED; }
         const int tiles_m = (M + V3_BM - 1) / V3_BM, tiles_n = (N + V3_BN - 1) / V3_BN;
         const size_t need = (DUAL && Epi::PARK) ? (size_t)tiles_m * tiles_n * V3_BM * V3_BN * sizeof(float) : 0;
         if (need > ctx->park_bytes) {                        // the parking tiles (grown on demand, kept)
@@ -417,7 +505,7 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
             ctx->park_bytes = need;
         }
         float* park = ctx->park;
-        const void* kern = (const void*)gemm_nt_v3<DUAL, Epi>;
+        const void* kern = (const void*)gemm_nt_v3<DUAL, AK, BK, Epi>;
         static bool configured = false;                      // per instantiation
         if (!configured) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);

@@ -121,6 +121,21 @@ class FusedMLP:
             return
         self._N = N
         dev, tdt = self.device, self.tdt
+        lib = L.lib()
+        # K-major operands (vbnn_kmajor_supported): when a layer's parameter-gradient GEMM reads x and g as the forward
+        # / gradInput GEMMs hold them, nobody has to write x^T, (x.x)^T, g^T, gv^T for it; when its gradInput GEMM reads
+        # mu, sigma^2 as stored, the parameter sweep writes no transposed shadows. The library decides by shape; the
+        # fused configuration that takes that kernel is bf16, LRT, total gradients from the epilogue, one draw.
+        km_ok = (self.opt.get("dtype", "f32") == "bf16") and not self.opt.get("keep_transposes", False)
+        need_prepare = False
+        for li, v in enumerate(self.vb):
+            v.dw_km = bool(km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1 and
+                           lib.vbnn_kmajor_supported(v.I, v.O, N))
+            v.dx_km = bool(km_ok and li > 0 and lib.vbnn_kmajor_supported(v.I, N, v.O))
+            use_muT = (li > 0) and not v.dx_km
+            if use_muT and not getattr(v, "use_muT", True):
+                need_prepare = True                            # the shadows' transposes were being skipped: refresh them
+            v.use_muT = use_muT
         for v in self.vb:
             v.x_s, v.x2_s = _Packed(N, v.I, tdt, dev), _Packed(N, v.I, tdt, dev)
             # Layers whose parameter-gradient GEMM is not the whole-tile 256 x 256 kernel anyway (I % 256 != 0: the
@@ -129,11 +144,14 @@ class FusedMLP:
             last_fused = (v is self.vb[-1]) and self.n_classes <= 16
             v.bias_from_dw = (v.I % 256 != 0) and not last_fused
             extra = 1 if v.bias_from_dw else 0
-            v.xT_s, v.x2T_s = _Packed(v.I + extra, N, tdt, dev), _Packed(v.I + extra, N, tdt, dev)
-            if v.bias_from_dw:
-                v.xT_s.t[v.I, :N] = 1.0
+            if v.dw_km:
+                v.xT_s = v.x2T_s = v.gT_s = v.gvT_s = None
+            else:
+                v.xT_s, v.x2T_s = _Packed(v.I + extra, N, tdt, dev), _Packed(v.I + extra, N, tdt, dev)
+                v.gT_s, v.gvT_s = _Packed(v.O, N, tdt, dev), _Packed(v.O, N, tdt, dev)
+                if v.bias_from_dw:
+                    v.xT_s.t[v.I, :N] = 1.0
             v.g_s, v.gv_s = _Packed(N, v.O, tdt, dev), _Packed(N, v.O, tdt, dev)
-            v.gT_s, v.gvT_s = _Packed(v.O, N, tdt, dev), _Packed(v.O, N, tdt, dev)
             v.r = torch.zeros(N, v.O, dtype=tdt, device=dev)          # z / (2 sqrt(v)), stored in the operand type
         H = self.sizes[-1]
         self.h_s = _Packed(N, H, tdt, dev)            # input of the final Linear
@@ -143,6 +161,8 @@ class FusedMLP:
         self.out = torch.zeros(N, self.n_classes, dtype=torch.float32, device=dev)
         self.g3_s = _Packed(N, self.n_classes, tdt, dev)
         self.g3T_s = _Packed(self.n_classes, N, tdt, dev)
+        if need_prepare:
+            self.prepare()
 
     # ---- mlp.lua:62-67. Nothing is zeroed: the first accGradParameters of the minibatch overwrites the gradients
     # and the first criterion pass overwrites the loss / hit accumulators.
@@ -157,8 +177,9 @@ class FusedMLP:
             descs = (L.PrepDesc * len(self.vb))()
             for k, v in enumerate(self.vb):
                 descs[k] = L.PrepDesc(means=_p(v.means), lvars=_p(v.lvars), O=v.O, I=v.I, mu_s=v.mu_s.ptr, var_s=v.var_s.ptr,
-                                      ld_w=v.mu_s.ld, muT_s=v.muT_s.ptr if v.muT_s else None,
-                                      varT_s=v.varT_s.ptr if v.varT_s else None, ld_wT=v.muT_s.ld if v.muT_s else 0,
+                                      ld_w=v.mu_s.ld, muT_s=v.muT_s.ptr if (v.muT_s and getattr(v, "use_muT", True)) else None,
+                                      varT_s=v.varT_s.ptr if (v.varT_s and getattr(v, "use_muT", True)) else None,
+                                      ld_wT=v.muT_s.ld if v.muT_s else 0,
                                       stats=_p(v.stats))
             w3 = L.PackDesc(src=_p(self.weight3), rows=self.n_classes, cols=self.sizes[-1], ld_src=self.sizes[-1],
                             dst=self.w3_s.ptr, ld_dst=self.w3_s.ld, dstT=self.w3T_s.ptr, ld_dstT=self.w3T_s.ld)
@@ -279,15 +300,19 @@ class FusedMLP:
                          h=self.h_s.ptr if last else nxt.x_s.ptr,
                          h2=None if (last or not lrt) else nxt.x2_s.ptr,
                          ld_h=self.h_s.ld if last else nxt.x_s.ld,
-                         hT=(None if self.n_classes <= 16 else self.hT_s.ptr) if last else nxt.xT_s.ptr,
-                         h2T=None if (last or not lrt) else nxt.x2T_s.ptr,
-                         ld_hT=self.hT_s.ld if last else nxt.xT_s.ld)
+                         hT=(None if self.n_classes <= 16 else self.hT_s.ptr) if last else (nxt.xT_s.ptr if nxt.xT_s else None),
+                         h2T=None if (last or not lrt or not nxt.x2T_s) else nxt.x2T_s.ptr,
+                         ld_hT=self.hT_s.ld if last else (nxt.xT_s.ld if nxt.xT_s else 0))
 
     def _dw_args(self, li, N, accumulate):
         v, lrt = self.vb[li], self._lrt()
-        d = L.DwArgs(xT=v.xT_s.ptr, x2T=v.x2T_s.ptr if lrt else None, gT=v.gT_s.ptr,
-                     gvT=v.gvT_s.ptr if lrt else None, ld_n=v.xT_s.ld, N=N, I=v.I, O=v.O, scale=1.0,
-                     accumulate=accumulate, seed=self.seed, layer=v.layer_id, draw=self.draw, lvars=_p(v.lvars))
+        has_t = v.xT_s is not None
+        d = L.DwArgs(xT=v.xT_s.ptr if has_t else None, x2T=v.x2T_s.ptr if (lrt and has_t) else None,
+                     gT=v.gT_s.ptr if has_t else None, gvT=v.gvT_s.ptr if (lrt and has_t) else None,
+                     ld_n=v.xT_s.ld if has_t else 0, N=N, I=v.I, O=v.O, scale=1.0,
+                     accumulate=accumulate, seed=self.seed, layer=v.layer_id, draw=self.draw, lvars=_p(v.lvars),
+                     x=v.x_s.ptr, x2=v.x2_s.ptr if lrt else None, g=v.g_s.ptr, gv=v.gv_s.ptr if lrt else None,
+                     ld_x=v.x_s.ld, ld_g=v.g_s.ld)
         if self.fuse_kl:
             d.gradWeight, d.gradSum = None, None
             d.grad_mu, d.grad_lv = _p(v.gradWeight), _p(v.gradSum)
@@ -300,12 +325,15 @@ class FusedMLP:
 
     def _dx_args(self, li, N):
         v, p, lrt = self.vb[li], self.vb[li - 1], self._lrt()
-        return L.DxArgs(wT=v.muT_s.ptr, w2T=v.varT_s.ptr if lrt else None, g=v.g_s.ptr,
+        use_t = v.use_muT
+        return L.DxArgs(wT=v.muT_s.ptr if use_t else None, w2T=v.varT_s.ptr if (lrt and use_t) else None, g=v.g_s.ptr,
                         gv=v.gv_s.ptr if lrt else None, ld_wT=v.muT_s.ld, ld_g=v.g_s.ld, N=N, I=v.I, O=v.O,
                         x=v.x_s.ptr, ld_x=v.x_s.ld, gx=None, ld_gx=0, relu_mask=1,
                         r_prev=_p(p.r) if lrt else None, ld_r_prev=p.O, r_prev_packed=1, g_prev=p.g_s.ptr,
-                        gv_prev=p.gv_s.ptr if lrt else None, ld_gp=p.g_s.ld, gT_prev=p.gT_s.ptr,
-                        gvT_prev=p.gvT_s.ptr if lrt else None, ld_gpT=p.gT_s.ld)
+                        gv_prev=p.gv_s.ptr if lrt else None, ld_gp=p.g_s.ld,
+                        gT_prev=p.gT_s.ptr if p.gT_s else None, gvT_prev=p.gvT_s.ptr if (lrt and p.gvT_s) else None,
+                        ld_gpT=p.gT_s.ld if p.gT_s else 0,
+                        w=v.mu_s.ptr, w2=v.var_s.ptr if lrt else None, ld_w=v.mu_s.ld)
 
     # ---- mlp.lua:76-84, fused
     def run(self, inputs, targets, row0=None, backward=True):
@@ -321,7 +349,8 @@ class FusedMLP:
         inv_n = 1.0 / (N * self.world)
         v0 = self.vb[0]
         L.check(lib.vbnn_pack_input(ctx, code, _p(x), x.stride(0), N, v0.I, v0.x_s.ptr, v0.x2_s.ptr if lrt else None,
-                                    v0.x_s.ld, v0.xT_s.ptr, v0.x2T_s.ptr if lrt else None, v0.xT_s.ld))
+                                    v0.x_s.ld, v0.xT_s.ptr if v0.xT_s else None,
+                                    v0.x2T_s.ptr if (lrt and v0.x2T_s) else None, v0.xT_s.ld if v0.xT_s else 0))
         nl = len(self.vb)
         # ---------------- forward
         for li in range(nl):
@@ -343,8 +372,8 @@ class FusedMLP:
                                            _p(self.g_logits), N, H, Cn, accumulate, _p(self.gradWeight3),
                                            _p(self.gradBias3), _p(vl.gradBias), 1, _p(vl.r) if lrt else None, vl.O, 1,
                                            vl.g_s.ptr,
-                                           vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr,
-                                           vl.gvT_s.ptr if lrt else None, vl.gT_s.ld))
+                                           vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr if vl.gT_s else None,
+                                           vl.gvT_s.ptr if (lrt and vl.gvT_s) else None, vl.gT_s.ld if vl.gT_s else 0))
             self._reduce(self.bucket3)
         else:
             self._generic_head(N, targets, inv_n, accumulate)
