@@ -31,7 +31,7 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
     static constexpr bool SPLITTABLE = false;
     __device__ __forceinline__ void set_part(int) {}
     static constexpr int FOLD_BATCH = 8;
-    static constexpr bool FOLD_SERIAL = false;
+    static constexpr int FOLD_SERIAL = 0;
     struct Pre {};
     struct FPre {};
     struct Lane { unsigned o; };

@@ -176,7 +176,7 @@ struct EpiFwd {
 #ifndef VBNN_FWD_PARK           // default: the noise term b + sqrt(v) z (and r) is formed between the passes
     static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 1;          // m-blocks per batch of fold loads (only the bias here)
-    static constexpr bool FOLD_SERIAL = true;     // a Philox block per quad: keep them one at a time
+    static constexpr int FOLD_SERIAL = 1;         // a Philox block per quad: at most this many in flight (0 = no limit; 2 spills 24 registers and is no faster)
     struct FPre { f32x4 b; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         (void)un;
@@ -217,7 +217,7 @@ struct EpiFwd {
     // from the bias, the noise is applied in the final epilogue (+128 MB of L2/MALL traffic per launch)
     static constexpr bool PARK = true;
     static constexpr int FOLD_BATCH = 1;
-    static constexpr bool FOLD_SERIAL = false;
+    static constexpr int FOLD_SERIAL = 0;
     struct FPre { f32x4 b; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         (void)un;
@@ -333,7 +333,7 @@ struct EpiDx {
     // ---- fold protocol (LRT only: acc2 = gv sigma^2): the accumulator continues from 2 x . acc2
     static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 8;          // all 32 quads' x loads (64 registers) in flight together
-    static constexpr bool FOLD_SERIAL = false;
+    static constexpr int FOLD_SERIAL = 0;
     struct FPre { typename V4<T>::type x; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         FPre p;
@@ -508,7 +508,7 @@ struct EpiDw {
     // (its stores drain under the second pass) and the second pass starts from zero
     static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 4;          // 16 quads' lvars loads (64 registers) in flight together
-    static constexpr bool FOLD_SERIAL = false;
+    static constexpr int FOLD_SERIAL = 0;
     struct FPre { f32x4 lv; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         FPre p;

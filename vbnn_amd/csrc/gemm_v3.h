@@ -344,10 +344,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[i0 + b][j] = epi.fold(fm0 + 16 * (i0 + b), fn0 + 16 * j, fln, acc[i0 + b][j], fp[b][j]);
-                    if (Epi::FOLD_SERIAL)       // one quad at a time, also for the optimiser: the next quad's coordinates
-                        asm volatile("" : "+s"(fn0), "+s"(fm0)          // "depend" on this result (32 interleaved Philox
-                                     : "v"(acc[i0 + b][j][0]), "v"(acc[i0 + b][j][1]),       // blocks beside 128 live
-                                       "v"(acc[i0 + b][j][2]), "v"(acc[i0 + b][j][3]));      // accumulators spill)
+                    // FOLD_SERIAL quads at a time, also for the optimiser: the next group's coordinates "depend" on this
+                    // result (32 interleaved Philox blocks beside 128 live accumulators spill; two at a time fit and
+                    // give the VALU two independent dependency chains)
+                    if (Epi::FOLD_SERIAL > 0 && (j % Epi::FOLD_SERIAL) == Epi::FOLD_SERIAL - 1)
+                        asm volatile("" : "+s"(fn0), "+s"(fm0)
+                                     : "v"(acc[i0 + b][j][0]), "v"(acc[i0 + b][j][1]), "v"(acc[i0 + b][j][2]), "v"(acc[i0 + b][j][3]),
+                                       "v"(acc[i0 + b][j ? j - 1 : 0][0]));
                 }
         };
         static_assert(8 % Epi::FOLD_BATCH == 0, "FOLD_BATCH divides the 8 m-blocks of a wave tile");
