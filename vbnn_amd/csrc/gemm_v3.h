@@ -172,6 +172,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
         f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
     };
+    // Pipelined transpose reads of the A fragments, two fragments (four reads) at a time: a pair is ISSUED by one asm
+    // statement and waited for by a later one that names its registers ("+v": every use comes after that wait), so the
+    // reads fly under the eight MFMAs of the pair before -- register-neutral (two pairs = the four fragments of before).
+    struct TrPair { bf16x4 l0, h0, l1, h1; };
+    auto tr_issue2 = [&](unsigned a0, unsigned a1, auto lo_c, auto hi_c, TrPair& o) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
+                     "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
+                     : "=v"(o.l0), "=v"(o.h0), "=v"(o.l1), "=v"(o.h1)
+                     : "v"(a0), "v"(a1), "n"(LO), "n"(HI)
+                     : "memory");
+    };
+    auto tr_wait2 = [&](TrPair& o) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.l0), "+v"(o.h0), "+v"(o.l1), "+v"(o.h1)::"memory");
+    };
     auto load_a = [&](const unsigned char* sa, auto s_c, bf16x8 (&f)[4]) {
         constexpr int S = decltype(s_c)::value;
         if constexpr (AK) {
@@ -225,47 +240,107 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             __builtin_amdgcn_s_barrier();
             {
                 const unsigned char* sa = lds + ((t & 1) * 2 + 0) * V3_APART;
-                auto half = [&](auto s_c) {
-                    constexpr int s = decltype(s_c)::value;
-                    bf16x8 af[4];
-                    load_a(sa, s_c, af);
-                    load_b(sb, s_c, bf[s]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s][j], acc[i][j], 0, 0, 0);
-                        if (s == 0 && i == 1 && n1) dma_a(t + 1, c1, c0);
-                        if (s == 0 && i == 3 && n1) dma_a(t + 1, c1, c1);
-                        if (s == 1 && i == 1 && n2) dma_b(t + 2, bs2, c0);
-                        if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c1);
-                        if (i & 1) __builtin_amdgcn_sched_barrier(0);      // keep each DMA where it was put
-                    }
+                auto dma_slot = [&](int s, int i) {
+                    if (s == 0 && i == 1 && n1) dma_a(t + 1, c1, c0);
+                    if (s == 0 && i == 3 && n1) dma_a(t + 1, c1, c1);
+                    if (s == 1 && i == 1 && n2) dma_b(t + 2, bs2, c0);
+                    if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c1);
                 };
-                half(c0); half(c1);
+                if constexpr (AK) {
+                    const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
+                    TrPair g[2];
+                    auto issue = [&](auto idx_c) {             // pair idx: k-half idx >> 1, fragments 2 (idx & 1), +1
+                        constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                        tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                  std::integral_constant<int, S * 8192 + 1024>(), g[IDX & 1]);
+                    };
+                    auto work = [&](auto idx_c) {
+                        constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                        TrPair& p = g[IDX & 1];
+                        tr_wait2(p);
+                        if constexpr (IDX < 3) issue(std::integral_constant<int, IDX + 1>());
+                        if constexpr (IDX == 1) load_b(sb, c1, bf[1]);       // the other k-half's B fragments
+                        const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bf[S][j], acc[F][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[F + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bf[S][j], acc[F + 1][j], 0, 0, 0);
+                        dma_slot(S, F + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    load_b(sb, c0, bf[0]);
+                    issue(c0);
+                    work(c0); work(c1); work(c2); work(c3);
+                } else {
+                    auto half = [&](auto s_c) {
+                        constexpr int s = decltype(s_c)::value;
+                        bf16x8 af[4];
+                        load_a(sa, s_c, af);
+                        load_b(sb, s_c, bf[s]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s][j], acc[i][j], 0, 0, 0);
+                            dma_slot(s, i);
+                            if (i & 1) __builtin_amdgcn_sched_barrier(0);      // keep each DMA where it was put
+                        }
+                    };
+                    half(c0); half(c1);
+                }
             }
             // ------------------------------------------------ phase 1: A rows 64..127 of the wave, B from registers
             if (t == nk - 1) v2_wait_vmcnt<0>(); else if (t == nk - 2) v2_wait_vmcnt<8>(); else v2_wait_vmcnt<10>();
             __builtin_amdgcn_s_barrier();
             {
                 const unsigned char* sa = lds + ((t & 1) * 2 + 1) * V3_APART;
-                auto half = [&](auto s_c) {
-                    constexpr int s = decltype(s_c)::value;
-                    bf16x8 af[4];
-                    load_a(sa, s_c, af);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s][j], acc[4 + i][j], 0, 0, 0);
-                        if (s == 0 && i == 1 && n2) dma_a(t + 2, c0, c0);
-                        if (s == 0 && i == 3 && n2) dma_a(t + 2, c0, c1);
-                        if (s == 1 && i == 1 && n2) dma_b(t + 2, bs2, c2);
-                        if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c3);
-                        if (i & 1) __builtin_amdgcn_sched_barrier(0);
-                    }
+                auto dma_slot = [&](int s, int i) {
+                    if (s == 0 && i == 1 && n2) dma_a(t + 2, c0, c0);
+                    if (s == 0 && i == 3 && n2) dma_a(t + 2, c0, c1);
+                    if (s == 1 && i == 1 && n2) dma_b(t + 2, bs2, c2);
+                    if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c3);
                 };
-                half(c0); half(c1);
+                if constexpr (AK) {
+                    const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
+                    TrPair g[2];
+                    auto issue = [&](auto idx_c) {
+                        constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                        tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                  std::integral_constant<int, S * 8192 + 1024>(), g[IDX & 1]);
+                    };
+                    auto work = [&](auto idx_c) {
+                        constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                        TrPair& p = g[IDX & 1];
+                        tr_wait2(p);
+                        if constexpr (IDX < 3) issue(std::integral_constant<int, IDX + 1>());
+                        const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[4 + F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bf[S][j], acc[4 + F][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[5 + F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bf[S][j], acc[5 + F][j], 0, 0, 0);
+                        dma_slot(S, F + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    issue(c0);
+                    work(c0); work(c1); work(c2); work(c3);
+                } else {
+                    auto half = [&](auto s_c) {
+                        constexpr int s = decltype(s_c)::value;
+                        bf16x8 af[4];
+                        load_a(sa, s_c, af);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s][j], acc[4 + i][j], 0, 0, 0);
+                            dma_slot(s, i);
+                            if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    };
+                    half(c0); half(c1);
+                }
             }
             bs = bs == 2 ? 0 : bs + 1;
         }
