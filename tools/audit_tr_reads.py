@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Audit of the split issue / wait inline-asm transpose reads in gemm_v3.h (K-major operands).
+
+A `ds_read_b64_tr_b16` issued by one asm statement is waited for by a LATER one; hipcc knows nothing about the
+load in flight, so nothing in between may read or write its destination registers (a compiler-inserted copy or spill
+there would move garbage). This script compiles csrc/gemm.hip to assembly and checks exactly that for every
+gemm_nt_v3 instantiation with a K-major operand. Run it after any change to gemm_v3.h or to the compiler:
+    python3 tools/audit_tr_reads.py        (CPU only; ~2 min)
+"""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def regs_of(tok):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def main():
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, "gemm.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include",
+                        f"-I{ROOT}/vbnn_amd/csrc", "-S", "--cuda-device-only", "-o", asm, f"{ROOT}/vbnn_amd/csrc/gemm.hip"],
+                       check=True, stderr=subprocess.DEVNULL)
+        txt = open(asm).read()
+    total_bad, kernels = 0, 0
+    for name in re.findall(r"^(_Z10gemm_nt_v3ILb[01]E(?:Lb1ELb[01]|Lb0ELb1)\S+):", txt, re.M):
+        a = txt.index(name + ":")
+        b = txt.index(".Lfunc_end", a)
+        inflight, bad, nread = set(), 0, 0
+        for line in txt[a:b].splitlines():
+            line = line.split(";")[0].strip()
+            if not line or line.endswith(":") or line.startswith("."):
+                continue
+            if line.startswith("ds_read_b64_tr_b16"):
+                inflight |= regs_of(line.split()[1].rstrip(","))
+                nread += 1
+                continue
+            if line.startswith("s_waitcnt") and "lgkmcnt(0)" in line:
+                inflight = set()
+                continue
+            if regs_of(line) & inflight:
+                bad += 1
+                print("  touches a register in flight:", line)
+        kernels += 1
+        total_bad += bad
+        print(f"{name[:72]:72s} transpose reads {nread:4d}  violations {bad}")
+    if kernels == 0:
+        print("no K-major gemm_nt_v3 instantiation found")
+        return 1
+    return 1 if total_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
