@@ -66,6 +66,10 @@ int vbnn_debug_set(int key, int value);
  * per layer whether it needs the transposed copies at all (accGradParameters: M = I, N = O, K = minibatch rows;
  * gradInput: M = I, N = minibatch rows, K = O). */
 int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K);
+/* The same question for accGradParameters of an I -> O layer on N rows, which has a second K-major form (the pair-split
+ * launch for outputs with few tiles). bias_row = 1: the bias gradient is to come from the GEMM (vbnn_dw_args.gradBias),
+ * K-major that means column I of x is all ones (and ld_x > I). */
+int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
  * (which is also what PyTorch-ROCm's default stream is, so the two stay ordered). */

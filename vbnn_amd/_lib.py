@@ -65,6 +65,7 @@ _SIGS = {
     "vbnn_last_error": ([], C.c_char_p),
     "vbnn_debug_set": ([_i, _i], _i),
     "vbnn_kmajor_supported": ([_i64, _i64, _i64], _i),
+    "vbnn_kmajor_supported_dw": ([_i64, _i64, _i64, _i], _i),
     "vbnn_ctx_create": ([_i, _vp, C.POINTER(_vp)], _i),
     "vbnn_ctx_destroy": ([_vp], _i),
     "vbnn_ctx_set_stream": ([_vp, _vp], _i),

@@ -33,6 +33,15 @@ static bool kmajor_selected(int64_t M, int64_t N, int64_t K) {
     return g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_shape_ok(M, N, K);
 }
 extern "C" int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K) { return kmajor_selected(M, N, K) ? 1 : 0; }
+// accGradParameters only: the pair-split launch of gemm_v2 also has a K-major form (outputs too few for gemm_v3)
+static bool kmajor_dw_v2_selected(int64_t M, int64_t N, int64_t K) {
+    return g_kmajor && K % V2_BK == 0 && (g_force_kernel == 0 || g_force_kernel == 2) && g_v2_tile != 128 && g_v2_tile != 64 &&
+           g_v2_split != 1 && gemm_v2_eligible<bf16_t>(M, N, K, 64, 64) && gemm_v2_psplit_by_shape(M, N, K);
+}
+extern "C" int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row) {
+    if (!bias_row && kmajor_selected(I, O, N)) return 1;
+    return kmajor_dw_v2_selected(I + (bias_row ? 1 : 0), O, N) ? 1 : 0;
+}
 
 // the K-major launch (A and / or B stored [K][rows]); false = this shape / configuration does not take it
 template <typename T, bool DUAL, bool AK, bool BK, class Epi>
@@ -124,13 +133,20 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
     e.means = a->means; e.stats = a->stats; e.B = a->B; e.S = a->S; e.kl_scale = a->kl_scale;
     e.gradBias = a->gradBias;
     e.I = (int)a->I; e.O = (int)a->O;
-    const int64_t M = a->I + (a->gradBias ? 1 : 0);          // the ones row of xT rides along as one more output row
+    const int64_t M = a->I + (a->gradBias ? 1 : 0);          // the ones row of xT (K-major: column I of x) rides along as one more output row
     const bool dual = e.lrt != 0;
     int st = VBNN_OK;                                        // K-major x, g first (no transposed copies needed)
     if (!a->gradBias &&
         (dual ? try_kmajor<T, true, true, true>(ctx, a->x, a->x2, a->ld_x, a->g, a->gv, a->ld_g, a->I, a->O, a->N, e, &st)
               : try_kmajor<T, false, true, true>(ctx, a->x, nullptr, a->ld_x, a->g, nullptr, a->ld_g, a->I, a->O, a->N, e, &st)))
         return st;
+    if constexpr (sizeof(T) == 2) {                          // ... or the pair-split form of the pipelined kernel
+        if (dual && a->x && a->x2 && a->g && a->gv && kmajor_dw_v2_selected(M, a->O, a->N)) {
+            st = launch_gemm_v2<T, true, EpiDw>(ctx, (const T*)a->x, (const T*)a->x2, a->ld_x, (const T*)a->g, (const T*)a->gv, a->ld_g,
+                                                (int)M, (int)a->O, (int)a->N, e, true);
+            if (st != VBNN_ERR_UNSUPPORTED) return st;
+        }
+    }
     if (dual) return launch_gemm<T, true>(ctx, a->xT, a->x2T, a->ld_n, a->gT, a->gvT, a->ld_n, M, a->O, a->N, e);
     return launch_gemm<T, false>(ctx, a->xT, nullptr, a->ld_n, a->gT, nullptr, a->ld_n, M, a->O, a->N, e);
 }

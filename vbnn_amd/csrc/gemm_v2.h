@@ -79,7 +79,11 @@ template <> __device__ __forceinline__ void v2_wait_vmcnt<0>() { asm volatile("s
 template <> __device__ __forceinline__ void v2_wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void v2_wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
-template <bool DUAL, int SCHED, int WM, int ST, class Epi>
+// KM (pair-split launches only): both operands K-MAJOR -- element (row, k) at X[k * ld + row], i.e. x and g as the
+// forward / gradInput GEMMs hold them (see gemm_v3.h: tile image [64 k][rows], chunk swizzle 2 h(k), fragments by
+// ds_read_b64_tr_b16 through inline asm). Columns past the matrix are clamped to its last whole chunk: the rows of C they
+// feed are masked by the epilogue. K must be whole 64-row steps.
+template <bool DUAL, int SCHED, int WM, int ST, class Epi, bool KM = false>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                           const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
                                                           int M, int N, int nk, int tiles_m, int tiles_n, int ksplit, float* exch,
@@ -146,19 +150,35 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     // (row 8g + (l>>3), chunk slot l&7) with global chunk (l&7) ^ f(row), f(row) = (row >> 1) & 7.
     const bf16_t* a_src[2][AG];
     const bf16_t* b_src[2][BG];
+    static_assert(!KM || (WM == 4 && !DUAL), "the K-major form exists for the 256 x 128 single-accumulator tile only");
+    auto hk = [](int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); };
 #pragma unroll
     for (int i = 0; i < AG; ++i) {
-        const int row = 8 * (wave + NW * i) + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int64_t off = (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        int64_t off;
+        if (KM) {                              // instruction g = wave + 8 i: k-rows 2 g, 2 g + 1 of the [64 k][256 m] tile
+            const int kr = 2 * (wave + NW * i) + (lane >> 5);
+            const int cs = (lane & 31) ^ (hk(kr) << 1);
+            off = (int64_t)kr * lda + min(m0 + cs * 8, (int)lda - 8);
+        } else {
+            const int row = 8 * (wave + NW * i) + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            off = (int64_t)min(m0 + row, M - 1) * lda + chunk * 8;
+        }
         a_src[0][i] = A + off;
         a_src[1][i] = DUAL ? A2 + off : A + off;
     }
 #pragma unroll
     for (int i = 0; i < BG; ++i) {
-        const int row = 8 * (wave + NW * i) + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int64_t off = (int64_t)min(n0 + row, N - 1) * ldb + chunk * 8;
+        int64_t off;
+        if (KM) {                              // instruction g = wave + 8 i: k-rows 4 g .. 4 g + 3 of the [64 k][128 n] tile
+            const int kr = 4 * (wave + NW * i) + (lane >> 4);
+            const int cs = (lane & 15) ^ (hk(kr) << 1);
+            off = (int64_t)kr * ldb + min(n0 + cs * 8, (int)ldb - 8);
+        } else {
+            const int row = 8 * (wave + NW * i) + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            off = (int64_t)min(n0 + row, N - 1) * ldb + chunk * 8;
+        }
         b_src[0][i] = B + off;
         b_src[1][i] = DUAL ? B2 + off : B + off;
     }
@@ -169,7 +189,8 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     auto issue_one = [&](int u, auto pair_c, auto idx_c) {      // DMA number IDX (0..AG-1: A groups, then B groups) of tile u
         constexpr int P = decltype(pair_c)::value;
         constexpr int IDX = decltype(idx_c)::value;
-        const int64_t koff = (int64_t)(kt0 + (DUAL ? (u >> 1) : u)) * V2_BK;
+        const int64_t kstep = (int64_t)(kt0 + (DUAL ? (u >> 1) : u)) * V2_BK;
+        const int64_t koff = KM ? kstep * (IDX < AG ? lda : ldb) : kstep;
         unsigned char* base = lds + (u % ST) * STAGE;
         if constexpr (IDX < AG)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + NW * IDX) * 1024), 16, 0, 0);
@@ -198,6 +219,33 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         a_off[s] = (wm * 64 + (lane & 15)) * 128 + csw;
         b_off[s] = A_BYTES + (wn * 64 + (lane & 15)) * 128 + csw;
     }
+
+    // K-major fragments (KM): see gemm_v3.h. Lane j = lane & 15 of its 16-lane group addresses k-row (j >> 2), columns 4 (j & 3) ..
+    typedef __attribute__((address_space(3))) unsigned char* ldsb_t;
+    const int trq = (lane & 15) >> 2, trp = lane & 3;
+    const int thx = (trq | ((q & 1) << 2)) << 1;
+    int a_tr[4], b_tr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_tr[i] = (8 * q + trq) * 512 + (((wm * 8 + 2 * i + (trp >> 1)) ^ thx) * 16) + (trp & 1) * 8;
+        b_tr[i] = A_BYTES + (8 * q + trq) * 256 + (((wn * 8 + 2 * i + (trp >> 1)) ^ thx) * 16) + (trp & 1) * 8;
+    }
+    auto tr_load4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x8 (&f)[4]) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI)
+                     : "memory");
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
 
     f32x4 acc1[4][4], acc2[4][4];
 #pragma unroll
@@ -240,10 +288,25 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
             bf16x8 af[4], bf[4];
+            if constexpr (KM) {
+                const unsigned sb = (unsigned)(uintptr_t)(ldsb_t)stage;
+                if (sidx == 0) {
+                    tr_load4(sb + a_tr[0], sb + a_tr[1], sb + a_tr[2], sb + a_tr[3], std::integral_constant<int, 0>(),
+                             std::integral_constant<int, 2048>(), af);
+                    tr_load4(sb + b_tr[0], sb + b_tr[1], sb + b_tr[2], sb + b_tr[3], std::integral_constant<int, 0>(),
+                             std::integral_constant<int, 1024>(), bf);
+                } else {
+                    tr_load4(sb + a_tr[0], sb + a_tr[1], sb + a_tr[2], sb + a_tr[3], std::integral_constant<int, 16384>(),
+                             std::integral_constant<int, 16384 + 2048>(), af);
+                    tr_load4(sb + b_tr[0], sb + b_tr[1], sb + b_tr[2], sb + b_tr[3], std::integral_constant<int, 8192>(),
+                             std::integral_constant<int, 8192 + 1024>(), bf);
+                }
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
-                bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const bf16x8*>(stage + a_off[sidx] + i * 16 * 128);
+                    bf[i] = *reinterpret_cast<const bf16x8*>(stage + b_off[sidx] + i * 16 * 128);
+                }
             }
             auto slot = [&](int s_, int i_) {            // the DMA that belongs to MFMA group (k-half s_, row i_)
                 if (s_ == 0 && i_ == 0) issue_one(u + LA, la_c, std::integral_constant<int, 0>());
@@ -429,9 +492,17 @@ static inline bool gemm_v2_eligible(int64_t M, int64_t N, int64_t K, int64_t lda
     return v2_tiles(M, N, 128) >= 96;
 }
 
+// would launch_gemm_v2 take the pair split for a DUAL launch of this shape? (shared with the K-major query)
+static inline bool gemm_v2_psplit_by_shape(int64_t M, int64_t N, int64_t K) {
+    const int nk = (int)((K + V2_BK - 1) / V2_BK);
+    return g_v2_psplit == 1 || (g_v2_psplit == -1 && g_v2_tile == 0 && v2_tiles(M, N, 256) <= 128 && nk >= 16);
+}
+
+// kmajor: A / A2 and B / B2 are K-major (lda / ldb = pitch of a K row). Only the pair-split launch has that form:
+// when the shape does not take it the call returns VBNN_ERR_UNSUPPORTED without launching and the caller falls back.
 template <typename T, bool DUAL, class Epi>
 static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, const T* B, const T* B2, int64_t ldb,
-                          int M, int N, int K, const Epi& epi) {
+                          int M, int N, int K, const Epi& epi, bool kmajor = false) {
     hipStream_t stream = ctx->stream;
     if constexpr (sizeof(T) != 2) {
         vbnn_set_error("gemm_v2 is bf16 only");
@@ -442,10 +513,13 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
             return VBNN_ERR_INVALID;
         }
         const int nk = (K + V2_BK - 1) / V2_BK;
-        if (lda < (int64_t)nk * V2_BK || ldb < (int64_t)nk * V2_BK) {
+        if (!kmajor && (lda < (int64_t)nk * V2_BK || ldb < (int64_t)nk * V2_BK)) {
             vbnn_set_error("packed leading dimension too small for K=%d", K);
             return VBNN_ERR_INVALID;
         }
+        if (kmajor && !(K % V2_BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= 8 && ldb >= 8 && lda >= M && ldb >= N &&
+                        (int64_t)K * lda < (1ll << 31) && (int64_t)K * ldb < (1ll << 31)))
+            return VBNN_ERR_UNSUPPORTED;
         // 256 x 128 tiles unless they would leave more than a quarter of the 256 CUs without a block while the
         // 128 x 128 tiling fills more of them (the 784 x 4096 gradient: 128 blocks vs 224)
         const int64_t t256 = v2_tiles(M, N, 256), t128 = v2_tiles(M, N, 128);
@@ -466,7 +540,8 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         // the CUs a block (the 784 x 4096 gradient: 128 tiles) and K is long; g_v2_psplit: -1 by shape, 0 never, 1 always.
         bool psplit = false;
         if constexpr (DUAL && Epi::SPLITTABLE)
-            psplit = !pairs && !split && g_v2_tile != 128 && (g_v2_psplit == 1 || (g_v2_psplit == -1 && g_v2_tile == 0 && t256 <= 128 && nk >= 16));
+            psplit = !pairs && !split && g_v2_tile != 128 && gemm_v2_psplit_by_shape(M, N, K);
+        if (kmajor && !psplit) return VBNN_ERR_UNSUPPORTED;
         const bool small = !split && !psplit && (pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256));
         const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small && !pairs ? 0 : 2);
         const int vi0 = pairs ? 2 : small ? 1 : 0;       // variant: 256 x 128 / 128 x 128 / 128 x 128 co-resident / pair split
@@ -480,16 +555,20 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
             kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 2, 3, Epi> : (const void*)gemm_nt_v2<DUAL, 2, 2, 3, Epi>;
             threads = 256; lds_bytes = v2_lds(2, 3); bm = 128;
         } else if (psplit) {                             // the single-accumulator instantiations, two blocks per tile
-            kern = sched == 0 ? (const void*)gemm_nt_v2<false, 0, 4, 3, Epi>
-                 : sched == 2 ? (const void*)gemm_nt_v2<false, 2, 4, 3, Epi> : (const void*)gemm_nt_v2<false, 4, 4, 3, Epi>;
+            if (kmajor)
+                kern = (const void*)gemm_nt_v2<false, 2, 4, 3, Epi, true>;
+            else
+                kern = sched == 0 ? (const void*)gemm_nt_v2<false, 0, 4, 3, Epi>
+                     : sched == 2 ? (const void*)gemm_nt_v2<false, 2, 4, 3, Epi> : (const void*)gemm_nt_v2<false, 4, 4, 3, Epi>;
             threads = 512; lds_bytes = v2_lds(4, 3); bm = 256;
         } else {
             kern = sched == 0 ? (const void*)gemm_nt_v2<DUAL, 0, 4, 3, Epi>
                  : sched == 2 ? (const void*)gemm_nt_v2<DUAL, 2, 4, 3, Epi> : (const void*)gemm_nt_v2<DUAL, 4, 4, 3, Epi>;
             threads = 512; lds_bytes = v2_lds(4, 3); bm = 256;
         }
-        static bool configured[4][3] = {{false, false, false}, {false, false, false}, {false, false, false}, {false, false, false}};   // per instantiation
-        const int vi = psplit ? 3 : vi0;
+        static bool configured[5][3] = {{false, false, false}, {false, false, false}, {false, false, false}, {false, false, false},
+                                        {false, false, false}};   // per instantiation
+        const int vi = psplit ? (kmajor ? 4 : 3) : vi0;
         if (!configured[vi][si]) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }

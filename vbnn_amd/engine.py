@@ -129,21 +129,26 @@ class FusedMLP:
         km_ok = (self.opt.get("dtype", "f32") == "bf16") and not self.opt.get("keep_transposes", False)
         need_prepare = False
         for li, v in enumerate(self.vb):
+            last_fused = (v is self.vb[-1]) and self.n_classes <= 16
+            v.bias_from_dw = (v.I % 256 != 0) and not last_fused
             v.dw_km = bool(km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1 and
-                           lib.vbnn_kmajor_supported(v.I, v.O, N))
+                           lib.vbnn_kmajor_supported_dw(v.I, v.O, N, 1 if v.bias_from_dw else 0))
             v.dx_km = bool(km_ok and li > 0 and lib.vbnn_kmajor_supported(v.I, N, v.O))
             use_muT = (li > 0) and not v.dx_km
             if use_muT and not getattr(v, "use_muT", True):
                 need_prepare = True                            # the shadows' transposes were being skipped: refresh them
             v.use_muT = use_muT
         for v in self.vb:
-            v.x_s, v.x2_s = _Packed(N, v.I, tdt, dev), _Packed(N, v.I, tdt, dev)
             # Layers whose parameter-gradient GEMM is not the whole-tile 256 x 256 kernel anyway (I % 256 != 0: the
             # 784-wide input layer) get their bias gradient from that GEMM: x^T carries one more row, all ones, whose
             # output row is sum_n g[n][o] (vbnn_dw_args.gradBias). Written once here: the packers only touch rows < I.
-            last_fused = (v is self.vb[-1]) and self.n_classes <= 16
-            v.bias_from_dw = (v.I % 256 != 0) and not last_fused
+            # K-major the row of ones is COLUMN I of x (in the K padding of the forward operand, where the packed
+            # weights are zero, so the forward does not see it).
             extra = 1 if v.bias_from_dw else 0
+            v.x_s = _Packed(N, v.I + (extra if v.dw_km else 0), tdt, dev)
+            v.x2_s = _Packed(N, v.I + (extra if v.dw_km else 0), tdt, dev)
+            if v.dw_km and v.bias_from_dw:
+                v.x_s.t[:, v.I] = 1.0
             if v.dw_km:
                 v.xT_s = v.x2T_s = v.gT_s = v.gvT_s = None
             else:
