@@ -189,7 +189,11 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     auto issue_one = [&](int u, auto pair_c, auto idx_c) {      // DMA number IDX (0..AG-1: A groups, then B groups) of tile u
         constexpr int P = decltype(pair_c)::value;
         constexpr int IDX = decltype(idx_c)::value;
+#ifdef V3_LAB_KWRAP     // tools/gemm_lab.hip only: every operand line an L2 hit (timing only, wrong results)
+        const int64_t kstep = (int64_t)((kt0 + (DUAL ? (u >> 1) : u)) & (V3_LAB_KWRAP - 1)) * V2_BK;
+#else
         const int64_t kstep = (int64_t)(kt0 + (DUAL ? (u >> 1) : u)) * V2_BK;
+#endif
         const int64_t koff = KM ? kstep * (IDX < AG ? lda : ldb) : kstep;
         unsigned char* base = lds + (u % ST) * STAGE;
         if constexpr (IDX < AG)

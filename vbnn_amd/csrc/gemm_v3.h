@@ -115,14 +115,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     const int a_kstep = AK ? V2_BK * (int)lda : V2_BK, b_kstep = BK ? V2_BK * (int)ldb : V2_BK;
     const bf16_t* Ap = A;
     const bf16_t* Bp = B;
+#ifdef V3_LAB_KWRAP     // tools/gemm_lab.hip only: wrap the K walk so every operand line is an L2 hit (timing only, wrong results)
+#define V3_KT(t) ((t) & (V3_LAB_KWRAP - 1))
+#else
+#define V3_KT(t) (t)
+#endif
     auto dma_a = [&](int t, auto P_c, auto d_c) {
         constexpr int P = decltype(P_c)::value, D = decltype(d_c)::value;
-        __builtin_amdgcn_global_load_lds((gptr_t)(Ap + (a_off[P][D] + t * a_kstep)),
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ap + (a_off[P][D] + V3_KT(t) * a_kstep)),
                                          (lptr_t)(lds + ((t & 1) * 2 + P) * V3_APART + (wave + 8 * D) * 1024), 16, 0, 0);
     };
     auto dma_b = [&](int t, int slot, auto d_c) {
         constexpr int D = decltype(d_c)::value;
-        __builtin_amdgcn_global_load_lds((gptr_t)(Bp + (b_off[D] + t * b_kstep)),
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bp + (b_off[D] + V3_KT(t) * b_kstep)),
                                          (lptr_t)(lds + 4 * V3_APART + slot * V3_BTILE + (wave + 8 * D) * 1024), 16, 0, 0);
     };
     std::integral_constant<int, 0> c0;
