@@ -699,3 +699,56 @@ def test_error_convention(nnmod):
     ctx = nnmod.Context.get()
     st = L.lib().vbnn_pack(ctx.h, 7, 0, None, None, 0, 0, 0, None, 0, None, 0)
     assert st != 0 and len(L.lib().vbnn_last_error()) > 0
+
+
+# --------------------------------------------------------------------- the benchmark configurations, whole step
+@pytest.mark.parametrize("hidden,I0", [([4096, 4096], 784), ([4096] * 8, 4096)], ids=["wide", "deep"])
+def test_full_size_step_properties(oracle, nnmod, hidden, I0):
+    """BASELINE.json's measured configurations (batch 4096, bf16, LRT, S = 1) are beyond what the oracle finishes in
+    seconds, so the WHOLE fused step is held to size-independent properties instead:
+      1. two fresh engines produce bit-identical gradient arenas (no atomics, no arrival-order sums);
+      2. the launch with K-major operands (gemm_v3 AK/BK, gemm_v2 pair split KM) and the launch with the transposed
+         copies (debug key 6 = 0) are different kernels over different buffers: their gradients must agree to bf16
+         operand rounding of the bias column sums, far below any layout or indexing error;
+      3. two half-batch ranks of a world of 2 sum to the single-process gradients and loss (wide only: memory);
+      4. softmax-gradient identities: the final Linear's bias gradient sums to zero over classes; every gradient finite."""
+    import torch
+    from vbnn_amd import _lib as L
+    from vbnn_amd.engine import FusedMLP
+    N = 4096
+    opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True)
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = ((torch.arange(N, device="cuda", dtype=torch.int64) * 2654435761) % 10).to(torch.int32)
+
+    def one(world=1, rank=0, xs=x, ts=t, **over):
+        eng = FusedMLP(dict(opt, **over), world_size=world, rank=rank)
+        eng.reduce = False
+        eng.resetGradients(); eng.prepare(); eng.sample()
+        eng.run(xs, ts)
+        loss, correct = eng.loss_and_accuracy()
+        g = eng.grads.clone()
+        gb3 = eng.gradBias3.clone()
+        del eng
+        return g, loss, gb3
+
+    g_a, loss_a, gb3 = one()
+    g_b, loss_b, _ = one()
+    assert torch.equal(g_a, g_b) and loss_a == loss_b                                   # 1
+    assert bool(torch.isfinite(g_a).all()) and np.isfinite(loss_a) and loss_a > 1.0   # untrained: worse than chance's log 10
+    assert abs(float(gb3.sum())) <= 1e-5 * float(gb3.abs().sum() + 1e-12)               # 4
+    L.check(L.lib().vbnn_debug_set(6, 0))
+    try:
+        g_t, loss_t, _ = one()
+    finally:
+        L.check(L.lib().vbnn_debug_set(6, 1))
+    assert abs(loss_t - loss_a) <= 1e-6 * abs(loss_a)
+    rel = float((g_t - g_a).norm() / g_a.norm())
+    assert rel <= 2e-3, rel                                                             # 2
+    del g_t, g_b
+    if len(hidden) == 2:
+        g0, l0, _ = one(2, 0, x[: N // 2].contiguous(), t[: N // 2].contiguous())
+        g1, l1, _ = one(2, 1, x[N // 2:].contiguous(), t[N // 2:].contiguous())
+        assert abs((l0 + l1) - loss_a) <= 1e-5 * abs(loss_a)
+        rel = float((g0 + g1 - g_a).norm() / g_a.norm())
+        assert rel <= 2e-3, rel                                                         # 3
