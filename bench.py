@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
     args = ap.parse_args()
 
+    # multi-process GPU work on this driver needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the boxes
+    # export it already, this keeps a hand-built environment from dropping it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     from vbnn_amd import _lib as L
