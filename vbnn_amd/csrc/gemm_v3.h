@@ -10,10 +10,10 @@
 // ds_reads per MFMA -- what the vendor library's 256x256x64 macro-tile runs on. Every output of the three epilogues
 // is LINEAR in the mean GEMM once the variance GEMM is known (y = m + [b + sqrt(v) z], gx = g mu + [2 x . gv s2],
 // d/dmeans and d/dlvars depend on one GEMM each), so the pair runs as two passes of the SAME workgroup over the same
-// accumulator registers and, for DX and DW, nothing is parked in between. (FWD's term needs a Philox block per quad;
-// 32 of them beside 128 live accumulators spill, so FWD parks the variance tile as it stands in a per-workgroup
-// scratch tile -- 256 KiB, written and read back by the same thread, served by L2/MALL -- and applies the noise in
-// the final epilogue: 128 MB per launch of extra cache traffic, 10-15 us.)
+// accumulator registers and nothing is parked in between. (FWD's term needs a Philox block per quad; 32 of them beside
+// 128 live accumulators spilled until the folds were serialised -- FOLD_SERIAL in epilogues.h -- so that one quad's
+// draw is live at a time. The earlier form, which parked the variance tile in a per-workgroup scratch tile and drew the
+// noise in the final epilogue, is kept behind -DVBNN_FWD_PARK: +128 MB of cache traffic per launch, 10-15 us.)
 //
 //   workgroup   8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = acc[8][4] (128 accumulator registers)
 //   K step      64 bf16 (128-B rows, the swizzle of gemm_v2.h), two PHASES of 32 MFMAs per wave:
