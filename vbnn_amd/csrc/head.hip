@@ -216,7 +216,10 @@ __device__ __forceinline__ void head_load(HeadRaw<T>& o, const T* __restrict__ h
 // FULL: every tile is whole and vector-accessible (H % 64 == 0, N % 64 == 0, aligned operands): no bounds checks at
 // all, and every global access is (block-uniform base) + (one 32-bit lane offset) -- the guarded general form spent
 // most of its VALU issue slots on 64-bit address arithmetic and exec-mask bookkeeping (it was issue-bound, not HBM-bound).
-template <typename T, bool VEC, bool FULL>
+// CP > 0 (FULL only, C <= CP, r in the operand type or absent): the block's 64 columns of the final weight live in
+// REGISTERS (CP x 8 per thread) instead of being re-read from LDS for every row of every tile -- the loop was bound
+// by LDS round trips at two waves per SIMD, not by HBM (g_prev alone: 30 us for 67 MB).
+template <typename T, bool VEC, bool FULL, int CP = 0>
 __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, int64_t ld_h, const T* __restrict__ w3, int64_t ld_w,
                                                        const float* __restrict__ g, int64_t N, int64_t H, int C, int relu_mask,
                                                        const float* __restrict__ r_prev, const T* __restrict__ r_prev_t, int64_t ld_r,
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
     __shared__ __attribute__((aligned(16))) T th[64][TP];      // h tile
     __shared__ __attribute__((aligned(16))) T tg[64][TP];      // g_prev tile, as stored
     __shared__ __attribute__((aligned(16))) T tv[64][TP];      // gv_prev tile
-    __shared__ float gs[2][64][HEAD_CMAX + 1];                 // d(loss)/d(logits) rows of the tile, operand-rounded
+    __shared__ __attribute__((aligned(16))) float gs[2][64][HEAD_CMAX + 4];   // d(loss)/d(logits) rows of the tile, operand-rounded; 80-B rows: 16-byte reads, 8 rows on 8 bank groups
     __shared__ __attribute__((aligned(16))) float ws[HEAD_CMAX][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ch = tid & 7, c16 = lane & 15, q = lane >> 4;
@@ -241,6 +244,14 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
     for (int k = tid; k < HEAD_CMAX * 64; k += 256) {
         const int wc = k >> 6, wi = k & 63;
         ws[wc][wi] = (wc < C && c0 + wi < H) ? Elt<T>::from(w3[(int64_t)wc * ld_w + c0 + wi]) : 0.f;
+    }
+    float wreg[CP > 0 ? CP : 1][8];
+    if constexpr (CP > 0) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wreg[c][e] = ws[c][ch * 8 + e];
     }
     const bool has_r = r_prev || r_prev_t;
     f32x4 accw = {0.f, 0.f, 0.f, 0.f}, accp = {0.f, 0.f, 0.f, 0.f};
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
             if constexpr (FULL) {
                 dst[p].h = Vec8<T>::load_raw(h + ((r0 + 32 * p) * ld_h + c0) + lo_h);
                 if (r_prev_t) dst[p].rt = Vec8<T>::load_raw(r_prev_t + ((r0 + 32 * p) * ld_r + c0) + lo_r);
-                if (r_prev) dst[p].rf = Vec8<float>::load_raw(r_prev + ((r0 + 32 * p) * ld_r + c0) + lo_r);
+                if constexpr (CP == 0) { if (r_prev) dst[p].rf = Vec8<float>::load_raw(r_prev + ((r0 + 32 * p) * ld_r + c0) + lo_r); }
             } else {
                 head_load<T, VEC>(dst[p], h, ld_h, r_prev, r_prev_t, ld_r, r0 + (tid >> 3) + 32 * p, n_hi, i8, H);
             }
@@ -298,14 +309,25 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
 #pragma unroll
             for (int e = 0; e < 8; ++e) { gx[e] = 0.f; rv[e] = 0.f; }
             if (r_prev_t) Vec8<T>::cvt(cur[p].rt, rv);
-            if (r_prev) Vec8<float>::cvt(cur[p].rf, rv);
+            if constexpr (CP == 0) { if (r_prev) Vec8<float>::cvt(cur[p].rf, rv); }
+            if constexpr (CP > 0) {
 #pragma unroll
-            for (int c = 0; c < HEAD_CMAX; ++c)
-                if (c < C) {
-                    const float gv = gs[buf][rr][c];        // 0 for rows past the chunk
+                for (int c4 = 0; c4 < CP; c4 += 4) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(&gs[buf][rr][c4]);      // classes past C: weights are 0
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gx[e] = fmaf(gv, ws[c][ch * 8 + e], gx[e]);     // ws is 0 past H
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gx[e] = fmaf(g4[k], wreg[c4 + k][e], gx[e]);
                 }
+            } else {
+#pragma unroll
+                for (int c = 0; c < HEAD_CMAX; ++c)
+                    if (c < C) {
+                        const float gv = gs[buf][rr][c];        // 0 for rows past the chunk
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gx[e] = fmaf(gv, ws[c][ch * 8 + e], gx[e]);     // ws is 0 past H
+                    }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 gp[e] = (relu_mask && !(hv[e] > 0.f)) ? 0.f : gx[e];
@@ -504,7 +526,11 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
     float* pbp = gradBias_prev ? partial_bp : nullptr;
     const bool full = vec && (H % 64 == 0) && (N % 64 == 0) && N * ld_h < (1ll << 31) && N * ld_gp < (1ll << 31) &&
                       H * ld_gpT < (1ll << 31) && (!r_prev_any || N * ld_r_prev < (1ll << 31));
-    if (full)
+    if (full && C <= 12 && !r_prev)
+        hipLaunchKernelGGL((k_head_backward<T, true, true, 12>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
+                           relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
+                           pw, pb, pbp);
+    else if (full)
         hipLaunchKernelGGL((k_head_backward<T, true, true>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
                            relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
                            pw, pb, pbp);
