@@ -35,3 +35,5 @@ print(f"  backward without gradWeight/bias sums      {run(lambda: bwd(dw=False))
 print(f"  backward without the transposed copies     {run(lambda: bwd(tr=False)):7.1f} us")
 print(f"  backward without gv (no r, no gv outputs)  {run(lambda: bwd(gv=False)):7.1f} us")
 print(f"  backward: g_prev only                      {run(lambda: bwd(dw=False, tr=False, gv=False)):7.1f} us")
+print(f"  no transposes, no sums                     {run(lambda: bwd(dw=False, tr=False)):7.1f} us")
+print(f"  no transposes, sums without bias_prev      {run(lambda: bwd(tr=False, bp=False)):7.1f} us")
