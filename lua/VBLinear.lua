@@ -234,5 +234,58 @@ function VBLinear:calc_lc(opt)                                      -- VBLinear.
     return torch.Tensor(1):fill(s[0])
 end
 
--- VBLinear:update (VBLinear.lua:124-166) is host-side optimiser code (optim.sgd / optim.adam on the host tensors)
--- and is taken unchanged from the reference: it only calls compute_prior / compute_mugrads / compute_vargrads above.
+-- VBLinear:update (VBLinear.lua:124-166): SGD on the bias, compute_prior, likelihood + KL gradients, Adam on means
+-- (opt.meanState) and on lvars (opt.varState) with per-layer moment state -- on the device (vbnn_sgd_step /
+-- vbnn_adam_step: one streaming pass per tensor, the two gradient parts added inside it); the host tensors are
+-- refreshed afterwards because mlp.lua and the logger read them. Same fourteen series as the reference (:149-164).
+local function adam(self, key, x_host, d_x, d_g1, d_g2, cfg)
+    local f = function(p) return ffi.cast('float*', p) end
+    local st = self._adam[key]
+    if not st then
+        st = { t = 0, m = dev_like(x_host), v = dev_like(x_host), norms = vb.alloc(16) }
+        check(C.vbnn_buf_zero(vb.ctx, st.m, self.W * 4)); check(C.vbnn_buf_zero(vb.ctx, st.v, self.W * 4))
+        self._adam[key] = st
+    end
+    st.t = st.t + 1
+    check(C.vbnn_adam_step(vb.ctx, f(d_x), f(d_g1), f(d_g2), f(st.m), f(st.v), self.W, cfg.learningRate,
+                           cfg.beta1 or 0.9, cfg.beta2 or 0.999, cfg.epsilon or 1e-8, cfg.lambda or 1, st.t,
+                           ffi.cast('double*', st.norms)))
+    local n = ffi.new('double[2]')
+    check(C.vbnn_buf_download(vb.ctx, n, st.norms, 16))
+    return n[0] / n[1]                                              -- torch.norm(update) / torch.norm(x), :139,144
+end
+
+function VBLinear:update(opt)
+    local f = function(p) return ffi.cast('float*', p) end
+    self._adam = self._adam or {}
+    upload(self.d.bias, self.bias); upload(self.d.gradBias, self.gradBias)
+    check(C.vbnn_sgd_step(vb.ctx, f(self.d.bias), f(self.d.gradBias), self.bias:nElement(), self.biasState.learningRate))  -- :125-128
+    download(self.bias, self.d.bias)
+    self:compute_prior()                                            -- :130
+    local mleg, mlcg = self:compute_mugrads(opt)                    -- :131  (d.gradWeight, d.lcg hold them on the device)
+    local d_mlcg = self.d.lcg
+    self.d.lcg = self.d.lcg2 or dev_like(self.means)                -- keep the first KL gradient while the second is formed
+    local vleg, vlcg = self:compute_vargrads(opt)                   -- :133
+    local d_vlcg = self.d.lcg
+    local mu_normratio = adam(self, 'mean', self.means, self.d.means, self.d.gradWeight, d_mlcg, self.meanState)   -- :135-139
+    local var_normratio = adam(self, 'var', self.lvars, self.d.lvars, self.d.gradSum, d_vlcg, self.varState)       -- :140-144
+    self.d.lcg, self.d.lcg2 = d_mlcg, d_vlcg
+    download(self.means, self.d.means); download(self.lvars, self.d.lvars)
+    if opt.log then                                                 -- :148-164
+        local vars = torch.exp(self.lvars)
+        Log:add('vlc grad', vlcg:norm() / self.lvars:norm())
+        Log:add('vle grad', vleg:norm() / self.lvars:norm())
+        Log:add('mlc grad', mlcg:norm() / self.means:norm())
+        Log:add('mle grad', mleg:norm() / self.means:norm())
+        Log:add('min variance', vars:min())
+        Log:add('max variance', vars:max())
+        Log:add('mean variance', vars:mean())
+        Log:add('var hat', self.var_hat)
+        Log:add('mean means', self.means:mean())
+        Log:add('std means', self.means:std())
+        Log:add('min. means', self.means:min())
+        Log:add('max. means', self.means:max())
+        Log:add('mu normratio', mu_normratio)
+        Log:add('var normratio', var_normratio)
+    end
+end

@@ -108,3 +108,34 @@ def test_pad_ld():
 
 if __name__ == "__main__":
     sys.exit(pytest.main([__file__, "-q"]))
+
+
+def _lua_tokens(path):
+    """Identifier / keyword tokens of a Lua file with comments and string literals removed."""
+    txt = open(path).read()
+    txt = re.sub(r"--\[\[.*?\]\]", " ", txt, flags=re.S)
+    txt = re.sub(r"--[^\n]*", " ", txt)
+    txt = re.sub(r"'(?:\\.|[^'\\\n])*'|\"(?:\\.|[^\"\\\n])*\"", " S ", txt)
+    return txt, re.findall(r"[A-Za-z_][A-Za-z_0-9]*", txt)
+
+
+def test_lua_shim_structure():
+    """No Lua interpreter exists here, so lua/VBLinear.lua is linted structurally: block keywords balance, every
+    C.vbnn_* it calls is declared in include/vbnn_hip.h, and it defines every method the reference's callers use
+    (mlp.lua:14-142, main.lua:127-128: the §8b method set)."""
+    path = os.path.join(ROOT, "lua", "VBLinear.lua")
+    txt, toks = _lua_tokens(path)
+    opens = sum(toks.count(k) for k in ("function", "if", "for", "while")) + toks.count("repeat") * 0
+    # `for ... do` / `while ... do` open one block each (counted by for / while); a bare `do ... end` would add one
+    bare_do = toks.count("do") - toks.count("for") - toks.count("while")
+    assert bare_do >= 0
+    assert opens + bare_do == toks.count("end"), (opens, bare_do, toks.count("end"))
+    assert txt.count("(") == txt.count(")") and txt.count("{") == txt.count("}") and txt.count("[") == txt.count("]")
+    header = open(os.path.join(ROOT, "include", "vbnn_hip.h")).read()
+    declared = set(re.findall(r"\b(vbnn_[a-z0-9_]+)\s*\(", header))
+    used = set(re.findall(r"\bC\.(vbnn_[a-z0-9_]+)", txt))
+    assert used and used <= declared, used - declared
+    methods = set(re.findall(r"function\s+VBLinear:([A-Za-z_]+)", txt))
+    need = {"__init", "sample", "clamp_to_map", "resetAcc", "updateOutput", "updateGradInput", "accGradParameters",
+            "compute_prior", "compute_mugrads", "compute_vargrads", "calc_lc", "update"}
+    assert need <= methods, need - methods
