@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Audit of the split issue / wait inline-asm transpose reads in gemm_v3.h (K-major operands).
+"""Audit of the split issue / wait inline-asm transpose reads in gemm_v3.h and gemm_v2.h (K-major operands).
 
 A `ds_read_b64_tr_b16` issued by one asm statement is waited for by a LATER one; hipcc knows nothing about the
 load in flight, so nothing in between may read or write its destination registers (a compiler-inserted copy or spill
 there would move garbage). This script compiles csrc/gemm.hip to assembly and checks exactly that for every
-gemm_nt_v3 instantiation with a K-major operand. Run it after any change to gemm_v3.h or to the compiler:
+gemm_nt_v3 / gemm_nt_v2 instantiation with a K-major operand. LDS operations return in order, so a counted
+`s_waitcnt lgkmcnt(N)` retires all but the N youngest of them: the reads are tracked as a FIFO. Run it after any change to gemm_v3.h or to the compiler:
     python3 tools/audit_tr_reads.py        (CPU only; ~2 min)
 """
 import os, re, subprocess, sys, tempfile
@@ -30,29 +31,36 @@ def main():
                        check=True, stderr=subprocess.DEVNULL)
         txt = open(asm).read()
     total_bad, kernels = 0, 0
-    for name in re.findall(r"^(_Z10gemm_nt_v3ILb[01]E(?:Lb1ELb[01]|Lb0ELb1)\S+):", txt, re.M):
+    names = re.findall(r"^(_Z10gemm_nt_v3ILb[01]E(?:Lb1ELb[01]|Lb0ELb1)\S+):", txt, re.M)
+    names += re.findall(r"^(_Z10gemm_nt_v2I\S+?Lb1EEv\S+):", txt, re.M)
+    for name in names:
         a = txt.index(name + ":")
         b = txt.index(".Lfunc_end", a)
-        inflight, bad, nread = set(), 0, 0
+        fifo, bad, nread = [], 0, 0                     # LDS operations in flight, oldest first: sets of destination VGPRs
         for line in txt[a:b].splitlines():
             line = line.split(";")[0].strip()
             if not line or line.endswith(":") or line.startswith("."):
                 continue
             if line.startswith("ds_read_b64_tr_b16"):
-                inflight |= regs_of(line.split()[1].rstrip(","))
+                fifo.append(regs_of(line.split()[1].rstrip(",")))
                 nread += 1
                 continue
-            if line.startswith("s_waitcnt") and "lgkmcnt(0)" in line:
-                inflight = set()
+            m = re.search(r"lgkmcnt\((\d+)\)", line) if line.startswith("s_waitcnt") else None
+            if m:
+                keep = int(m.group(1))
+                fifo = fifo[len(fifo) - keep:] if keep else []
                 continue
+            inflight = set().union(*fifo) if fifo else set()
             if regs_of(line) & inflight:
                 bad += 1
                 print("  touches a register in flight:", line)
+            if line.startswith("ds_") and not line.startswith("ds_read_b64_tr_b16"):
+                fifo.append(set())                      # any other LDS operation takes a slot in the in-order queue
         kernels += 1
         total_bad += bad
         print(f"{name[:72]:72s} transpose reads {nread:4d}  violations {bad}")
     if kernels == 0:
-        print("no K-major gemm_nt_v3 instantiation found")
+        print("no K-major instantiation found")
         return 1
     return 1 if total_bad else 0
 
