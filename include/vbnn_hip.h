@@ -58,7 +58,7 @@ const char* vbnn_last_error(void);
 #define VBNN_DEBUG_V3_MIN_K 4      /* shortest K for which shape selection picks the two-pass 256 x 256 kernel (default 704) */
 #define VBNN_DEBUG_V2_PSPLIT 5     /* pipelined kernel pair split (the pair's two GEMMs in different workgroups, parameter
                                       gradients only): -1 = by shape (default), 0 = never, 1 = whenever possible */
-#define VBNN_DEBUG_KMAJOR 6        /* K-major operands (gemm_v3.h AK / BK): 1 = use when the shape allows (default), 0 = never */
+#define VBNN_DEBUG_KMAJOR 6        /* K-major operands (gemm_v3.h AK / BK): 1 = use when the shape allows (default), 0 = never, 2 = gemm_v3 only */
 int vbnn_debug_set(int key, int value);
 
 /* 1 when a GEMM with an M x N output and contraction length K would take the K-major form of the two-pass kernel

@@ -29,6 +29,8 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
     static constexpr int FAST_BATCH = 8;
     static constexpr bool PARK = false;
     static constexpr bool SPLITTABLE = false;
+    static constexpr bool EDGE_FAST = false;
+    __device__ __forceinline__ void edge_row(int, float) const {}
     __device__ __forceinline__ void set_part(int) {}
     static constexpr int FOLD_BATCH = 8;
     static constexpr int FOLD_SERIAL = 0;

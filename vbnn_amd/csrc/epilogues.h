@@ -60,6 +60,8 @@ struct EpiFwd {
     int O, N;
 
     static constexpr bool SPLITTABLE = false;     // every output needs both GEMMs of the pair
+    static constexpr bool EDGE_FAST = false;      // ragged wave tiles take the guarded form
+    __device__ __forceinline__ void edge_row(int, float) const {}
     __device__ __forceinline__ void set_part(int) {}
     __host__ __device__ __forceinline__ T* t1_ptr() const { return hT; }
     __host__ __device__ __forceinline__ T* t2_ptr() const { return h2T; }
@@ -251,6 +253,8 @@ struct EpiDx {
     int I, N;
 
     static constexpr bool SPLITTABLE = false;
+    static constexpr bool EDGE_FAST = false;
+    __device__ __forceinline__ void edge_row(int, float) const {}
     __device__ __forceinline__ void set_part(int) {}
     __host__ __device__ __forceinline__ T* t1_ptr() const { return gT_prev; }
     __host__ __device__ __forceinline__ T* t2_ptr() const { return gvT_prev; }
@@ -381,6 +385,14 @@ struct EpiDw {
     int part = 0;
     static constexpr bool SPLITTABLE = true;
     __device__ __forceinline__ void set_part(int p) { part = p; }
+    // A wave tile that straddles the last row I of the output (I % 4 == 0, so every lane's quad is wholly inside or
+    // wholly outside) may still take the FAST protocol with the outside lanes switched off: its batched loads then
+    // cost one latency per batch instead of one per position, on the wave that otherwise finishes the launch last.
+    // The row right after the output, m = I, is the GEMM's row of ones (gradBias): edge_row takes its sums.
+    static constexpr bool EDGE_FAST = true;
+    __device__ __forceinline__ void edge_row(int n, float v) const {
+        if (part != 2 && gradBias && n < O) gradBias[n] = scale * v;      // fast_ok() implies accumulate == 0
+    }
 
     __host__ __device__ __forceinline__ bf16_t* t1_ptr() const { return nullptr; }
     __host__ __device__ __forceinline__ bf16_t* t2_ptr() const { return nullptr; }

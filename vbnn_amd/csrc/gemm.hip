@@ -20,7 +20,7 @@ extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_V2_SPLITK && value >= -1 && value <= 1) { g_v2_split = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V3_MIN_K && value >= 64) { g_v3_min_k = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_PSPLIT && value >= -1 && value <= 1) { g_v2_psplit = value; return VBNN_OK; }
-    if (key == VBNN_DEBUG_KMAJOR && value >= 0 && value <= 1) { g_kmajor = value; return VBNN_OK; }
+    if (key == VBNN_DEBUG_KMAJOR && value >= 0 && value <= 2) { g_kmajor = value; return VBNN_OK; }   // 2: gemm_v3 only
     vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
     return VBNN_ERR_INVALID;
 }
@@ -35,7 +35,7 @@ static bool kmajor_selected(int64_t M, int64_t N, int64_t K) {
 extern "C" int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K) { return kmajor_selected(M, N, K) ? 1 : 0; }
 // accGradParameters only: the pair-split launch of gemm_v2 also has a K-major form (outputs too few for gemm_v3)
 static bool kmajor_dw_v2_selected(int64_t M, int64_t N, int64_t K) {
-    return g_kmajor && K % V2_BK == 0 && (g_force_kernel == 0 || g_force_kernel == 2) && g_v2_tile != 128 && g_v2_tile != 64 &&
+    return g_kmajor == 1 && K % V2_BK == 0 && (g_force_kernel == 0 || g_force_kernel == 2) && g_v2_tile != 128 && g_v2_tile != 64 &&
            g_v2_split != 1 && gemm_v2_eligible<bf16_t>(M, N, K, 64, 64) && gemm_v2_psplit_by_shape(M, N, K);
 }
 extern "C" int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row) {

@@ -431,21 +431,33 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     };
     // A wave tile that lies fully inside the matrix takes the functor's FAST protocol when it applies (epilogues.h):
     // the epilogue's global loads go out a batch at a time instead of one guarded, waited-for load per position.
-    const bool fast = epi.fast_ok() && (wm0 + 64 <= epi.m_dim()) && (wn0 + 64 <= epi.n_dim());     // wave-uniform
-    if (fast) {
+    const bool fast_full = epi.fast_ok() && (wm0 + 64 <= epi.m_dim()) && (wn0 + 64 <= epi.n_dim());     // wave-uniform
+    // ... and so does one that straddles the last output row when the functor allows it (EDGE_FAST): the lanes whose
+    // quad lies past the edge are switched off, the lane on row m_dim hands its first value to edge_row
+    const bool fast_edge = Epi::EDGE_FAST && !fast_full && epi.fast_ok() && !any_t && (wm0 < epi.m_dim()) &&
+                           (epi.m_dim() % 4 == 0) && (wn0 + 64 <= epi.n_dim());
+    if (fast_full || fast_edge) {
         const int um = __builtin_amdgcn_readfirstlane(wm0), un = __builtin_amdgcn_readfirstlane(wn0);
         const typename Epi::Lane eln = epi.lane_init(q4, 4 * c16);
+        const bool lane_in = fast_full || (wm0 + 4 * c16 + 4 <= epi.m_dim());
+        const bool lane_edge = fast_edge && (wm0 + 4 * c16 == epi.m_dim());
         constexpr int FB = Epi::FAST_BATCH / 2;
 #pragma unroll
         for (int p0 = 0; p0 < 16; p0 += FB) {
             typename Epi::Pre pre[FB];
+            if (lane_in) {
 #pragma unroll
-            for (int b = 0; b < FB; ++b) pre[b] = epi.load_fast(um, un + 4 * (p0 + b), eln);
+                for (int b = 0; b < FB; ++b) pre[b] = epi.load_fast(um, un + 4 * (p0 + b), eln);
 #pragma unroll
-            for (int b = 0; b < FB; ++b) {
-                float t1[4], t2[4];
-                epi.apply_fast(um, un + 4 * (p0 + b), eln, r1[p0 + b], r2[p0 + b], pre[b], t1, t2);
-                if (any_t) stage_t(p0 + b, t1, t2);
+                for (int b = 0; b < FB; ++b) {
+                    float t1[4], t2[4];
+                    epi.apply_fast(um, un + 4 * (p0 + b), eln, r1[p0 + b], r2[p0 + b], pre[b], t1, t2);
+                    if (any_t) stage_t(p0 + b, t1, t2);
+                }
+            }
+            if (lane_edge) {
+#pragma unroll
+                for (int b = 0; b < FB; ++b) epi.edge_row(wn0 + 4 * (p0 + b) + q4, r1[p0 + b][0]);
             }
         }
     } else {
