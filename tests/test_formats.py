@@ -171,3 +171,37 @@ def test_synthetic_digits_are_reproducible():
     b, _ = data.synthetic_digits(64, 16, seed=3)
     assert np.array_equal(a["inputs"], b["inputs"]) and np.array_equal(a["targets"], b["targets"])
     assert a["inputs"].shape == (64, 28, 28) and set(np.unique(a["targets"])) <= set(range(10))
+
+
+def test_t7_round_trip_property():
+    """Random nested tables / tensors survive dumps -> loads (hypothesis; the reader is the writer's only judge here)."""
+    hyp = pytest.importorskip("hypothesis")
+    st = pytest.importorskip("hypothesis.strategies")
+    hnp = pytest.importorskip("hypothesis.extra.numpy")
+
+    dtypes = st.sampled_from([np.float32, np.float64, np.int64, np.int32, np.int16, np.uint8, np.int8])
+    tensors = dtypes.flatmap(lambda dt: hnp.arrays(dt, hnp.array_shapes(min_dims=1, max_dims=3, min_side=1, max_side=5),
+                                                   elements=st.integers(0, 100)))
+    leaves = st.one_of(st.booleans(), st.integers(-2 ** 40, 2 ** 40), st.floats(allow_nan=False, allow_infinity=True),
+                       st.text(alphabet=st.characters(min_codepoint=32, max_codepoint=126), max_size=12), tensors)
+    keys = st.text(alphabet="abcdefghijklmnopqrstuvwxyz_", min_size=1, max_size=6)
+    trees = st.recursive(leaves, lambda ch: st.one_of(st.lists(ch, min_size=1, max_size=4),
+                                                      st.dictionaries(keys, ch, min_size=1, max_size=4)), max_leaves=12)
+
+    def same(a, b):
+        if isinstance(a, np.ndarray):
+            return isinstance(b, np.ndarray) and a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+        if isinstance(a, dict):
+            return isinstance(b, dict) and a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, (list, tuple)):
+            return isinstance(b, list) and len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        if isinstance(a, bool) or isinstance(b, bool):
+            return a is b
+        return a == b                                  # Lua has one number type: 3 and 3.0 are the same value
+
+    @hyp.settings(max_examples=150, deadline=None)
+    @hyp.given(trees)
+    def check(obj):
+        assert same(obj, t7file.loads(t7file.dumps(obj)))
+
+    check()
