@@ -405,6 +405,33 @@ def test_bf16_gemm_exact_on_integers(nnmod, gemm_kernel, N, I, O):
         assert np.array_equal(host(m.gradBias), g.sum(axis=0))
 
 
+def _fuzz_shapes():
+    rng = np.random.default_rng(20260401)
+    shapes = [(int(rng.integers(1, 700)), int(rng.integers(1, 900)), int(rng.integers(1, 700))) for _ in range(10)]
+    # tile-boundary neighbours of the three kernels' block tiles (32 / 64 / 128 / 256) and of the 64-element K step
+    shapes += [(255, 64, 257), (256, 63, 256), (257, 65, 255), (129, 128, 127), (1024, 192, 1280), (768, 1088, 1025)]
+    return shapes
+
+
+@pytest.mark.parametrize("N,I,O", _fuzz_shapes())
+def test_bf16_gemm_exact_on_random_shapes(nnmod, N, I, O):
+    """The same exactness screen as test_bf16_gemm_exact_on_integers on seeded random and tile-boundary shapes, with the
+    library's OWN kernel choice per shape (no debug key): whatever the heuristics pick must be exact on ragged edges."""
+    rng = np.random.default_rng(N * 7919 + I * 31 + O)
+    W = rng.integers(-3, 4, (O, I)).astype(np.float32)
+    b = rng.integers(-5, 6, O).astype(np.float32)
+    x = rng.integers(-3, 4, (N, I)).astype(np.float32)
+    g = rng.integers(-2, 3, (N, O)).astype(np.float32)
+    m = nnmod.Linear(I, O, dict(dtype="bf16"))
+    m.weight.copy_(dev(W)); m.bias.copy_(dev(b))
+    for _ in range(2):
+        assert np.array_equal(host(m.updateOutput(dev(x))), x @ W.T + b)
+        m.gradWeight.zero_(); m.gradBias.zero_()
+        assert np.array_equal(host(m.backward(dev(x), dev(g), 1.0)), g @ W)
+        assert np.array_equal(host(m.gradWeight), g.T @ x)
+        assert np.array_equal(host(m.gradBias), g.sum(axis=0))
+
+
 @pytest.mark.parametrize("N,I,O", [(3, 7, 5), (100, 130, 70), (256, 784, 400)])
 def test_layer_bf16_against_rounded_operands(nnmod, oracle, gemm_kernel, N, I, O):
     """bf16 MFMA path of one VBLinear (LRT) against float64 math on the SAME bf16-rounded operands
