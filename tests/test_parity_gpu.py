@@ -310,6 +310,55 @@ def test_engine_matches_oracle_f32(oracle, nnmod, mode, fuse_kl):
         assert abs(eng.calc_lc() - onet.calc_lc()) <= 2e-4 * abs(onet.calc_lc()) + 1e-9
 
 
+def _fuzz_nets():
+    rng = np.random.default_rng(424242)
+    nets = []
+    for classes in (2, 7, 10, 13, 16, 20):                # <= 16: the fused classifier head; 20: the generic GEMM head
+        depth = int(rng.integers(1, 4))
+        nets.append(([int(rng.integers(1, 150)) for _ in range(depth)], int(rng.integers(1, 200)), int(rng.integers(1, 100)), classes))
+    nets.append(([64, 128], 256, 64, 10))                 # whole tiles everywhere: every unguarded fast path
+    nets.append(([1], 1, 1, 2))                           # the smallest network there is
+    return nets
+
+
+@pytest.mark.parametrize("hidden,I0,N,classes", _fuzz_nets())
+@pytest.mark.parametrize("mode", ["lrt", "wn"])
+def test_engine_matches_oracle_on_random_networks(oracle, nnmod, mode, hidden, I0, N, classes):
+    """test_engine_matches_oracle_f32 on seeded random depths / widths / batch sizes / class counts (fp32, total
+    gradients from the fused epilogue, S = 2): ragged everything, including the classifier head's class padding."""
+    from vbnn_amd.engine import FusedMLP
+    opt = opt_for(mode, "f32", input_size=I0, hidden=hidden, S=2, fuse_kl=True, n_classes=classes)
+    eng, onet = FusedMLP(opt), oracle.OracleMLP(opt)
+    rng = np.random.default_rng(9)
+    for k, v in enumerate(eng.vb):
+        om = onet.vb[k]
+        lv = rng.normal(np.log(1e-3), 0.3, om.lvars.shape).astype(np.float32)
+        b = rng.normal(0, 0.05, om.bias.shape).astype(np.float32)
+        om.means[:] = om.weight; om.lvars[:] = lv; om.bias[:] = b
+        v.lvars.copy_(dev(lv)); v.bias.copy_(dev(b))
+        om.compute_prior()
+    x = oracle.fill_normal(N, I0, SEED, 4, 0, 0)
+    t = (np.arange(N) * 7 % classes).astype(np.int32)
+    eng.resetGradients(); eng.prepare(); onet.resetGradients()
+    werr = 0.0
+    for _ in range(2):
+        eng.sample(); onet.sample()
+        eng.run(dev(x), dev(t))
+        werr += onet.run(x, t)[0]
+    loss, _ = eng.loss_and_accuracy()
+    assert abs(loss - werr) <= 3e-5 * abs(werr) + 1e-6, (loss, werr)
+    for k, v in enumerate(eng.vb):
+        om = onet.vb[k]
+        mle, mlc = om.compute_mugrads(opt)
+        vle, vlc = om.compute_vargrads(opt)
+        want_mu, want_lv = mle + mlc, vle + vlc
+        np.testing.assert_allclose(host(v.gradWeight), want_mu, rtol=0, atol=3e-5 * np.abs(want_mu).max() + 1e-10)
+        np.testing.assert_allclose(host(v.gradSum), want_lv, rtol=0, atol=2e-4 * np.abs(want_lv).max() + 1e-10)
+        np.testing.assert_allclose(host(v.gradBias), om.gradBias, rtol=0, atol=3e-5 * np.abs(om.gradBias).max() + 1e-10)
+    np.testing.assert_allclose(host(eng.gradWeight3), onet.last.gradWeight, rtol=0, atol=3e-5 * np.abs(onet.last.gradWeight).max() + 1e-10)
+    np.testing.assert_allclose(host(eng.gradBias3), onet.last.gradBias, rtol=0, atol=3e-5 * np.abs(onet.last.gradBias).max() + 1e-9)
+
+
 @pytest.mark.parametrize("mode", ["lrt", "wn"])
 def test_engine_bf16_close_to_f32_oracle(oracle, nnmod, gemm_kernel, mode):
     """bf16 operands / fp32 accumulate against the fp32 oracle: normalised max error <= 3e-2 on the
