@@ -29,12 +29,14 @@ extern "C" int vbnn_debug_set(int key, int value) {
 // fast-path conditions are checked at launch)
 static bool kmajor_selected(int64_t M, int64_t N, int64_t K) {
     if (!g_kmajor || K % V2_BK != 0) return false;
+    if (K * (M + 64) >= (1ll << 30) || K * (N + 64) >= (1ll << 30)) return false;      // 32-bit byte offsets of the buffer-form DMA
     if (g_force_kernel == 3) return M % V3_BM == 0 && N % V3_BN == 0;
     return g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_shape_ok(M, N, K);
 }
 extern "C" int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K) { return kmajor_selected(M, N, K) ? 1 : 0; }
 // accGradParameters only: the pair-split launch of gemm_v2 also has a K-major form (outputs too few for gemm_v3)
 static bool kmajor_dw_v2_selected(int64_t M, int64_t N, int64_t K) {
+    if (K * (M + 64) >= (1ll << 30) || K * (N + 64) >= (1ll << 30)) return false;
     return g_kmajor == 1 && K % V2_BK == 0 && (g_force_kernel == 0 || g_force_kernel == 2) && g_v2_tile != 128 && g_v2_tile != 64 &&
            g_v2_split != 1 && gemm_v2_eligible<bf16_t>(M, N, K, 64, 64) && gemm_v2_psplit_by_shape(M, N, K);
 }
@@ -65,7 +67,7 @@ static int launch_gemm(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda
         vbnn_set_error("the K-contiguous operands are required for this shape (vbnn_kmajor_supported says no)");
         return VBNN_ERR_INVALID;
     }
-    const bool v2_ok = gemm_v2_possible<T>(lda, ldb);
+    const bool v2_ok = gemm_v2_possible<T>(lda, ldb) && M * lda < (1ll << 30) && N * ldb < (1ll << 30);
     if (v2_ok && sizeof(T) == 2 &&
         ((g_force_kernel == 3 && gemm_v3_possible(M, N, K, lda, ldb, false, false, epi)) ||
          (g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_eligible(M, N, K, lda, ldb, false, false, epi))))

@@ -150,6 +150,13 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     // (row 8g + (l>>3), chunk slot l&7) with global chunk (l&7) ^ f(row), f(row) = (row >> 1) & 7.
     const bf16_t* a_src[2][AG];
     const bf16_t* b_src[2][BG];
+#if defined(__HIP_DEVICE_COMPILE__)       // the LDS-DMA pieces go out in buffer form (see gemm_v3.h): SGPR resource + 32-bit lane byte offset + SGPR K offset
+    int dma_avo[AG], dma_bvo[BG];
+    const __amdgpu_buffer_rsrc_t dma_ra[2] = {__builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000),
+                                              __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? A2 : A), 0, 0x7fffffff, 0x00020000)};
+    const __amdgpu_buffer_rsrc_t dma_rb[2] = {__builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000),
+                                              __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? B2 : B), 0, 0x7fffffff, 0x00020000)};
+#endif
     static_assert(!KM || (WM == 4 && !DUAL), "the K-major form exists for the 256 x 128 single-accumulator tile only");
     auto hk = [](int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); };
 #pragma unroll
@@ -166,6 +173,9 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         }
         a_src[0][i] = A + off;
         a_src[1][i] = DUAL ? A2 + off : A + off;
+#if defined(__HIP_DEVICE_COMPILE__)
+        dma_avo[i] = (int)(off * 2);
+#endif
     }
 #pragma unroll
     for (int i = 0; i < BG; ++i) {
@@ -181,6 +191,9 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         }
         b_src[0][i] = B + off;
         b_src[1][i] = DUAL ? B2 + off : B + off;
+#if defined(__HIP_DEVICE_COMPILE__)
+        dma_bvo[i] = (int)(off * 2);
+#endif
     }
     const int U = DUAL ? 2 * nk : nk;       // tiles in the stream
 
@@ -196,9 +209,18 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
 #endif
         const int64_t koff = KM ? kstep * (IDX < AG ? lda : ldb) : kstep;
         unsigned char* base = lds + (u % ST) * STAGE;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int dma_so = __builtin_amdgcn_readfirstlane((int)(koff * 2));
+        if constexpr (IDX < AG)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_ra[P], (lptr_t)(base + (wave + NW * IDX) * 1024), 16, dma_avo[IDX], dma_so, 0, 0);
+#ifndef V2_LAB_SKIP_B      // tools/gemm_lab.hip only: time the loop with a third of the DMA traffic removed (wrong results)
+        else if constexpr (IDX < G)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rb[P], (lptr_t)(base + A_BYTES + (wave + NW * (IDX - AG)) * 1024), 16,
+                                                     dma_bvo[IDX - AG], dma_so, 0, 0);
+#endif
+#else
         if constexpr (IDX < AG)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + NW * IDX) * 1024), 16, 0, 0);
-#ifndef V2_LAB_SKIP_B      // tools/gemm_lab.hip only: time the loop with a third of the DMA traffic removed (wrong results)
         else if constexpr (IDX < G)
             __builtin_amdgcn_global_load_lds((gptr_t)(b_src[P][IDX - AG] + koff),
                                              (lptr_t)(base + A_BYTES + (wave + NW * (IDX - AG)) * 1024), 16, 0, 0);

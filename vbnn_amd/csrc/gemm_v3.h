@@ -120,15 +120,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
 #else
 #define V3_KT(t) (t)
 #endif
+    // The LDS-DMA pieces go out in their BUFFER form: resource in SGPRs, the lane's byte offset in one VGPR, the K step in
+    // an SGPR -- no 64-bit address arithmetic per piece, and the piece issues a few cycles sooner (lab: -2.5 ... -5 %
+    // on the pipelined loops, which are bound by exactly this issue). The host pass never runs the body.
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, 0x7fffffff, 0x00020000);
+#define V3_SET_OPERANDS(a_, b_) do { Ap = (a_); Bp = (b_); ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, 0x7fffffff, 0x00020000); \
+                                     rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, 0x7fffffff, 0x00020000); } while (0)
+#else
+#define V3_SET_OPERANDS(a_, b_) do { Ap = (a_); Bp = (b_); } while (0)
+#endif
     auto dma_a = [&](int t, auto P_c, auto d_c) {
         constexpr int P = decltype(P_c)::value, D = decltype(d_c)::value;
-        __builtin_amdgcn_global_load_lds((gptr_t)(Ap + (a_off[P][D] + V3_KT(t) * a_kstep)),
-                                         (lptr_t)(lds + ((t & 1) * 2 + P) * V3_APART + (wave + 8 * D) * 1024), 16, 0, 0);
+        unsigned char* dst = lds + ((t & 1) * 2 + P) * V3_APART + (wave + 8 * D) * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)dst, 16, (int)(2u * (unsigned)a_off[P][D]),
+                                                 (int)(2u * (unsigned)(V3_KT(t) * a_kstep)), 0, 0);
+#else
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ap + (a_off[P][D] + V3_KT(t) * a_kstep)), (lptr_t)dst, 16, 0, 0);
+#endif
     };
     auto dma_b = [&](int t, int slot, auto d_c) {
         constexpr int D = decltype(d_c)::value;
-        __builtin_amdgcn_global_load_lds((gptr_t)(Bp + (b_off[D] + V3_KT(t) * b_kstep)),
-                                         (lptr_t)(lds + 4 * V3_APART + slot * V3_BTILE + (wave + 8 * D) * 1024), 16, 0, 0);
+        unsigned char* dst = lds + 4 * V3_APART + slot * V3_BTILE + (wave + 8 * D) * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)dst, 16, (int)(2u * (unsigned)b_off[D]),
+                                                 (int)(2u * (unsigned)(V3_KT(t) * b_kstep)), 0, 0);
+#else
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bp + (b_off[D] + V3_KT(t) * b_kstep)), (lptr_t)dst, 16, 0, 0);
+#endif
     };
     std::integral_constant<int, 0> c0;
     std::integral_constant<int, 1> c1;
@@ -387,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         // The pair as two passes over ONE accumulator (the functor's FOLD protocol, epilogues.h): the pair's second GEMM
         // first; then every accumulator quad, as it stands in the MFMA layout (lane (q4, c16): 4 consecutive m at one n),
         // is turned into the term the first GEMM accumulates on top of -- in registers, no LDS, nothing parked.
-        Ap = A2; Bp = B2;
+        V3_SET_OPERANDS(A2, B2);
         zero_acc();
         prologue();
         run_pass();
@@ -395,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         // loads and stores are younger than those DMAs on the in-order vmcnt counter: the counted waits of run_pass
         // only get stricter.)
         __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
-        Ap = A; Bp = B;
+        V3_SET_OPERANDS(A, B);
         prologue();
         // opaque to the optimiser from here on: otherwise the fold's address / counter arithmetic is hoisted above
         // pass 1 and held live through its loop, which is already at the register limit (it spilled)
@@ -533,8 +554,9 @@ static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t K, int64_t lda
     Epi e = epi;
     const bool t_ok = (!e.t1_ptr() && !e.t2_ptr()) ||
                       ((e.t_ld() % 8 == 0) && ((((uintptr_t)e.t1_ptr() | (uintptr_t)e.t2_ptr()) & 15u) == 0));
-    const bool a_ok = ak ? (K % V2_BK == 0 && lda % 8 == 0 && lda >= M && K * lda < (1ll << 31)) : M * lda < (1ll << 31);
-    const bool b_ok = bk ? (K % V2_BK == 0 && ldb % 8 == 0 && ldb >= N && K * ldb < (1ll << 31)) : N * ldb < (1ll << 31);
+    // operand extents below 2^30 elements: the LDS-DMA goes out in buffer form with 32-bit BYTE offsets under a 2 GiB range
+    const bool a_ok = ak ? (K % V2_BK == 0 && lda % 8 == 0 && lda >= M && K * lda < (1ll << 30)) : M * lda < (1ll << 30);
+    const bool b_ok = bk ? (K % V2_BK == 0 && ldb % 8 == 0 && ldb >= N && K * ldb < (1ll << 30)) : N * ldb < (1ll << 30);
     return (M % V3_BM == 0) && (N % V3_BN == 0) && a_ok && b_ok && epi.fast_ok() && t_ok && M * e.t_ld() < (1ll << 31);
 }
 // Worth it when K is long enough to amortise the second pipeline fill and the fold between the passes (measured against
