@@ -151,6 +151,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         __builtin_amdgcn_global_load_lds((gptr_t)(Bp + (b_off[D] + V3_KT(t) * b_kstep)), (lptr_t)dst, 16, 0, 0);
 #endif
     };
+    // the main loop's form: LDS destination and K offset are LOOP-CARRIED scalars (run_pass), so a piece costs one
+    // scalar add for M0 instead of six scalar operations recomputing both from the step index (lab: the address work
+    // was 8-10 % of the loop, which is bound by the issue of these pieces)
+    auto dma_a_at = [&](unsigned lds_off, int so_bytes, auto P_c, auto d_c) {
+        constexpr int P = decltype(P_c)::value, D = decltype(d_c)::value;
+        unsigned char* dst = lds + lds_off + (P * V3_APART + D * 8192) + wave * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)dst, 16, (int)(2u * (unsigned)a_off[P][D]), so_bytes, 0, 0);
+#else
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ap + a_off[P][D] + so_bytes / 2), (lptr_t)dst, 16, 0, 0);
+#endif
+    };
+    auto dma_b_at = [&](unsigned lds_off, int so_bytes, auto d_c) {
+        constexpr int D = decltype(d_c)::value;
+        unsigned char* dst = lds + lds_off + (4 * V3_APART + D * 8192) + wave * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)dst, 16, (int)(2u * (unsigned)b_off[D]), so_bytes, 0, 0);
+#else
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bp + b_off[D] + so_bytes / 2), (lptr_t)dst, 16, 0, 0);
+#endif
+    };
     std::integral_constant<int, 0> c0;
     std::integral_constant<int, 1> c1;
     std::integral_constant<int, 2> c2;
@@ -255,22 +276,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         }
     };
     auto run_pass = [&]() {
-        int bs = 0;                                           // B slot of step t (t % 3)
-        for (int t = 0; t < nk; ++t) {
-            const int bs2 = bs == 0 ? 2 : bs - 1;             // (t + 2) % 3
-            const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-            const unsigned char* sb = lds + 4 * V3_APART + bs * V3_BTILE;
+        // loop-carried scalars of step t: LDS offset of A part (t & 1) * 2, of B slots t % 3 and (t + 2) % 3, and the
+        // operands' byte offsets of step t (see dma_a_at)
+        unsigned oa = 0, ob = 0, ob2 = 2 * V3_BTILE;
+        int ka = 0, kb = 0;
+        const int da = 2 * a_kstep, db = 2 * b_kstep;
+        // TAIL = false: a step with both prefetches ahead of it (every DMA unconditional, constant waits); the last two
+        // steps take the guarded form
+        auto kstep = [&](const int t, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
+            const bool n1 = TAIL ? (t + 1 < nk) : true, n2 = TAIL ? (t + 2 < nk) : true;
+#ifdef V3_LAB_KWRAP
+            const int so_a1 = 2 * V3_KT(t + 1) * a_kstep, so_a2 = 2 * V3_KT(t + 2) * a_kstep, so_b2 = 2 * V3_KT(t + 2) * b_kstep;
+#else
+            const int so_a1 = ka + da, so_a2 = ka + 2 * da, so_b2 = kb + 2 * db;
+#endif
+            const unsigned oa_next = oa ^ (2u * V3_APART);        // A part pair of step t + 1
+            const unsigned char* sb = lds + 4 * V3_APART + ob;
             bf16x8 bf[2][4];
             // ------------------------------------------------ phase 0: A rows 0..63 of the wave
-            if (t == nk - 1) v2_wait_vmcnt<2>(); else v2_wait_vmcnt<8>();
+            if (TAIL && t == nk - 1) v2_wait_vmcnt<2>(); else v2_wait_vmcnt<8>();
             __builtin_amdgcn_s_barrier();
             {
-                const unsigned char* sa = lds + ((t & 1) * 2 + 0) * V3_APART;
+                const unsigned char* sa = lds + oa;
                 auto dma_slot = [&](int s, int i) {
-                    if (s == 0 && i == 1 && n1) dma_a(t + 1, c1, c0);
-                    if (s == 0 && i == 3 && n1) dma_a(t + 1, c1, c1);
-                    if (s == 1 && i == 1 && n2) dma_b(t + 2, bs2, c0);
-                    if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c1);
+                    if (s == 0 && i == 1 && n1) dma_a_at(oa_next, so_a1, c1, c0);
+                    if (s == 0 && i == 3 && n1) dma_a_at(oa_next, so_a1, c1, c1);
+                    if (s == 1 && i == 1 && n2) dma_b_at(ob2, so_b2, c0);
+                    if (s == 1 && i == 3 && n2) dma_b_at(ob2, so_b2, c1);
                 };
                 if constexpr (AK) {
                     const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
@@ -317,15 +350,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 }
             }
             // ------------------------------------------------ phase 1: A rows 64..127 of the wave, B from registers
-            if (t == nk - 1) v2_wait_vmcnt<0>(); else if (t == nk - 2) v2_wait_vmcnt<8>(); else v2_wait_vmcnt<10>();
+            if (TAIL && t == nk - 1) v2_wait_vmcnt<0>(); else if (TAIL && t == nk - 2) v2_wait_vmcnt<8>(); else v2_wait_vmcnt<10>();
             __builtin_amdgcn_s_barrier();
             {
-                const unsigned char* sa = lds + ((t & 1) * 2 + 1) * V3_APART;
+                const unsigned char* sa = lds + oa + V3_APART;
                 auto dma_slot = [&](int s, int i) {
-                    if (s == 0 && i == 1 && n2) dma_a(t + 2, c0, c0);
-                    if (s == 0 && i == 3 && n2) dma_a(t + 2, c0, c1);
-                    if (s == 1 && i == 1 && n2) dma_b(t + 2, bs2, c2);
-                    if (s == 1 && i == 3 && n2) dma_b(t + 2, bs2, c3);
+                    if (s == 0 && i == 1 && n2) dma_a_at(oa, so_a2, c0, c0);      // (t + 2) & 1 == t & 1: this step's part 0
+                    if (s == 0 && i == 3 && n2) dma_a_at(oa, so_a2, c0, c1);
+                    if (s == 1 && i == 1 && n2) dma_b_at(ob2, so_b2, c2);
+                    if (s == 1 && i == 3 && n2) dma_b_at(ob2, so_b2, c3);
                 };
                 if constexpr (AK) {
                     const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
@@ -368,8 +401,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                     half(c0); half(c1);
                 }
             }
-            bs = bs == 2 ? 0 : bs + 1;
-        }
+            oa = oa_next;
+            ob = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+            ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
+            ka += da; kb += db;
+        };
+        int t = 0;
+        for (; t + 2 < nk; ++t) kstep(t, std::false_type());
+        for (; t < nk; ++t) kstep(t, std::true_type());
     };
 
     // ---- epilogue: the LDS re-layout of gemm_v2.h, one QUARTER of the wave tile (64 m x 32 n) at a time -- a whole
