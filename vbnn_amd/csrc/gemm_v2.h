@@ -98,7 +98,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: keep it in an SGPR (LDS-DMA destinations)
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- block -> tile mapping. Blocks that share an XCD (bid % 8, T1) get a contiguous chunk of
@@ -233,6 +233,27 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         issue_one(u, pair_c, std::integral_constant<int, 6>()); issue_one(u, pair_c, std::integral_constant<int, 7>());
     };
 
+    // The main loop's form of issue_one: the stage's LDS offset and the operands' K byte offsets are LOOP-CARRIED scalars
+    // (advanced once per step below) instead of being recomputed per piece from the tile index (u % ST, a multiply, two
+    // vector adds and a v_readfirstlane per piece).
+    unsigned la_stage = 0;          // LDS offset of the stage of tile u + LA
+    int la_ka = 0, la_kb = 0;       // byte offsets along K of tile u + LA in the A / B operand
+    auto issue_one_at = [&](auto pair_c, auto idx_c) {
+        constexpr int P = decltype(pair_c)::value;
+        constexpr int IDX = decltype(idx_c)::value;
+        (void)P;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (IDX < AG)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_ra[P], (lptr_t)(lds + la_stage + IDX * (NW * 1024) + wave * 1024), 16,
+                                                     dma_avo[IDX], la_ka, 0, 0);
+#ifndef V2_LAB_SKIP_B
+        else if constexpr (IDX < G)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rb[P], (lptr_t)(lds + la_stage + (A_BYTES + (IDX - AG) * (NW * 1024)) + wave * 1024),
+                                                     16, dma_bvo[IDX - AG], la_kb, 0, 0);
+#endif
+#endif
+    };
+
     // ---- fragment read offsets (bytes inside a stage). Lane reads row r = base + (l & 15), chunk
     // c = 4s + (l >> 4) of k-half s; swizzled chunk = c ^ ((r >> 1) & 7). Row bases are multiples of 16,
     // so (r >> 1) & 7 == ((l & 15) >> 1) for every fragment of the lane.
@@ -295,20 +316,34 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     // tile u + LA (LA = ST - 1 tiles of lookahead) is issued while tile u is computed; its operand pair is the pair
     // of tile u when LA = 2 and the other pair when LA = 1 (DUAL alternates pairs tile by tile)
     constexpr int LA = ST - 1;
-    auto step = [&](int u, auto pair_c, auto next_c, f32x4 (&acc)[4][4]) {
+    la_stage = (unsigned)(LA % ST) * STAGE;
+    {
+        const int kidx = kt0 + (DUAL ? (LA >> 1) : LA);
+        la_ka = 2 * kidx * V2_BK * (KM ? (int)lda : 1);
+        la_kb = 2 * kidx * V2_BK * (KM ? (int)ldb : 1);
+    }
+    const int la_dka = 2 * V2_BK * (KM ? (int)lda : 1), la_dkb = 2 * V2_BK * (KM ? (int)ldb : 1);
+    // ALWAYS: tile u + LA exists (every step but the last LA): its DMAs are unconditional and the waits constant
+    auto step = [&](int u, auto pair_c, auto next_c, f32x4 (&acc)[4][4], auto always_c) {
+        constexpr bool ALWAYS = decltype(always_c)::value;
         auto la_c = std::conditional_t<ST == 3, decltype(pair_c), decltype(next_c)>();
         V2_STAMP(0);
 #ifdef V2_LAB_SKIP_B
         if (u + 1 < U) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #else
-        if (ST == 3 && u + 1 < U) v2_wait_vmcnt<G>();     // tile u + 1's DMAs may stay in flight
+        if (ST == 3 && (ALWAYS || u + 1 < U)) v2_wait_vmcnt<G>();     // tile u + 1's DMAs may stay in flight
 #endif
         else                       v2_wait_vmcnt<0>();
         V2_STAMP(1);                                     // [0->1] waiting for this wave's DMAs
         __builtin_amdgcn_s_barrier();
         V2_STAMP(2);                                     // [1->2] barrier
-        const bool more = u + LA < U;
-        if (SCHED == 0 && more) issue(u + LA, la_c);
+        const bool more = ALWAYS ? true : (u + LA < U);
+        if (SCHED == 0 && more) {
+            issue_one_at(la_c, std::integral_constant<int, 0>()); issue_one_at(la_c, std::integral_constant<int, 1>());
+            issue_one_at(la_c, std::integral_constant<int, 2>()); issue_one_at(la_c, std::integral_constant<int, 3>());
+            issue_one_at(la_c, std::integral_constant<int, 4>()); issue_one_at(la_c, std::integral_constant<int, 5>());
+            issue_one_at(la_c, std::integral_constant<int, 6>()); issue_one_at(la_c, std::integral_constant<int, 7>());
+        }
         V2_STAMP(3);                                     // [2->3] issuing the DMAs (schedule 0)
         const unsigned char* stage = lds + (u % ST) * STAGE;
 #pragma unroll
@@ -335,14 +370,14 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
                 }
             }
             auto slot = [&](int s_, int i_) {            // the DMA that belongs to MFMA group (k-half s_, row i_)
-                if (s_ == 0 && i_ == 0) issue_one(u + LA, la_c, std::integral_constant<int, 0>());
-                if (s_ == 0 && i_ == 1) issue_one(u + LA, la_c, std::integral_constant<int, 1>());
-                if (s_ == 0 && i_ == 2) issue_one(u + LA, la_c, std::integral_constant<int, 2>());
-                if (s_ == 0 && i_ == 3) issue_one(u + LA, la_c, std::integral_constant<int, 6>());
-                if (s_ == 1 && i_ == 0) issue_one(u + LA, la_c, std::integral_constant<int, 3>());
-                if (s_ == 1 && i_ == 1) issue_one(u + LA, la_c, std::integral_constant<int, 4>());
-                if (s_ == 1 && i_ == 2) issue_one(u + LA, la_c, std::integral_constant<int, 5>());
-                if (s_ == 1 && i_ == 3) issue_one(u + LA, la_c, std::integral_constant<int, 7>());
+                if (s_ == 0 && i_ == 0) issue_one_at(la_c, std::integral_constant<int, 0>());
+                if (s_ == 0 && i_ == 1) issue_one_at(la_c, std::integral_constant<int, 1>());
+                if (s_ == 0 && i_ == 2) issue_one_at(la_c, std::integral_constant<int, 2>());
+                if (s_ == 0 && i_ == 3) issue_one_at(la_c, std::integral_constant<int, 6>());
+                if (s_ == 1 && i_ == 0) issue_one_at(la_c, std::integral_constant<int, 3>());
+                if (s_ == 1 && i_ == 1) issue_one_at(la_c, std::integral_constant<int, 4>());
+                if (s_ == 1 && i_ == 2) issue_one_at(la_c, std::integral_constant<int, 5>());
+                if (s_ == 1 && i_ == 3) issue_one_at(la_c, std::integral_constant<int, 7>());
             };
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -360,11 +395,17 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
             }
         }
         V2_STAMP(4);                                     // [3->4] 16 ds_read_b128 + 32 MFMA
+        la_stage = la_stage == (unsigned)(ST - 1) * STAGE ? 0u : la_stage + STAGE;       // tile u + 1 + LA
+        if constexpr (!DUAL || decltype(la_c)::value == 1) { la_ka += la_dka; la_kb += la_dkb; }
     };
     if (DUAL) {
-        for (int u = 0; u < U; u += 2) { step(u, c0, c1, acc1); step(u + 1, c1, c0, acc2); }
+        int u = 0;
+        for (; u + 1 + LA < U; u += 2) { step(u, c0, c1, acc1, std::true_type()); step(u + 1, c1, c0, acc2, std::true_type()); }
+        for (; u < U; u += 2) { step(u, c0, c1, acc1, std::false_type()); step(u + 1, c1, c0, acc2, std::false_type()); }
     } else {
-        for (int u = 0; u < U; ++u) step(u, c0, c0, acc1);
+        int u = 0;
+        for (; u + LA < U; ++u) step(u, c0, c0, acc1, std::true_type());
+        for (; u < U; ++u) step(u, c0, c0, acc1, std::false_type());
     }
     V2_STAMP_FLUSH
 
