@@ -94,6 +94,9 @@ class FusedMLP:
         self.gradWeight3 = take(self.n_classes * H, (self.n_classes, H))
         self.gradBias3 = take(self.n_classes, (self.n_classes,))
         self.bucket3 = self.grads[start:off]
+        # the final Linear's gradients sit right behind the last VB layer's in the arena: ONE all-reduce covers both (the
+        # head's backward finishes before that layer's accGradParameters is even launched), a collective fewer per step
+        self.bucket_tail = self.grads[off - self.bucket3.numel() - self.vb[-1].bucket.numel():off]
         self.w3_s = _Packed(self.n_classes, H, self.tdt, dev)
         self.w3T_s = _Packed(H, self.n_classes, self.tdt, dev)
         self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -283,7 +286,6 @@ class FusedMLP:
                      scale=1.0, accumulate=accumulate, gradWeight=_p(self.gradWeight3), gradSum=None)
         L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
         L.check(lib.vbnn_acc_grad_bias(ctx, L.F32, _p(self.g_logits), Cn, N, Cn, 1.0, accumulate, _p(self.gradBias3)))
-        self._reduce(self.bucket3)
         vl = self.vb[-1]
         dx = L.DxArgs(wT=self.w3T_s.ptr, w2T=None, g=self.g3_s.ptr, gv=None, ld_wT=self.w3T_s.ld, ld_g=self.g3_s.ld,
                       N=N, I=H, O=Cn, x=self.h_s.ptr, ld_x=self.h_s.ld, gx=None, ld_gx=0, relu_mask=1,
@@ -379,7 +381,6 @@ class FusedMLP:
                                            vl.g_s.ptr,
                                            vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr if vl.gT_s else None,
                                            vl.gvT_s.ptr if (lrt and vl.gvT_s) else None, vl.gT_s.ld if vl.gT_s else 0))
-            self._reduce(self.bucket3)
         else:
             self._generic_head(N, targets, inv_n, accumulate)
         # ---------------- backward: VB layers, last to first. accGradParameters (+ bias gradient + the bucket's
@@ -395,7 +396,7 @@ class FusedMLP:
                 # the fused head already summed the last layer's g columns; ones-row layers got theirs from the GEMM
                 if not (fused_head and li == nl - 1) and not v.bias_from_dw:
                     L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
-                self._reduce(v.bucket)
+                self._reduce(self.bucket_tail if li == nl - 1 else v.bucket)
                 if li > 0:
                     dx = self._dx_args(li, N)
                     with self._probed("updateGradInput", li):
@@ -412,7 +413,7 @@ class FusedMLP:
                 if not (fused_head and li == nl - 1) and not v.bias_from_dw:
                     L.check(lib.vbnn_acc_grad_bias(ctx2, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
                 with torch.cuda.stream(side):
-                    self._reduce(v.bucket)                   # RCCL orders itself after the side stream
+                    self._reduce(self.bucket_tail if li == nl - 1 else v.bucket)   # RCCL orders itself after the side stream
                 if li > 0:
                     dx = self._dx_args(li, N)
                     L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
