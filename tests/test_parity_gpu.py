@@ -379,7 +379,9 @@ def test_engine_bf16_close_to_f32_oracle(oracle, nnmod, gemm_kernel, mode):
 
 
 @pytest.mark.parametrize("hidden,I0,N", [([50, 34], 70, 37), ([400, 400], 784, 256), ([512, 384], 320, 640),
-                                         ([512, 256], 256, 512)])     # the last: whole 256 x 256 tiles (gemm_v3.h)
+                                         ([512, 256], 256, 512),      # whole 256 x 256 tiles (gemm_v3.h)
+                                         ([256, 256], 64, 256), ([256, 512], 128, 256), ([512, 256], 192, 256)])
+                                         # the last three: 1, 2 and 3 K steps in the first forward (gemm_v3's peeled pipeline)
 @pytest.mark.parametrize("fuse_kl", [False, True])
 def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidden, I0, N, fuse_kl):
     """The bf16 fused step against float64 math that rounds to bf16 at exactly the engine's rounding points
@@ -452,6 +454,29 @@ def test_bf16_gemm_exact_on_integers(nnmod, gemm_kernel, N, I, O):
         assert np.array_equal(gx, g @ W)
         assert np.array_equal(host(m.gradWeight), g.T @ x)
         assert np.array_equal(host(m.gradBias), g.sum(axis=0))
+
+
+@pytest.mark.parametrize("N,I,O", [(256, 64, 256), (256, 128, 512), (512, 192, 256), (256, 256, 256), (512, 320, 256)])
+def test_two_pass_kernel_short_k(nnmod, N, I, O):
+    """gemm_v3's peeled pipeline (prologue of two steps, unguarded main loop, guarded last two steps) at 1, 2, 3, 4 and 5
+    K steps in each of its three roles (forced with debug key 0 = 3; the shape rule would never pick it for these)."""
+    from vbnn_amd import _lib as L
+    L.check(L.lib().vbnn_debug_set(0, 3))
+    try:
+        rng = np.random.default_rng(N + I + O)
+        W = rng.integers(-3, 4, (O, I)).astype(np.float32)
+        b = rng.integers(-5, 6, O).astype(np.float32)
+        x = rng.integers(-3, 4, (N, I)).astype(np.float32)
+        g = rng.integers(-2, 3, (N, O)).astype(np.float32)
+        m = nnmod.Linear(I, O, dict(dtype="bf16"))
+        m.weight.copy_(dev(W)); m.bias.copy_(dev(b))
+        for _ in range(2):
+            assert np.array_equal(host(m.updateOutput(dev(x))), x @ W.T + b)
+            m.gradWeight.zero_(); m.gradBias.zero_()
+            assert np.array_equal(host(m.backward(dev(x), dev(g), 1.0)), g @ W)
+            assert np.array_equal(host(m.gradWeight), g.T @ x)
+    finally:
+        L.check(L.lib().vbnn_debug_set(0, 0))
 
 
 def _fuzz_shapes():
