@@ -1,0 +1,52 @@
+"""The engine's REAL multi-rank path on the MI355X: two processes, one GPU, gloo collectives (RCCL needs a GPU per rank;
+the builder's box has one). Everything but the transport is what `bench.py --gpus N` runs: the row partition, z by global
+row, the criterion over the global batch, KL / world, the async all-reduces issued inside the step (the final Linear's
+gradients riding in the last VB layer's), finish(). The reduced arena must equal a single process on the whole batch."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("dtype,hidden,I0,N,tol", [("f32", "50,34", 70, 64, 2e-5), ("bf16", "512,256", 256, 512, 2e-3),
+                                                    ("bf16", "4096,4096", 784, 1024, 2e-3)])
+def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hidden, I0, N, tol):
+    import torch
+    from vbnn_amd.engine import FusedMLP
+    from vbnn_amd.nn import fill_normal
+    out = str(tmp_path / "r")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), out, dtype, hidden, str(I0), str(N)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    got = np.load(out + ".grads.npy")
+    loss2 = float(np.load(out + ".loss.npy")[0])
+    opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=1, mode="lrt", dtype=dtype, seed=3, input_size=I0,
+               hidden=[int(h) for h in hidden.split(",")], n_classes=10, fuse_kl=True)
+    eng = FusedMLP(opt)
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    fill_normal(x, 3, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    for _ in range(2):
+        eng.resetGradients(); eng.prepare(); eng.sample()
+        eng.run(x, t)
+    loss1, _ = eng.loss_and_accuracy()
+    want = eng.grads.cpu().numpy()
+    assert abs(loss2 - loss1) <= 1e-5 * abs(loss1), (loss2, loss1)
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel <= tol, rel
