@@ -163,6 +163,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: no HIP device is visible and there is no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    # rehearsal on a box with fewer GPUs than ranks (VBNN_DIST_BACKEND=gloo: RCCL wants a device per rank): ranks share devices
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # VBNN_FORCE_DIST=1: run the RCCL code path (process group, bucketed all-reduce, barriers) even with one
     # rank -- the only way to exercise it on a one-GPU box
@@ -172,7 +174,11 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+        backend = os.environ.get("VBNN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     L.lib()                                               # fail loudly if the HIP extension is missing
 
     cfg = dict(CONFIGS[args.config])
