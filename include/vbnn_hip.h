@@ -16,7 +16,9 @@
  *     are the only blocking calls.
  *   - matrices are dense row-major. "packed operands" are the GEMM-ready copies made by
  *     vbnn_pack: element type f32 or bf16 (dtype), leading dimension padded to a
- *     multiple of VBNN_KPAD elements with ZERO fill (allocate them zeroed).
+ *     multiple of VBNN_KPAD elements with ZERO fill (allocate them zeroed). A packed bf16
+ *     operand of 2^30 elements (rows x ld) or more is still computed, by the general kernel:
+ *     the pipelined kernels address their operands with 32-bit byte offsets.
  *   - O = outputSize, I = inputSize, N = minibatch rows (local rows on this rank).
  */
 #ifndef VBNN_HIP_H
