@@ -2,14 +2,20 @@
 """bench.py -- VBLinear fwd+bwd samples/sec on MI355X (BASELINE.json's metric).
 
 A step = one pass of the hot path over one synthetic minibatch, exactly main.lua:28-37 with S = 1:
-    resetGradients -> (compute_prior + operand packing) -> sample -> run (forward of every VB layer,
-    final Linear, LogSoftMax + ClassNLL, backward with accGradParameters incl. the KL-gradient
-    epilogue) -> all-reduce of the gradient arena when N > 1.
-The optimiser update is excluded. Inputs are resident in HBM before the timed region.
+    resetGradients -> sample -> run (input packing, forward of every VB layer, final Linear, LogSoftMax + ClassNLL,
+    backward with accGradParameters incl. the KL-gradient epilogue) -> all-reduce of the gradient arena when N > 1.
+The optimiser update is excluded -- and with it the parameter sweep: the reference runs
+`compute_prior` inside `VBLinear:update` (VBLinear.lua:130), and here the update kernel (vbnn_update) is what
+leaves the bf16 mu / sigma^2 operand shadows and the prior statistics for the next minibatch; `prepare()` runs once,
+before the first step (`--prepare-each-step` puts it back into the step: round 1's protocol). `--with-update`
+times the whole training step (step + update) beside it. Inputs are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config wide|small]
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).
-Prints ONE JSON line on rank 0.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config wide|small|deep]
+N > 1: launched by the driver through torch.distributed.run (one rank per GPU, RCCL) -- or, from a bare shell, by
+bench.py itself: a parent that has not imported torch or touched HIP starts the same torch.distributed.run line as a
+CHILD process, relays its output and exits with its code. The timed region is `--repeats` (5) blocks of exactly K
+steps, each bracketed by barrier + synchronize (wall clock, MAX over ranks) and by HIP events; `ms_per_step` is the
+median block. Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -130,19 +136,47 @@ def cpu_baseline(cfg, budget_s=25.0):
                        f"on NumPy/OpenBLAS sgemm + MT19937 Gaussian fill, {el:.1f} s; Torch7 itself cannot run here")
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` from a bare shell: start the ranks as a CHILD process (never exec), before this
+    process has imported torch or made any HIP call, and hand back the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def device_identity(torch, idx):
+    p = torch.cuda.get_device_properties(idx)
+    uuid = getattr(p, "uuid", None)
+    return str(uuid) if uuid is not None else f"{p.name}#{getattr(p, 'pci_bus_id', idx)}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; ms_per_step is the median block")
     ap.add_argument("--config", default="wide", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run accGradParameters on a second stream (A/B; slower)")
     ap.add_argument("--mode", default="lrt", choices=["lrt", "wn"])
     ap.add_argument("--batch", type=int, default=0, help="exploration only: rows per GPU instead of the configuration's")
-    ap.add_argument("--probe-every", type=int, default=8, help="bracket the roofline kernels with HIP events on every n-th timed step")
+    ap.add_argument("--S", type=int, default=1, help="Monte-Carlo draws per minibatch (main.lua:32-37); the metric is quoted at 1")
+    ap.add_argument("--prepare-each-step", action="store_true", help="round 1's protocol: the parameter sweep inside every step")
+    ap.add_argument("--with-update", action="store_true", help="also time step + optimiser update (reported beside the metric)")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # multi-process GPU work on this driver needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the boxes
     # export it already, this keeps a hand-built environment from dropping it
@@ -156,15 +190,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (WORLD_SIZE={world})",
+    if args.gpus != world:
+        print(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher's rank count must match",
               file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: no HIP device is visible and there is no CPU fallback", file=sys.stderr)
         sys.exit(2)
-    # rehearsal on a box with fewer GPUs than ranks (VBNN_DIST_BACKEND=gloo: RCCL wants a device per rank): ranks share devices
-    local_rank %= torch.cuda.device_count()
+    backend = os.environ.get("VBNN_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > ndev and backend == "nccl":
+        print(f"bench.py --gpus {world}: {ndev} HIP device(s) visible and RCCL wants one per rank "
+              "(a rehearsal on fewer devices: VBNN_DIST_BACKEND=gloo, ranks share devices)", file=sys.stderr)
+        sys.exit(2)
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
     # VBNN_FORCE_DIST=1: run the RCCL code path (process group, bucketed all-reduce, barriers) even with one
     # rank -- the only way to exercise it on a one-GPU box
@@ -174,7 +213,6 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("VBNN_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
         else:
@@ -185,9 +223,13 @@ def main():
     if args.batch > 0:
         cfg["batch"] = args.batch
         cfg["name"] += f" [batch overridden: {args.batch}]"
+    if args.S != 1:
+        cfg["name"] = cfg["name"].replace("S=1", f"S={args.S}")
     N = cfg["batch"]
-    opt = dict(var_init=1e-3, B=1e6, S=1, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
-               hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap)
+    opt = dict(var_init=1e-3, B=1e6, S=args.S, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
+               hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap,
+               criterion=cfg.get("criterion", "nll"),
+               state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
     for kv in filter(None, args.debug_set.split(",")):
         k, v = kv.split("=")
@@ -195,56 +237,96 @@ def main():
     # synthetic minibatch, resident in HBM: x ~ N(0,1) addressed by GLOBAL row, targets uniform in 0..9
     x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
     fill_normal(x, 3, L.STREAM_DATA, 0, 0, row0=rank * N)
-    t = ((torch.arange(N, device="cuda", dtype=torch.int64) + rank * N) * 2654435761 % 10).to(torch.int32)
+    t = eng.synthetic_targets(x, rank * N)
 
     def step():
         eng.resetGradients()
-        eng.prepare()
-        eng.sample()
-        eng.run(x, t)
+        if args.prepare_each_step:
+            eng.prepare()
+        for _ in range(args.S):
+            eng.sample()
+            eng.run(x, t)
         eng.finish()
 
+    def train_step():
+        step()
+        eng.update()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_blocks(fn, repeats):
+        """`repeats` blocks of exactly --steps calls of fn: wall clock between barrier + synchronize on both sides (MAX
+        over ranks) and HIP events on the launch stream around the same block."""
+        wall, evms = [], []
+        for _ in range(repeats):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(args.steps):
+                fn()
+            e1.record()
+            barrier()
+            el = time.perf_counter() - t0
+            if use_dist:
+                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            wall.append(el / args.steps * 1e3)
+            evms.append(e0.elapsed_time(e1) / args.steps)
+        return wall, evms
+
+    eng.prepare()                                        # once: afterwards the update kernel maintains shadows + statistics
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events around every launch of the widest layer's three dual GEMMs, on the stream they are launched on,
-    # DURING the timed steps (rank 0): the roofline kernel's average duration comes from these
-    wide_li = max(range(len(eng.vb)), key=lambda k: eng.vb[k].I * eng.vb[k].O)
-    # (every `--probe-every`-th step only: an event record is a marker packet between two kernels, six of them per
-    # step cost ~3 % of a 1.05 ms step)
-    probe = (wide_li, {}) if rank == 0 else None
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.probe = probe if (i % args.probe_every == 0) else None
-        step()
-    eng.probe = probe
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    wall, evms = timed_blocks(step, max(1, args.repeats))
     loss, correct = eng.loss_and_accuracy()
+    ms = sorted(wall)[len(wall) // 2]
+
+    # HIP events around every launch of the widest layer's three dual GEMMs, on the stream they are launched on, in one
+    # more block of --steps steps of the same step (rank 0; kept out of the blocks above: an event record is a marker
+    # packet between two kernels, six per step cost ~3 % of the step)
+    wide_li = max(range(len(eng.vb)), key=lambda k: eng.vb[k].I * eng.vb[k].O)
+    eng.probe = (wide_li, {}) if rank == 0 else None
+    barrier()
+    tp0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    probed_ms = (time.perf_counter() - tp0) / args.steps * 1e3
+    probe, eng.probe = eng.probe, None
+
+    train = None
+    if args.with_update:
+        for _ in range(3):
+            train_step()
+        tw, te = timed_blocks(train_step, max(1, args.repeats))
+        train = {"ms_per_train_step": round(sorted(tw)[len(tw) // 2], 4), "repeats_wall_ms": [round(v, 4) for v in tw],
+                 "note": "step + FusedMLP.update (fused Adam on means / lvars that also writes the operand shadows and prior "
+                         "statistics, SGD on biases and the final Linear)"}
+
+    comm = None
+    if use_dist:
+        ident = [None] * world
+        dist.all_gather_object(ident, (rank, local_rank, device_identity(torch, local_rank), os.getpid()))
+        comm = {"backend": eng.comm_backend(), "ranks_seen": [list(i) for i in ident],
+                "distinct_devices": len({i[2] for i in ident}), "allreduce": eng.time_buckets(5)}
 
     if rank == 0:
         sizes = [cfg["input_size"]] + cfg["hidden"]
-        fps = algorithmic_flops_per_sample(sizes, cfg["n_classes"])
-        ms = el / args.steps * 1e3
+        fps = algorithmic_flops_per_sample(sizes, cfg["n_classes"]) * args.S
         peak = PEAK_TFLOPS[cfg["dtype"]]
-        live = {LIVE_NAMES[k]: sum(a.elapsed_time(b) for a, b in ev) / len(ev) for k, ev in eng.probe[1].items() if ev}
-        eng.probe = None
+        live = {LIVE_NAMES[k]: sum(a.elapsed_time(b) for a, b in ev) / len(ev) for k, ev in probe[1].items() if ev}
         _, _, kflops, kall = dominant_kernel_roofline(eng, N, torch)      # the same launches in isolation (cross-check)
         kname = max(live, key=live.get)
         kms = live[kname]
         achieved = kflops / (kms * 1e-3) / 1e12
         out = {
-            "metric": "VBLinear fwd+bwd samples/sec", "value": round(N * world * args.steps / el, 1),
+            "metric": "VBLinear fwd+bwd samples/sec", "value": round(N * world * args.S / (ms * 1e-3), 1),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
@@ -252,13 +334,23 @@ def main():
                        "parallelism": f"dp{world}", "flop_per_sample": fps,
                        "step_tflops": round(fps * N / (ms * 1e-3) / 1e12, 2),
                        "step_frac_of_mfma_peak": round(fps * N / (ms * 1e-3) / 1e12 / peak, 4),
-                       "loss": round(loss, 5)},
+                       "loss": round(loss, 5),
+                       "step": ("resetGradients, prepare, S x (sample, run), all-reduce" if args.prepare_each_step else
+                                "resetGradients, S x (sample, run), all-reduce; the parameter sweep (compute_prior + operand "
+                                "shadows) belongs to the excluded update, as VBLinear.lua:130 has it: prepare() ran once"),
+                       "timing": f"median of {len(wall)} blocks of {args.steps} steps, wall clock between barrier+synchronize, MAX over ranks",
+                       "repeats_wall_ms": [round(v, 4) for v in wall], "repeats_event_ms": [round(v, 4) for v in evms],
+                       "probed_block_ms": round(probed_ms, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": measured_traffic(kname, args.config), "kernel": kname,
                          "kernel_ms": round(kms, 4), "flop_per_launch": kflops,
                          "timed_region_kernels_ms": {k: round(v_, 4) for k, v_ in live.items()},
                          "isolated_kernels_ms": kall},
         }
+        if train:
+            out["config"]["train"] = train
+        if comm:
+            out["comm"] = comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

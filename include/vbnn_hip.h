@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
 #endif
 
-#define VBNN_ABI_VERSION 1
+#define VBNN_ABI_VERSION 2
 #define VBNN_KPAD 64            /* packed leading dimensions are multiples of this */
 
 enum { VBNN_OK = 0, VBNN_ERR_INVALID = 1, VBNN_ERR_HIP = 2, VBNN_ERR_NOMEM = 3, VBNN_ERR_UNSUPPORTED = 4 };
@@ -271,6 +271,60 @@ int vbnn_adam_step(vbnn_ctx* ctx, float* x, const float* grad, const float* grad
                    float lr, float beta1, float beta2, float eps, float lambda, int64_t t, double* norms_dev);
 /* optim.sgd with only learningRate set (config.lua:51-54): x -= lr * grad (VBLinear.lua:125-128, mlp.lua:120-128). */
 int vbnn_sgd_step(vbnn_ctx* ctx, float* x, const float* grad, int64_t n, float lr);
+
+/* VBLinear:update (VBLinear.lua:124-166) for every VB layer of a model in ONE call, fused with what the NEXT minibatch
+ * needs: per layer one sweep applies optim.sgd to the bias (:125-128) and optim.adam to means and lvars (:135-143, the
+ * arithmetic of vbnn_adam_step) from the TOTAL gradients (likelihood / S + KL: what the fused accGradParameters
+ * epilogue leaves in grad_mu / grad_lv, i.e. `mugrad` / `vgrad` of :132,134) and, from the NEW parameters in the same
+ * pass, writes the packed GEMM shadows and the prior statistics exactly as vbnn_prepare would (the reference runs
+ * compute_prior inside update as well, :130) -- so a training step needs no separate parameter sweep. `extra` as in
+ * vbnn_prepare (the final nn.Linear's weight, packed after its own vbnn_sgd_step). One finish kernel for all layers.
+ * log14 (optional, 14 doubles per layer) receives the series VBLinear.lua:149-164 logs, in that order:
+ *   vlc grad, vle grad, mlc grad, mle grad (norm of the KL / likelihood part over norm of the updated parameter; the
+ *   KL parts are re-derived from the pre-update parameters and stats[2], the likelihood parts are total - KL),
+ *   min / max / mean variance (updated), var hat (pre-update, as self.var_hat is at :156), mean / std (unbiased) / min /
+ *   max of the updated means, mu normratio, var normratio (:139,144).
+ * stats must hold the statistics of the PRE-update parameters on entry (vbnn_prepare / the previous vbnn_update). */
+typedef struct vbnn_adam_cfg { float lr, beta1, beta2, eps, lambda; int64_t t; } vbnn_adam_cfg;
+typedef struct vbnn_update_desc {
+    float* means; float* lvars; int64_t O, I;          /* updated in place */
+    void* mu_s; void* var_s; int64_t ld_w;             /* shadows of the NEW parameters (as vbnn_prep_desc) */
+    void* muT_s; void* varT_s; int64_t ld_wT;          /* NULL / 0: no transposed shadows */
+    double* stats;                                     /* in: pre-update statistics; out: statistics of the new parameters */
+    const float* grad_mu; const float* grad_lv;        /* total gradients, O x I */
+    float* m_mu; float* v_mu; float* m_lv; float* v_lv;    /* Adam state, O x I each */
+    vbnn_adam_cfg mu, lv;                              /* opt.meanState / opt.varState (config.lua:55-64) */
+    float* bias; const float* grad_bias; float lr_bias;    /* optional (NULL): optim.sgd on the bias */
+    float B;                                           /* opt.B: scale of the KL parts in the logged norms */
+    double* log14;                                     /* optional */
+} vbnn_update_desc;
+int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra);
+
+/* ---- data-parallel exchange (north_star: "RCCL all-reduce over xGMI on the (mu, log sigma^2) gradients after
+ * accGradParameters"; the reference itself is single-device, main.lua:142 sets BLAS threads only) ------------------
+ * One process per GPU, one communicator per process. Rank 0 calls vbnn_comm_unique_id and the HOST side hands the
+ * VBNN_COMM_ID_BYTES to every rank by its own means (a file, a socket, torch.distributed's store, MPI ...); every
+ * rank then calls vbnn_comm_create (collective: it returns when all `world` ranks have joined).
+ * vbnn_allreduce_grads(buf, n): in-place SUM over ranks of n floats -- a layer's contiguous gradient bucket
+ * [d/dmeans | d/dlvars | d/dbias]. It is ordered after everything enqueued so far on the context's stream (the
+ * accGradParameters that fills the bucket) and runs on the communicator's own high-priority stream, i.e. beside
+ * the launches that follow (the rest of backward). Every rank must issue the same sequence of calls.
+ * vbnn_comm_finish: orders the context's stream behind every exchange issued so far (no host wait; follow with
+ * vbnn_sync to block). The criterion already divides by the GLOBAL batch and the fused KL gradient carries
+ * 1 / world (vbnn_dw_args.kl_scale), so the sum IS the gradient: no division afterwards.
+ * librccl is loaded on first use (dlopen: VBNN_RCCL_PATH, then librccl.so.1); without it these calls return
+ * VBNN_ERR_UNSUPPORTED and nothing else in the library is affected. */
+#define VBNN_COMM_ID_BYTES 128
+typedef struct vbnn_comm vbnn_comm;
+int vbnn_comm_unique_id(void* id_out /* VBNN_COMM_ID_BYTES, host memory */);
+int vbnn_comm_create(vbnn_ctx* ctx, int rank, int world, const void* id, vbnn_comm** out);
+int vbnn_comm_destroy(vbnn_comm* comm);
+int vbnn_comm_info(vbnn_comm* comm, int* rank, int* world, int* ranks_in_comm /* as RCCL counts them */);
+int vbnn_allreduce_grads(vbnn_comm* comm, float* buf, int64_t n);
+int vbnn_comm_finish(vbnn_comm* comm);
+/* all_dev[r] = rank r's *mine_dev (device memory, 8 bytes per rank), gathered over the same communicator and stream:
+ * lets the host verify that `world` distinct processes / devices take part in the exchange. */
+int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
 
 /* ---- glue modules on the measured path (mlp.lua:12-32) --------------------------------------- */
 int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);

@@ -115,6 +115,28 @@ int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64_t ld_src, 
 int vbnn_adam_step(vbnn_ctx* ctx, float* x, const float* grad, const float* grad2, float* m, float* v, int64_t n,
                    float lr, float beta1, float beta2, float eps, float lambda, int64_t t, double* norms_dev);
 int vbnn_sgd_step(vbnn_ctx* ctx, float* x, const float* grad, int64_t n, float lr);
+typedef struct vbnn_adam_cfg { float lr, beta1, beta2, eps, lambda; int64_t t; } vbnn_adam_cfg;
+typedef struct vbnn_update_desc {
+    float* means; float* lvars; int64_t O, I;
+    void* mu_s; void* var_s; int64_t ld_w;
+    void* muT_s; void* varT_s; int64_t ld_wT;
+    double* stats;
+    const float* grad_mu; const float* grad_lv;
+    float* m_mu; float* v_mu; float* m_lv; float* v_lv;
+    vbnn_adam_cfg mu, lv;
+    float* bias; const float* grad_bias; float lr_bias;
+    float B;
+    double* log14;
+} vbnn_update_desc;
+int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra);
+typedef struct vbnn_comm vbnn_comm;
+int vbnn_comm_unique_id(void* id_out );
+int vbnn_comm_create(vbnn_ctx* ctx, int rank, int world, const void* id, vbnn_comm** out);
+int vbnn_comm_destroy(vbnn_comm* comm);
+int vbnn_comm_info(vbnn_comm* comm, int* rank, int* world, int* ranks_in_comm );
+int vbnn_allreduce_grads(vbnn_comm* comm, float* buf, int64_t n);
+int vbnn_comm_finish(vbnn_comm* comm);
+int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
 int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);
 int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx, int64_t n);
 int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const int32_t* target,

@@ -5,9 +5,10 @@
   - the fused KL gradient carries kl_scale = 1 / world;
   - a SUM all-reduce over [grad_mu | grad_lv | gradBias] per layer + the final Linear's gradients.
 
-The per-rank compute here is the oracle (tests may use it); what is under test is the partition /
-scaling / reduction logic of vbnn_amd/engine.py: the reduced result must equal the single-process result
-on the whole batch.
+The per-rank compute here is the oracle (tests may use it); what is under test is the ENGINE's host logic, called,
+not restated: vbnn_amd/partition.py (row shards, criterion / KL scales, arena layout, message order -- the functions
+FusedMLP computes with) and vbnn_amd/comm.py's TorchExchange (the transport FusedMLP uses under gloo). The reduced
+arena must equal the single-process result on the whole batch.
 """
 import os
 import socket
@@ -42,43 +43,56 @@ def _problem():
 
 
 def _rank_step(rank, world, layers, w3, b3, x, t, outs, B):
-    """What one engine rank computes: local rows, global-row noise, 1/(N_global) criterion, KL / world."""
+    """One engine rank: its rows (partition.shard_rows), noise by GLOBAL row, the criterion and KL scales of
+    partition.scales, its gradients written into an arena laid out by partition.arena_layout."""
     from oracle import vbnn_oracle as vo
     from oracle.ref_numpy import emulate_lrt_step
+    from vbnn_amd import partition
     N = x.shape[0]
-    n_loc = N // world
-    r0 = rank * n_loc
+    r0, n_loc = partition.shard_rows(N, world, rank)
+    sc = partition.scales(n_loc, world)
     xs, ts = x[r0:r0 + n_loc], t[r0:r0 + n_loc]
     zetas = [vo.fill_normal(n_loc, O, 3, vo.STREAM_ZETA, k, 1, r0).astype(np.float64) for k, O in enumerate(outs)]
-    loss, res, gw3, gb3 = emulate_lrt_step(layers, w3, b3, xs, ts, zetas, S=1.0, B=B, inv_n=1.0 / N)
-    flat = []
-    for lay, r in zip(layers, res):
-        vh = float(np.sum(np.exp(lay["lvars"].astype(np.float64)) + lay["means"].astype(np.float64) ** 2) / lay["means"].size)
-        var = np.exp(lay["lvars"].astype(np.float64))
-        kl_mu = lay["means"] / (B * vh)
+    loss, res, gw3, gb3 = emulate_lrt_step(layers, w3, b3, xs, ts, zetas, S=1.0, B=B, inv_n=sc["inv_n"])
+    sizes = [x.shape[1]] + list(outs)
+    lay, fin, total, buckets = partition.arena_layout(sizes, w3.shape[0])
+    arena = np.zeros(total, np.float64)
+
+    def put(span, a):
+        assert a.size == span[1]
+        arena[span[0]:span[0] + span[1]] = a.ravel()
+
+    for d, layer, r in zip(lay, layers, res):
+        vh = float(np.sum(np.exp(layer["lvars"].astype(np.float64)) + layer["means"].astype(np.float64) ** 2) / layer["means"].size)
+        var = np.exp(layer["lvars"].astype(np.float64))
+        kl_mu = layer["means"] / (B * vh)
         kl_lv = (var / vh - 1.0) / (2 * B)
-        # engine epilogue: likelihood / S + kl_scale * KL with kl_scale = 1 / world
-        flat += [(r["grad_mu"] - kl_mu + kl_mu / world).ravel(), (r["grad_lv"] - kl_lv + kl_lv / world).ravel(),
-                 r["gradBias"].ravel()]
-    flat += [gw3.ravel(), gb3.ravel()]
-    return loss, np.concatenate(flat)
+        # the fused epilogue: likelihood / S + kl_scale * KL
+        put(d["mu"], r["grad_mu"] - kl_mu + sc["kl_scale"] * kl_mu)
+        put(d["lv"], r["grad_lv"] - kl_lv + sc["kl_scale"] * kl_lv)
+        put(d["bias"], r["gradBias"])
+    put(fin["weight"], gw3)
+    put(fin["bias"], gb3)
+    return loss, arena, buckets
 
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
+    from vbnn_amd import partition
+    from vbnn_amd.comm import TorchExchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     opt, layers, w3, b3, x, t, outs = _problem()
-    loss, flat = _rank_step(rank, world, layers, w3, b3, x, t, outs, opt["B"])
+    loss, flat, buckets = _rank_step(rank, world, layers, w3, b3, x, t, outs, opt["B"])
     buf = torch.from_numpy(flat.copy())
     lbuf = torch.tensor([loss], dtype=torch.float64)
-    works = [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True),       # as FusedMLP._reduce
-             dist.all_reduce(lbuf, op=dist.ReduceOp.SUM, async_op=True)]
-    for w in works:
-        w.wait()
+    ex = TorchExchange()
+    assert sorted(buckets) == [(0, buckets[-1][1]), (buckets[0][0], flat.size)] and buckets[0][0] == buckets[-1][1]   # the whole arena, once
+    partition.exchange_step(buf, buckets, ex)                 # the messages of FusedMLP.run + finish, in issue order
+    ex.allreduce(lbuf); ex.finish()
     if rank == 0:
         q.put((float(lbuf[0]), buf.numpy().copy()))
     dist.barrier()
@@ -100,8 +114,28 @@ def test_two_rank_allreduce_equals_single_process():
         assert p.exitcode == 0
     sys.path.insert(0, ROOT)
     opt, layers, w3, b3, x, t, outs = _problem()
-    loss1, flat1 = _rank_step(0, 1, layers, w3, b3, x, t, outs, opt["B"])
+    loss1, flat1, _ = _rank_step(0, 1, layers, w3, b3, x, t, outs, opt["B"])
     assert abs(loss1 - loss2) <= 1e-6 * abs(loss1)          # the criterion sums fp32 log-probabilities
     # not bitwise: the per-rank dgemm sees a different row count, its last-bit differences move a few fp32
     # roundings of the activations (1e-7 relative), exactly as on the GPUs
     np.testing.assert_allclose(flat2, flat1, rtol=5e-6, atol=1e-8)
+
+
+def test_partition_host_logic():
+    """Row shards tile the global batch; the scales make a plain SUM the global-batch mean; the arena is covered once."""
+    from vbnn_amd import partition
+    for world in (1, 2, 4, 8):
+        rows = [partition.shard_rows(32768, world, r) for r in range(world)]
+        assert rows[0][0] == 0 and all(rows[i][0] + rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+        assert rows[-1][0] + rows[-1][1] == 32768
+        sc = partition.scales(rows[0][1], world)
+        assert abs(sc["inv_n"] * 32768 - 1.0) < 1e-12 and abs(sc["kl_scale"] * world - 1.0) < 1e-12
+    with pytest.raises(ValueError):
+        partition.shard_rows(10, 4, 0)
+    lay, fin, total, buckets = partition.arena_layout([784, 4096, 4096], 10)
+    assert total == 40026122                                    # SURVEY.md 8d config 4: the all-reduced gradient count
+    covered = sorted(buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert buckets[0] == (lay[1]["bucket"][0], total)           # last VB layer + final Linear first
+    deep = partition.arena_layout([4096] * 9, 10)
+    assert len(deep[3]) == 8 and deep[2] == 8 * (2 * 4096 * 4096 + 4096) + 10 * 4096 + 10

@@ -50,3 +50,29 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hid
     assert abs(loss2 - loss1) <= 1e-5 * abs(loss1), (loss2, loss1)
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert rel <= tol, rel
+
+
+def test_bench_launches_its_own_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts torch.distributed.run as a child before
+    touching HIP, the ranks rendezvous (gloo here: two ranks share the box's one GPU), rank 0's JSON line comes back
+    through the parent and proves that two processes took part."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VBNN_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "3", "--warmup", "1",
+           "--repeats", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * 256 and out["value"] > 0
+    seen = out["comm"]["ranks_seen"]
+    assert sorted(r[0] for r in seen) == [0, 1] and len({r[3] for r in seen}) == 2          # two ranks, two processes
+    assert len(out["comm"]["allreduce"]) == 2 and all(a["ms"] > 0 for a in out["comm"]["allreduce"])
+    assert len(out["config"]["repeats_wall_ms"]) == 2
+    # a rank count the launcher did not provide is an error, not a silent single-rank run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0

@@ -790,6 +790,77 @@ def test_engine_update_matches_oracle(oracle, nnmod):
         np.testing.assert_allclose(host(eng.weight3), onet.last.weight, rtol=0, atol=1e-7 * np.abs(onet.last.weight).max() + 1e-9)
 
 
+def test_update_leaves_what_prepare_would_and_logs_the_14_series(oracle, nnmod):
+    """vbnn_update = VBLinear:update + the next minibatch's parameter sweep in one pass. After two minibatches with
+    updates (Adam state carried): (1) the operand shadows it wrote are BITWISE what vbnn_prepare writes from the updated
+    parameters, the statistics agree to 1e-12; (2) the next step run WITHOUT prepare() gives bitwise the gradients of a
+    step run after prepare(); (3) the 14 logged series (VBLinear.lua:149-164) match float64 NumPy on the oracle's
+    update quantities."""
+    for dtype, hidden, I0, N in (("f32", [50, 34], 70, 37), ("bf16", [512, 256], 256, 512)):
+        opt, eng, onet = _engine_pair(oracle, "lrt", dtype, hidden, I0, True, S=1)
+        opt.update(OPT_STATES)
+        x = dev(oracle.fill_normal(N, I0, SEED, 4, 0, 0))
+        t = dev((np.arange(N) * 7 % 10).astype(np.int32))
+        eng.prepare()
+        for it in range(2):
+            eng.resetGradients(); eng.sample(); eng.run(x, t)
+            before = [(host(v.means).astype(np.float64), host(v.lvars).astype(np.float64), host(v.gradWeight).astype(np.float64),
+                       host(v.gradSum).astype(np.float64), float(host(v.stats)[2])) for v in eng.vb]
+            eng.update(opt, log=True)
+            torch.cuda.synchronize()
+            B = opt["B"]
+            for k, v in enumerate(eng.vb):                     # (3)
+                mu0, lv0, gmu, glv, vh = before[k]
+                mu1, lv1 = host(v.means).astype(np.float64), host(v.lvars).astype(np.float64)
+                mlc, vlc = mu0 / (B * vh), (np.exp(lv0) / vh - 1.0) / (2 * B)
+                mle, vle = gmu - mlc, glv - vlc
+                nl, nm = np.linalg.norm(lv1), np.linalg.norm(mu1)
+                var1 = np.exp(lv1)
+                want = [np.linalg.norm(vlc) / nl, np.linalg.norm(vle) / nl, np.linalg.norm(mlc) / nm, np.linalg.norm(mle) / nm,
+                        var1.min(), var1.max(), var1.mean(), vh, mu1.mean(), mu1.std(ddof=1), mu1.min(), mu1.max(),
+                        np.linalg.norm(mu1 - mu0) / nm, np.linalg.norm(lv1 - lv0) / nl]
+                got = host(eng.update_log[k])
+                np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-12, err_msg=f"{dtype} layer {k} step {it}")
+        got = [(v.mu_s.t.clone(), v.var_s.t.clone(), v.muT_s.t.clone() if v.muT_s is not None else None,
+                v.varT_s.t.clone() if v.varT_s is not None else None, v.stats.clone()) for v in eng.vb]
+        got_w3 = eng.w3_s.t.clone()
+        eng.resetGradients(); eng.sample(); eng.run(x, t)          # no prepare(): shadows + statistics from vbnn_update
+        g_a = eng.grads.clone()
+        eng.draw -= 1
+        eng.prepare()
+        torch.cuda.synchronize()
+        for v, (mu, var, muT, varT, st) in zip(eng.vb, got):       # (1)
+            assert torch.equal(mu, v.mu_s.t) and torch.equal(var, v.var_s.t)
+            if muT is not None and getattr(v, "use_muT", True):
+                assert torch.equal(muT, v.muT_s.t) and torch.equal(varT, v.varT_s.t)
+            np.testing.assert_allclose(host(st), host(v.stats), rtol=1e-12, atol=0)
+        assert torch.equal(got_w3, eng.w3_s.t)
+        eng.resetGradients(); eng.sample(); eng.run(x, t)
+        rel = float((eng.grads - g_a).norm() / g_a.norm())         # (2): bitwise unless the statistics moved in their last bit
+        assert rel <= 1e-7, rel
+
+
+def test_rccl_exchange_through_the_c_abi_one_rank(nnmod):
+    """vbnn_comm_* (RCCL bound with dlopen behind the C ABI) with a world of one -- all a one-GPU box can host: the
+    communicator comes up, an in-place SUM all-reduce of an arena-sized bucket leaves it unchanged, it is ordered after
+    the compute stream's producer and finish() orders the consumer after it, and the gather proves the rank count."""
+    from vbnn_amd.comm import RcclExchange
+    ctx = nnmod.Context.get()
+    ex = RcclExchange(ctx, 0, 1)
+    assert ex.backend == "vbnn_comm/rccl"
+    buf = torch.empty(6_000_000, dtype=torch.float32, device="cuda")
+    for rep in range(3):
+        buf.normal_()                                             # producer on the compute stream
+        want = buf.clone()
+        ex.allreduce(buf)
+        ex.finish()
+        got = buf * 1.0                                            # consumer on the compute stream
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    assert ex.gather_u64(0x1234567890ABCDEF) == [0x1234567890ABCDEF]
+    ex.close()
+
+
 # ------------------------------------------------------------------------------------------- errors
 def test_error_convention(nnmod):
     """Non-zero status + message instead of a crash (SURVEY 8b error convention)."""

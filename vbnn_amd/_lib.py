@@ -51,6 +51,17 @@ class PackDesc(C.Structure):          # vbnn_pack_desc
                 ("dstT", _vp), ("ld_dstT", _i64)]
 
 
+class AdamCfg(C.Structure):           # vbnn_adam_cfg
+    _fields_ = [("lr", _f), ("beta1", _f), ("beta2", _f), ("eps", _f), ("lambda_", _f), ("t", _i64)]
+
+
+class UpdateDesc(C.Structure):        # vbnn_update_desc
+    _fields_ = [("means", _vp), ("lvars", _vp), ("O", _i64), ("I", _i64), ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64),
+                ("muT_s", _vp), ("varT_s", _vp), ("ld_wT", _i64), ("stats", _vp), ("grad_mu", _vp), ("grad_lv", _vp),
+                ("m_mu", _vp), ("v_mu", _vp), ("m_lv", _vp), ("v_lv", _vp), ("mu", AdamCfg), ("lv", AdamCfg),
+                ("bias", _vp), ("grad_bias", _vp), ("lr_bias", _f), ("B", _f), ("log14", _vp)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [("xT", _vp), ("x2T", _vp), ("gT", _vp), ("gvT", _vp), ("ld_n", _i64),
                 ("N", _i64), ("I", _i64), ("O", _i64), ("scale", _f), ("accumulate", _i),
@@ -90,6 +101,14 @@ _SIGS = {
     "vbnn_pack_input": ([_vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64], _i),
     "vbnn_adam_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _vp], _i),
     "vbnn_sgd_step": ([_vp, _vp, _vp, _i64, _f], _i),
+    "vbnn_update": ([_vp, _i, _i, _vp, _vp], _i),
+    "vbnn_comm_unique_id": ([_vp], _i),
+    "vbnn_comm_create": ([_vp, _i, _i, _vp, C.POINTER(_vp)], _i),
+    "vbnn_comm_destroy": ([_vp], _i),
+    "vbnn_comm_info": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
+    "vbnn_allreduce_grads": ([_vp, _vp, _i64], _i),
+    "vbnn_comm_finish": ([_vp], _i),
+    "vbnn_comm_allgather_u64": ([_vp, _vp, _vp], _i),
     "vbnn_relu_forward": ([_vp, _vp, _vp, _i64], _i),
     "vbnn_relu_backward": ([_vp, _vp, _vp, _vp, _i64], _i),
     "vbnn_logsoftmax_nll": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp], _i),

@@ -1,0 +1,95 @@
+"""The data-parallel exchange of the fused engine: a SUM all-reduce of each layer's gradient bucket.
+
+Two transports behind one small interface (allreduce / finish / sync_finish):
+
+  RcclExchange   the product path: RCCL driven through the C ABI (include/vbnn_hip.h: vbnn_comm_create /
+                 vbnn_allreduce_grads / vbnn_comm_finish) -- the calls a LuaJIT host makes too (lua/FusedMLP.lua).
+                 torch.distributed is used ONLY as the out-of-band channel that hands rank 0's RCCL unique id to the
+                 other ranks (a file or a socket would do as well).
+  TorchExchange  torch.distributed.all_reduce on the default (or a given) process group: the rehearsal transport
+                 (gloo: several ranks sharing one GPU, CPU tests) and the fall-back if librccl cannot be bound --
+                 which the bench line reports, it is never silent.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib as L
+
+
+class TorchExchange:
+    def __init__(self, process_group=None, why=""):
+        import torch.distributed as dist
+        self.dist, self.pg, self.works = dist, process_group, []
+        self.backend = f"torch.distributed/{dist.get_backend(process_group)}" + (f" ({why})" if why else "")
+
+    def allreduce(self, bucket):
+        self.works.append(self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+class RcclExchange:
+    """vbnn_comm over RCCL. `process_group` (any backend) only carries the 128-byte unique id."""
+
+    def __init__(self, ctx, rank, world, process_group=None):
+        lib = L.lib()
+        self.ctx, self.rank, self.world = ctx, rank, world
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            L.check(lib.vbnn_comm_unique_id(uid))
+        if world > 1:
+            import torch.distributed as dist
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0, group=process_group)
+            uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        L.check(lib.vbnn_comm_create(ctx.h, rank, world, uid, C.byref(h)))
+        self.h = h
+        n = C.c_int()
+        L.check(lib.vbnn_comm_info(h, None, None, C.byref(n)))
+        assert n.value == world, (n.value, world)
+        self.backend = "vbnn_comm/rccl"
+
+    def allreduce(self, bucket):
+        assert bucket.dtype == torch.float32 and bucket.is_contiguous()
+        L.check(L.lib().vbnn_allreduce_grads(self.h, C.c_void_p(bucket.data_ptr()), bucket.numel()))
+
+    def finish(self):
+        L.check(L.lib().vbnn_comm_finish(self.h))
+
+    def gather_u64(self, value):
+        """Every rank's 64-bit word, exchanged over the communicator itself (bench.py: ranks_seen)."""
+        dev = self.ctx.device
+        mine = torch.tensor([value], dtype=torch.int64, device=dev)
+        out = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        L.check(L.lib().vbnn_comm_allgather_u64(self.h, C.c_void_p(mine.data_ptr()), C.c_void_p(out.data_ptr())))
+        self.finish()
+        torch.cuda.synchronize(dev)
+        return [int(v) for v in out.tolist()]
+
+    def close(self):
+        if self.h:
+            L.check(L.lib().vbnn_comm_destroy(self.h))
+            self.h = None
+
+
+def make_exchange(ctx, rank, world, process_group=None):
+    """RCCL through the C ABI unless VBNN_EXCHANGE=torch (or the torch backend is not nccl: a gloo rehearsal has no
+    device per rank for RCCL); a failure to bind librccl falls back to torch.distributed and says so."""
+    import torch.distributed as dist
+    want = os.environ.get("VBNN_EXCHANGE", "")
+    if want == "torch":
+        return TorchExchange(process_group, "VBNN_EXCHANGE=torch")
+    if dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) != "nccl" and want != "rccl":
+        return TorchExchange(process_group)
+    try:
+        return RcclExchange(ctx, rank, world, process_group)
+    except (L.VbnnError, OSError, AssertionError) as e:
+        if not (dist.is_available() and dist.is_initialized()):
+            raise
+        return TorchExchange(process_group, f"vbnn_comm unavailable: {e}")

@@ -686,6 +686,255 @@ extern "C" int vbnn_prepare(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_p
     VBNN_API_END
 }
 
+// ---------------------------------------------------------------------------------- update (+ next step's sweep)
+// VBLinear:update for one layer as ONE sweep (vbnn_update): Adam on means and lvars from the total gradients, the new
+// parameters' GEMM shadows (+ transposes) and prior sums, and the sums behind the 14 logged series -- 32 B read +
+// 24 B (+ 4..8 B of shadows) written per weight, HBM-bound. Tiling of k_prep_layer.
+constexpr int UPD_NSUM = 16;      // per-block partials: 12 sums, then min / max of the new variances and of the new means
+struct UpdLayer {
+    float* means; float* lvars; int64_t O, I;
+    void* mu_s; void* var_s; int64_t ld_w; void* muT_s; void* varT_s; int64_t ld_wT;
+    const double* stats;
+    const float* g_mu; const float* g_lv; float* m_mu; float* v_mu; float* m_lv; float* v_lv;
+    float b1_mu, b2_mu, eps_mu, step_mu, b1_lv, b2_lv, eps_lv, step_lv, B;
+    double* partial;
+};
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+// reduces the 16 per-thread values over the block's 256 threads (sums, 2 x (min, max)); thread 0 writes them
+__device__ __forceinline__ void upd_block_reduce(double (&a)[UPD_NSUM], double* out, double (*sh)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < UPD_NSUM; ++k) {
+        const double r = (k < 12) ? wave_sum(a[k]) : ((k & 1) ? wave_max(a[k]) : wave_min(a[k]));
+        if (lane == 0) sh[k][wave] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < UPD_NSUM) {
+        const int k = threadIdx.x;
+        const double* v = sh[k];
+        out[k] = (k < 12) ? v[0] + v[1] + v[2] + v[3] : ((k & 1) ? fmax(fmax(v[0], v[1]), fmax(v[2], v[3])) : fmin(fmin(v[0], v[1]), fmin(v[2], v[3])));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_vb_update(UpdLayer a) {
+    __shared__ float tm[64][65];
+    __shared__ float tv[64][65];
+    __shared__ double sh[UPD_NSUM][4];
+    const int64_t O = a.O, I = a.I;
+    const int64_t tiles_c = (I + 63) / 64, tiles_r = (O + 63) / 64;
+    const int64_t ntiles = tiles_c * tiles_r;
+    T* mu_s = (T*)a.mu_s; T* var_s = (T*)a.var_s; T* muT_s = (T*)a.muT_s; T* varT_s = (T*)a.varT_s;
+    const bool vec_in = ((I & 3) == 0) && ((((uintptr_t)a.means | (uintptr_t)a.lvars | (uintptr_t)a.g_mu | (uintptr_t)a.g_lv |
+                                             (uintptr_t)a.m_mu | (uintptr_t)a.v_mu | (uintptr_t)a.m_lv | (uintptr_t)a.v_lv) & 15u) == 0);
+    const bool vec_t = muT_s && ((a.ld_wT & 3) == 0);
+    // the KL parts of the logged norms, from the pre-update parameters and statistics (VBLinear.lua:91,96)
+    const float var_hat = (float)a.stats[2];
+    const float k_mu = 1.0f / (a.B * var_hat), k_lv = 1.0f / (2.0f * a.B), inv_vh = 1.0f / var_hat;
+    double acc[UPD_NSUM];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    acc[12] = acc[14] = 1e300; acc[13] = acc[15] = -1e300;
+    for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
+        const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            const int rr = idx >> 4, c4 = (idx & 15) * 4;
+            const int64_t r = r0 + rr, c = c0 + c4;
+            float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
+            const int valid = (r < O) ? (int)min((int64_t)4, I - c) : 0;
+            if (valid > 0) {
+                const int64_t base = r * I + c;
+                float l[4], gm[4], gl[4], mm[4], vm[4], ml[4], vl[4];
+                load4<float>(a.means + base, m, valid, vec_in);
+                load4<float>(a.lvars + base, l, valid, vec_in);
+                load4<float>(a.g_mu + base, gm, valid, vec_in);
+                load4<float>(a.g_lv + base, gl, valid, vec_in);
+                load4<float>(a.m_mu + base, mm, valid, vec_in);
+                load4<float>(a.v_mu + base, vm, valid, vec_in);
+                load4<float>(a.m_lv + base, ml, valid, vec_in);
+                load4<float>(a.v_lv + base, vl, valid, vec_in);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < valid) {
+                        // the two parts of each total gradient (logging only)
+                        const float mlc = k_mu * m[e], vlc = k_lv * fmaf(expf(l[e]), inv_vh, -1.0f);
+                        const float mle = gm[e] - mlc, vle = gl[e] - vlc;
+                        acc[6] += (double)mlc * mlc; acc[7] += (double)mle * mle;
+                        acc[8] += (double)vlc * vlc; acc[9] += (double)vle * vle;
+                        // optim.adam, the arithmetic of k_adam (optim.hip)
+                        mm[e] = a.b1_mu * mm[e] + (1.0f - a.b1_mu) * gm[e];
+                        vm[e] = a.b2_mu * vm[e] + (1.0f - a.b2_mu) * gm[e] * gm[e];
+                        const float um = a.step_mu * mm[e] / (sqrtf(vm[e]) + a.eps_mu);
+                        m[e] -= um;
+                        ml[e] = a.b1_lv * ml[e] + (1.0f - a.b1_lv) * gl[e];
+                        vl[e] = a.b2_lv * vl[e] + (1.0f - a.b2_lv) * gl[e] * gl[e];
+                        const float ul = a.step_lv * ml[e] / (sqrtf(vl[e]) + a.eps_lv);
+                        l[e] -= ul;
+                        v[e] = expf(l[e]);
+                        acc[0] += (double)(v[e] + m[e] * m[e]); acc[1] += (double)l[e];
+                        acc[2] += (double)um * um; acc[3] += (double)m[e] * m[e];
+                        acc[4] += (double)ul * ul; acc[5] += (double)l[e] * l[e];
+                        acc[10] += (double)v[e]; acc[11] += (double)m[e];
+                        acc[12] = fmin(acc[12], (double)v[e]); acc[13] = fmax(acc[13], (double)v[e]);
+                        acc[14] = fmin(acc[14], (double)m[e]); acc[15] = fmax(acc[15], (double)m[e]);
+                    }
+                store4<float>(a.means + base, m[0], m[1], m[2], m[3], valid, vec_in);
+                store4<float>(a.lvars + base, l[0], l[1], l[2], l[3], valid, vec_in);
+                store4<float>(a.m_mu + base, mm[0], mm[1], mm[2], mm[3], valid, vec_in);
+                store4<float>(a.v_mu + base, vm[0], vm[1], vm[2], vm[3], valid, vec_in);
+                store4<float>(a.m_lv + base, ml[0], ml[1], ml[2], ml[3], valid, vec_in);
+                store4<float>(a.v_lv + base, vl[0], vl[1], vl[2], vl[3], valid, vec_in);
+                store4<T>(mu_s + r * a.ld_w + c, m[0], m[1], m[2], m[3], valid, true);
+                store4<T>(var_s + r * a.ld_w + c, v[0], v[1], v[2], v[3], valid, true);
+            }
+            if (muT_s) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tm[rr][c4 + e] = m[e]; tv[rr][c4 + e] = v[e]; }
+            }
+        }
+        if (muT_s) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = threadIdx.x + 256 * k;
+                const int cc = idx >> 4, r4 = (idx & 15) * 4;
+                const int64_t c = c0 + cc, r = r0 + r4;
+                const int valid = (c < I) ? (int)min((int64_t)4, O - r) : 0;
+                if (valid > 0) {
+                    store4<T>(muT_s + c * a.ld_wT + r, tm[r4][cc], tm[r4 + 1][cc], tm[r4 + 2][cc], tm[r4 + 3][cc], valid, vec_t);
+                    store4<T>(varT_s + c * a.ld_wT + r, tv[r4][cc], tv[r4 + 1][cc], tv[r4 + 2][cc], tv[r4 + 3][cc], valid, vec_t);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    upd_block_reduce(acc, a.partial + (size_t)blockIdx.x * UPD_NSUM, sh);
+}
+
+struct UpdFinishArgs {
+    const double* partial[8]; int nb[8]; int64_t W[8]; double* stats[8]; double* log14[8];
+    float* bias[8]; const float* grad_bias[8]; int64_t O[8]; float lr_bias[8]; int n;
+    const float* src; int64_t rows, cols, ld_src; void* dst; int64_t ld_dst; void* dstT; int64_t ld_dstT;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_update_finish(UpdFinishArgs a) {
+    __shared__ double sh[UPD_NSUM][4];
+    if ((int)blockIdx.x < a.n) {
+        const int l = blockIdx.x;
+        double acc[UPD_NSUM];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+        acc[12] = acc[14] = 1e300; acc[13] = acc[15] = -1e300;
+        for (int b = threadIdx.x; b < a.nb[l]; b += 256) {
+            const double* p = a.partial[l] + (size_t)b * UPD_NSUM;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] += p[k];
+            acc[12] = fmin(acc[12], p[12]); acc[13] = fmax(acc[13], p[13]);
+            acc[14] = fmin(acc[14], p[14]); acc[15] = fmax(acc[15], p[15]);
+        }
+        __shared__ double tot[UPD_NSUM];
+        upd_block_reduce(acc, tot, sh);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double W = (double)a.W[l];
+            const double var_hat_old = a.stats[l][2];
+            if (a.log14[l]) {                                   // VBLinear.lua:149-164, in the order of the Log:add calls
+                double* g = a.log14[l];
+                const double nl = sqrt(tot[5]), nm = sqrt(tot[3]);
+                g[0] = sqrt(tot[8]) / nl; g[1] = sqrt(tot[9]) / nl; g[2] = sqrt(tot[6]) / nm; g[3] = sqrt(tot[7]) / nm;
+                g[4] = tot[12]; g[5] = tot[13]; g[6] = tot[10] / W; g[7] = var_hat_old;
+                const double mean = tot[11] / W;
+                g[8] = mean; g[9] = W > 1.0 ? sqrt(fmax(0.0, (tot[3] - W * mean * mean) / (W - 1.0))) : 0.0;
+                g[10] = tot[14]; g[11] = tot[15]; g[12] = sqrt(tot[2]) / nm; g[13] = sqrt(tot[4]) / nl;
+            }
+            double* st = a.stats[l];                            // as prior_finish, of the NEW parameters
+            st[0] = tot[0]; st[1] = tot[1]; st[2] = (1.0 / W) * tot[0]; st[3] = W;
+        }
+        if (a.bias[l])                                          // optim.sgd on the bias (VBLinear.lua:125-128)
+            for (int64_t o = threadIdx.x; o < a.O[l]; o += 256) a.bias[l][o] = fmaf(-a.lr_bias[l], a.grad_bias[l][o], a.bias[l][o]);
+        return;
+    }
+    T* dst = (T*)a.dst;
+    T* dstT = (T*)a.dstT;
+    const int64_t total = a.rows * a.cols;
+    for (int64_t t = (int64_t)(blockIdx.x - a.n) * 256 + threadIdx.x; t < total; t += (int64_t)(gridDim.x - a.n) * 256) {
+        const int64_t r = t / a.cols, c = t - r * a.cols;
+        const T v = Elt<T>::to(a.src[r * a.ld_src + c]);
+        if (dst) dst[r * a.ld_dst + c] = v;
+        if (dstT) dstT[c * a.ld_dstT + r] = v;
+    }
+}
+
+static inline float adam_step_size(const vbnn_adam_cfg& c, float* b1_out) {
+    const double b1t = (double)c.beta1 * pow((double)c.lambda, (double)(c.t - 1));       // as vbnn_adam_step
+    const double bc1 = 1.0 - pow((double)c.beta1, (double)c.t), bc2 = 1.0 - pow((double)c.beta2, (double)c.t);
+    *b1_out = (float)b1t;
+    return (float)((double)c.lr * sqrt(bc2) / bc1);
+}
+
+extern "C" int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && (layers || n_layers == 0), "null argument");
+    VBNN_REQUIRE(n_layers >= 0 && n_layers <= 8, "n_layers (0..8)");
+    VBNN_REQUIRE(dtype == VBNN_F32 || dtype == VBNN_BF16, "dtype");
+    constexpr int MAXB = 2048;
+    VBNN_REQUIRE((size_t)n_layers * MAXB * UPD_NSUM <= ctx->scratch_doubles, "scratch");
+    UpdFinishArgs fa{};
+    fa.n = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        const vbnn_update_desc& d = layers[l];
+        VBNN_REQUIRE(d.means && d.lvars && d.mu_s && d.var_s && d.stats, "null layer argument");
+        VBNN_REQUIRE(d.grad_mu && d.grad_lv && d.m_mu && d.v_mu && d.m_lv && d.v_lv, "null gradient / Adam state");
+        VBNN_REQUIRE((d.muT_s == nullptr) == (d.varT_s == nullptr), "muT_s and varT_s go together");
+        VBNN_REQUIRE(d.O > 0 && d.I > 0 && d.ld_w >= d.I && (!d.muT_s || d.ld_wT >= d.O), "layer shape");
+        VBNN_REQUIRE((d.bias == nullptr) == (d.grad_bias == nullptr), "bias and grad_bias go together");
+        VBNN_REQUIRE(d.B > 0, "B");
+        for (const vbnn_adam_cfg* c : {&d.mu, &d.lv})
+            VBNN_REQUIRE(c->t >= 1 && c->beta1 >= 0 && c->beta1 < 1 && c->beta2 >= 0 && c->beta2 < 1 && c->lr >= 0 && c->eps >= 0 &&
+                         c->lambda > 0 && c->lambda <= 1, "Adam hyper-parameters (t counts from 1)");
+        const int64_t ntiles = ((d.O + 63) / 64) * ((d.I + 63) / 64);
+        const int nb = (int)(ntiles < MAXB ? ntiles : MAXB);
+        UpdLayer a{};
+        a.means = d.means; a.lvars = d.lvars; a.O = d.O; a.I = d.I;
+        a.mu_s = d.mu_s; a.var_s = d.var_s; a.ld_w = d.ld_w; a.muT_s = d.muT_s; a.varT_s = d.varT_s; a.ld_wT = d.ld_wT;
+        a.stats = d.stats; a.g_mu = d.grad_mu; a.g_lv = d.grad_lv;
+        a.m_mu = d.m_mu; a.v_mu = d.v_mu; a.m_lv = d.m_lv; a.v_lv = d.v_lv;
+        a.step_mu = adam_step_size(d.mu, &a.b1_mu); a.b2_mu = d.mu.beta2; a.eps_mu = d.mu.eps;
+        a.step_lv = adam_step_size(d.lv, &a.b1_lv); a.b2_lv = d.lv.beta2; a.eps_lv = d.lv.eps;
+        a.B = d.B;
+        a.partial = ctx->scratch + (size_t)l * MAXB * UPD_NSUM;
+        if (dtype == VBNN_F32) hipLaunchKernelGGL(k_vb_update<float>, dim3(nb), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_vb_update<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, a);
+        fa.partial[l] = a.partial; fa.nb[l] = nb; fa.W[l] = d.O * d.I; fa.stats[l] = d.stats; fa.log14[l] = d.log14;
+        fa.bias[l] = d.bias; fa.grad_bias[l] = d.grad_bias; fa.O[l] = d.O; fa.lr_bias[l] = d.lr_bias;
+    }
+    int pack_blocks = 0;
+    if (extra) {
+        VBNN_REQUIRE(extra->src && extra->rows > 0 && extra->cols > 0 && extra->ld_src >= extra->cols, "extra matrix");
+        VBNN_REQUIRE(!extra->dst || extra->ld_dst >= extra->cols, "extra ld_dst");
+        VBNN_REQUIRE(!extra->dstT || extra->ld_dstT >= extra->rows, "extra ld_dstT");
+        fa.src = extra->src; fa.rows = extra->rows; fa.cols = extra->cols; fa.ld_src = extra->ld_src;
+        fa.dst = extra->dst; fa.ld_dst = extra->ld_dst; fa.dstT = extra->dstT; fa.ld_dstT = extra->ld_dstT;
+        pack_blocks = grid_for(extra->rows * extra->cols, 1024);
+    }
+    if (n_layers + pack_blocks > 0) {
+        if (dtype == VBNN_F32) hipLaunchKernelGGL(k_update_finish<float>, dim3(n_layers + pack_blocks), dim3(256), 0, ctx->stream, fa);
+        else hipLaunchKernelGGL(k_update_finish<bf16_t>, dim3(n_layers + pack_blocks), dim3(256), 0, ctx->stream, fa);
+    }
+    return vbnn_check_launch("vbnn_update");
+    VBNN_API_END
+}
+
 // ---------------------------------------------------------------------------------- pack_input
 // The minibatch as GEMM operands in one pass: x, x.x (of the ROUNDED x, as every epilogue produces it) and both
 // transposes. Same tiling as k_prep_layer: 4 elements per thread, LDS transpose.

@@ -16,6 +16,7 @@ import math
 import torch
 
 from . import _lib as L
+from . import partition
 from .nn import Context, _DT, _Packed, _p, fill_normal
 
 
@@ -35,6 +36,7 @@ class FusedMLP:
         self.seed = int(opt.get("seed", 3))
         self.world, self.rank, self.pg = world_size, rank, process_group
         self.reduce = world_size > 1 or force_reduce
+        self._exchange = None                 # made on first use (vbnn_amd/comm.py): RCCL through the C ABI
         self.fuse_kl = bool(opt.get("fuse_kl", True))
         # optional second HIP stream (+ its own context, hence its own reduction scratch) for the accGradParameters
         # GEMMs. Measured on MI355X (wide config): 1.32 ms with, 1.29 ms without -- two 512-block GEMMs sharing the
@@ -50,17 +52,12 @@ class FusedMLP:
         self.sizes = sizes
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
-        # ---- gradient arena: [gradWeight | gradSum | gradBias] per VB layer, then the final Linear
-        n_g = sum(2 * sizes[i] * sizes[i + 1] + sizes[i + 1] for i in range(len(hidden)))
-        n_g += sizes[-1] * self.n_classes + self.n_classes
+        # ---- gradient arena: [gradWeight | gradSum | gradBias] per VB layer, then the final Linear (partition.arena_layout)
+        lay, fin, n_g, self._bucket_ranges = partition.arena_layout(sizes, self.n_classes)
         self.grads = torch.zeros(n_g, **f32)
-        off = 0
 
-        def take(n, shape):
-            nonlocal off
-            v = self.grads[off:off + n].view(*shape)
-            off += n
-            return v
+        def take(span, shape):
+            return self.grads[span[0]:span[0] + span[1]].view(*shape)
 
         var_init = opt["var_init"] if not opt.get("msr_init") else None
         self.vb = []
@@ -73,13 +70,12 @@ class FusedMLP:
             v.lvars = torch.full((O, I), math.log(v.var_init), **f32)              # :18
             v.bias = torch.zeros(O, **f32)                                         # :13
             v.weight = torch.zeros(O, I, **f32) if self.mode == "wn" else None
-            start = off
             # with fuse_kl the first two blocks hold the TOTAL gradients d/dmeans, d/dlvars
             # (likelihood / S + KL, VBLinear.lua:90-98); otherwise the reference's gradWeight / gradSum
-            v.gradWeight = take(O * I, (O, I))
-            v.gradSum = take(O * I, (O, I))
-            v.gradBias = take(O, (O,))
-            v.bucket = self.grads[start:off]
+            v.gradWeight = take(lay[li]["mu"], (O, I))
+            v.gradSum = take(lay[li]["lv"], (O, I))
+            v.gradBias = take(lay[li]["bias"], (O,))
+            v.bucket = self.grads[lay[li]["bucket"][0]:lay[li]["bucket"][1]]
             v.stats = torch.zeros(4, dtype=torch.float64, device=dev)
             v.mu_s, v.var_s = _Packed(O, I, self.tdt, dev), _Packed(O, I, self.tdt, dev)
             if li > 0:
@@ -90,13 +86,12 @@ class FusedMLP:
         H = sizes[-1]
         self.weight3 = torch.zeros(self.n_classes, H, **f32)
         self.bias3 = torch.zeros(self.n_classes, **f32)
-        start = off
-        self.gradWeight3 = take(self.n_classes * H, (self.n_classes, H))
-        self.gradBias3 = take(self.n_classes, (self.n_classes,))
-        self.bucket3 = self.grads[start:off]
+        self.gradWeight3 = take(fin["weight"], (self.n_classes, H))
+        self.gradBias3 = take(fin["bias"], (self.n_classes,))
+        self.bucket3 = self.grads[fin["bucket"][0]:fin["bucket"][1]]
         # the final Linear's gradients sit right behind the last VB layer's in the arena: ONE all-reduce covers both (the
         # head's backward finishes before that layer's accGradParameters is even launched), a collective fewer per step
-        self.bucket_tail = self.grads[off - self.bucket3.numel() - self.vb[-1].bucket.numel():off]
+        self.bucket_tail = self.grads[lay[-1]["bucket"][0]:fin["bucket"][1]]
         self.w3_s = _Packed(self.n_classes, H, self.tdt, dev)
         self.w3T_s = _Packed(H, self.n_classes, self.tdt, dev)
         self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -106,7 +101,6 @@ class FusedMLP:
         self._map = False
         self._first = True
         self._N = None
-        self._works = []
         self.init_parameters()
 
     # mlp.lua:47-55 (He rule for every weight, bias zero) + the bench's non-degenerate means
@@ -324,7 +318,7 @@ class FusedMLP:
             d.gradWeight, d.gradSum = None, None
             d.grad_mu, d.grad_lv = _p(v.gradWeight), _p(v.gradSum)
             d.means, d.stats = _p(v.means), _p(v.stats)
-            d.B, d.S, d.kl_scale = self.B, self.S, 1.0 / self.world
+            d.B, d.S, d.kl_scale = self.B, self.S, partition.scales(1, self.world)["kl_scale"]
         else:
             d.gradWeight, d.gradSum = _p(v.gradWeight), _p(v.gradSum)
         d.gradBias = _p(v.gradBias) if v.bias_from_dw else None
@@ -353,7 +347,7 @@ class FusedMLP:
             row0 = self.rank * N
         lrt = self._lrt()
         accumulate = 0 if self._first else 1
-        inv_n = 1.0 / (N * self.world)
+        inv_n = partition.scales(N, self.world)["inv_n"]
         v0 = self.vb[0]
         L.check(lib.vbnn_pack_input(ctx, code, _p(x), x.stride(0), N, v0.I, v0.x_s.ptr, v0.x2_s.ptr if lrt else None,
                                     v0.x_s.ld, v0.xT_s.ptr if v0.xT_s else None,
@@ -412,8 +406,11 @@ class FusedMLP:
                 L.check(lib.vbnn_acc_grad_parameters(ctx2, code, C.byref(d)))
                 if not (fused_head and li == nl - 1) and not v.bias_from_dw:
                     L.check(lib.vbnn_acc_grad_bias(ctx2, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
-                with torch.cuda.stream(side):
-                    self._reduce(self.bucket_tail if li == nl - 1 else v.bucket)   # RCCL orders itself after the side stream
+                if self.reduce:                              # the exchange orders itself behind the MAIN stream: bring the
+                    filled = torch.cuda.Event()              # side stream's accGradParameters in front of it first
+                    filled.record(side)
+                    main.wait_event(filled)
+                    self._reduce(self.bucket_tail if li == nl - 1 else v.bucket)
                 if li > 0:
                     dx = self._dx_args(li, N)
                     L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
@@ -427,19 +424,60 @@ class FusedMLP:
     # already divides by the GLOBAL batch and the KL gradient carries 1/world, so the sum is the result.
     def _reduce(self, bucket):
         if self.reduce:
-            import torch.distributed as dist
-            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self.exchange().allreduce(bucket)
+
+    def exchange(self):
+        if self._exchange is None:
+            from .comm import make_exchange
+            self._exchange = make_exchange(self.ctx, self.rank, self.world, self.pg)
+        return self._exchange
+
+    def comm_backend(self):
+        return self.exchange().backend if self.reduce else "none"
 
     def finish(self):
-        """Wait for the outstanding all-reduces (end of the step)."""
-        for w in self._works:
-            w.wait()
-        self._works = []
+        """Order the compute stream behind the outstanding all-reduces (end of the step)."""
+        if self._exchange is not None:
+            self._exchange.finish()
+
+    def buckets(self):
+        """The all-reduce messages of one step, in issue order (last VB layer + final Linear first)."""
+        return [self.grads[s:e] for s, e in self._bucket_ranges]
+
+    def time_buckets(self, reps=5):
+        """Each bucket's all-reduce alone on an otherwise idle GPU: milliseconds (host clock around reps exchanges,
+        device-synchronised), algorithm GB/s and bus GB/s (x 2 (world - 1) / world). Collective: every rank calls it."""
+        import time
+        out = []
+        for b in self.buckets():
+            scratch = torch.zeros_like(b)
+            for _ in range(2):
+                self.exchange().allreduce(scratch); self.finish()
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.exchange().allreduce(scratch)
+            self.finish()
+            torch.cuda.synchronize(self.device)
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            nbytes = b.numel() * 4
+            alg = nbytes / (ms * 1e-3) / 1e9
+            out.append({"bytes": nbytes, "ms": round(ms, 4), "alg_GBps": round(alg, 1),
+                        "bus_GBps": round(alg * 2 * (self.world - 1) / max(self.world, 1), 1)})
+        return out
+
+    def synthetic_targets(self, x, row0=0):
+        """bench / tests: class targets uniform in 0..n_classes-1 by GLOBAL row (data.lua:16 convention, 0-based)."""
+        N = x.shape[0]
+        return ((torch.arange(N, device=x.device, dtype=torch.int64) + row0) * 2654435761 % self.n_classes).to(torch.int32)
 
     # ---- mlp:update + VBLinear:update (mlp.lua:117-142, VBLinear.lua:124-166) on the device: the dW epilogue
-    # already produced the TOTAL gradients (likelihood / S + KL), so the update is one Adam pass per parameter
-    # tensor; nothing is downloaded. Needs fuse_kl (otherwise use vbnn_amd/mlp.py's module-level update).
-    def update(self, opt=None):
+    # already produced the TOTAL gradients (likelihood / S + KL), so the update is ONE sweep per layer (vbnn_update):
+    # SGD on the bias, Adam on means and lvars, and -- from the new parameters, in the same pass -- the GEMM shadows
+    # and prior statistics of the next minibatch (the reference's update calls compute_prior too, :130). Nothing is
+    # downloaded. Needs fuse_kl (otherwise use vbnn_amd/mlp.py's module-level update). `log` = True also produces the
+    # 14 series of VBLinear.lua:149-164 per layer (self.update_log, a device tensor [layers][14]).
+    def update(self, opt=None, log=False):
         if not self.fuse_kl:
             raise RuntimeError("FusedMLP.update needs opt.fuse_kl = True (total gradients from the dW epilogue)")
         opt = opt or self.opt
@@ -447,19 +485,48 @@ class FusedMLP:
         lib, h = L.lib(), self.ctx.h
         lr = float(opt["state"]["learningRate"])
         st = self.__dict__.setdefault("_opt_state", {})
-        for v in self.vb:
-            L.check(lib.vbnn_sgd_step(h, _p(v.bias), _p(v.gradBias), v.O, lr))
-            for key, x, g, cfg in (("mean", v.means, v.gradWeight, opt["meanState"]), ("var", v.lvars, v.gradSum, opt["varState"])):
+        if log and getattr(self, "update_log", None) is None:
+            self.update_log = torch.zeros(len(self.vb), 14, dtype=torch.float64, device=self.device)
+        L.check(lib.vbnn_sgd_step(h, _p(self.weight3), _p(self.gradWeight3), self.weight3.numel(), lr))
+        L.check(lib.vbnn_sgd_step(h, _p(self.bias3), _p(self.gradBias3), self.bias3.numel(), lr))
+        if self.mode != "lrt":
+            # weight-noise mode keeps no parameter shadows between minibatches (sample() packs the drawn weights):
+            # per-tensor Adam, then the statistics
+            for v in self.vb:
+                L.check(lib.vbnn_sgd_step(h, _p(v.bias), _p(v.gradBias), v.O, lr))
+                for key, x, g, cfg in (("mean", v.means, v.gradWeight, opt["meanState"]), ("var", v.lvars, v.gradSum, opt["varState"])):
+                    s = st.setdefault((v.layer_id, key), {"t": 0})
+                    if "m" not in s:
+                        s["m"], s["v"] = torch.zeros_like(x), torch.zeros_like(x)
+                    s["t"] += 1
+                    L.check(lib.vbnn_adam_step(h, _p(x), _p(g), None, _p(s["m"]), _p(s["v"]), x.numel(),
+                                               float(cfg["learningRate"]), float(cfg.get("beta1", 0.9)),
+                                               float(cfg.get("beta2", 0.999)), float(cfg.get("epsilon", 1e-8)),
+                                               float(cfg.get("lambda", 1.0)), s["t"], None))
+            self.prepare()
+            return
+        descs = (L.UpdateDesc * len(self.vb))()
+        for k, v in enumerate(self.vb):
+            cfgs = []
+            for key, x, cfg in (("mean", v.means, opt["meanState"]), ("var", v.lvars, opt["varState"])):
                 s = st.setdefault((v.layer_id, key), {"t": 0})
                 if "m" not in s:
                     s["m"], s["v"] = torch.zeros_like(x), torch.zeros_like(x)
                 s["t"] += 1
-                L.check(lib.vbnn_adam_step(h, _p(x), _p(g), None, _p(s["m"]), _p(s["v"]), x.numel(),
-                                           float(cfg["learningRate"]), float(cfg.get("beta1", 0.9)),
-                                           float(cfg.get("beta2", 0.999)), float(cfg.get("epsilon", 1e-8)),
-                                           float(cfg.get("lambda", 1.0)), s["t"], None))
-        L.check(lib.vbnn_sgd_step(h, _p(self.weight3), _p(self.gradWeight3), self.weight3.numel(), lr))
-        L.check(lib.vbnn_sgd_step(h, _p(self.bias3), _p(self.gradBias3), self.bias3.numel(), lr))
+                cfgs.append((s, L.AdamCfg(lr=float(cfg["learningRate"]), beta1=float(cfg.get("beta1", 0.9)),
+                                          beta2=float(cfg.get("beta2", 0.999)), eps=float(cfg.get("epsilon", 1e-8)),
+                                          lambda_=float(cfg.get("lambda", 1.0)), t=s["t"])))
+            (sm, cm), (sv, cv) = cfgs
+            use_t = v.muT_s is not None and getattr(v, "use_muT", True)
+            descs[k] = L.UpdateDesc(means=_p(v.means), lvars=_p(v.lvars), O=v.O, I=v.I, mu_s=v.mu_s.ptr, var_s=v.var_s.ptr,
+                                    ld_w=v.mu_s.ld, muT_s=v.muT_s.ptr if use_t else None, varT_s=v.varT_s.ptr if use_t else None,
+                                    ld_wT=v.muT_s.ld if v.muT_s else 0, stats=_p(v.stats), grad_mu=_p(v.gradWeight),
+                                    grad_lv=_p(v.gradSum), m_mu=_p(sm["m"]), v_mu=_p(sm["v"]), m_lv=_p(sv["m"]), v_lv=_p(sv["v"]),
+                                    mu=cm, lv=cv, bias=_p(v.bias), grad_bias=_p(v.gradBias), lr_bias=lr, B=self.B,
+                                    log14=C.c_void_p(self.update_log[k].data_ptr()) if log else None)
+        w3 = L.PackDesc(src=_p(self.weight3), rows=self.n_classes, cols=self.sizes[-1], ld_src=self.sizes[-1],
+                        dst=self.w3_s.ptr, ld_dst=self.w3_s.ld, dstT=self.w3T_s.ptr, ld_dstT=self.w3T_s.ld)
+        L.check(lib.vbnn_update(h, self.code, len(self.vb), descs, C.byref(w3)))
 
     # ---- reporting (each of these synchronises)
     def loss_and_accuracy(self):

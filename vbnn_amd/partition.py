@@ -1,0 +1,66 @@
+"""Host logic of the data-parallel recipe (no GPU, no torch needed): which rows a rank owns, how the criterion and the
+KL gradient are scaled so that a plain SUM over ranks IS the global gradient, and how the gradient arena is laid out
+and cut into all-reduce messages. vbnn_amd/engine.py computes with exactly these functions; tests/test_dist_cpu.py
+drives them with two gloo ranks on the CPU.
+
+The reference is single-device (main.lua:142 only sets BLAS threads); the rule it fixes is the objective:
+    (1 / N_global) sum_n NLL_n   (nn.ClassNLLCriterion, sizeAverage, mlp.lua:32)   +   KL / B   (VBLinear.lua:90-103)
+so with G ranks of N_local rows each: every rank's criterion divides by N_local * G, and every rank adds KL-gradient / G.
+"""
+
+
+def shard_rows(n_global, world, rank):
+    """Rank r owns global rows [r * N/G, (r + 1) * N/G): returns (row0, n_local). N must divide evenly (the bench's
+    weak scaling gives every rank the same row count by construction)."""
+    if n_global % world:
+        raise ValueError(f"global batch {n_global} does not divide over {world} ranks")
+    n_local = n_global // world
+    return rank * n_local, n_local
+
+
+def scales(n_local, world):
+    """inv_n: what the criterion multiplies each row's loss / gradient by; kl_scale: the weight of the KL gradient in
+    each rank's fused accGradParameters epilogue (vbnn_dw_args.kl_scale)."""
+    return {"inv_n": 1.0 / (n_local * world), "kl_scale": 1.0 / world}
+
+
+def arena_layout(sizes, n_classes):
+    """The flat fp32 gradient arena: per VB layer [d/dmeans (O x I) | d/dlvars (O x I) | d/dbias (O)], then the final
+    Linear [gradWeight (C x H) | gradBias (C)].
+    Returns (layers, final, total, buckets):
+      layers[k] = dict(I, O, mu=(off, n), lv=(off, n), bias=(off, n), bucket=(start, end))
+      final     = dict(weight=(off, n), bias=(off, n), bucket=(start, end))
+      buckets   = the all-reduce messages of a step as (start, end), in ISSUE order: backward runs last layer first, and
+                  the final Linear's gradients (adjacent in the arena, finished before the last VB layer's
+                  accGradParameters is launched) ride in that layer's message."""
+    off, layers = 0, []
+    for i in range(len(sizes) - 1):
+        I, O = sizes[i], sizes[i + 1]
+        start = off
+        d = {"I": I, "O": O, "mu": (off, O * I)}
+        off += O * I
+        d["lv"] = (off, O * I)
+        off += O * I
+        d["bias"] = (off, O)
+        off += O
+        d["bucket"] = (start, off)
+        layers.append(d)
+    H = sizes[-1]
+    start = off
+    final = {"weight": (off, n_classes * H)}
+    off += n_classes * H
+    final["bias"] = (off, n_classes)
+    off += n_classes
+    final["bucket"] = (start, off)
+    buckets = []
+    for k in range(len(layers) - 1, -1, -1):
+        s, e = layers[k]["bucket"]
+        buckets.append((s, final["bucket"][1]) if k == len(layers) - 1 else (s, e))
+    return layers, final, off, buckets
+
+
+def exchange_step(arena, buckets, exchange):
+    """Issue one step's all-reduces in order and complete them (what FusedMLP.run + finish do around the kernels)."""
+    for s, e in buckets:
+        exchange.allreduce(arena[s:e])
+    exchange.finish()
