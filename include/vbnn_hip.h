@@ -60,6 +60,8 @@ const char* vbnn_last_error(void);
 #define VBNN_DEBUG_V3_MIN_K 4      /* shortest K for which shape selection picks the two-pass 256 x 256 kernel (default 704) */
 #define VBNN_DEBUG_V2_PSPLIT 5     /* pipelined kernel pair split (the pair's two GEMMs in different workgroups, parameter
                                       gradients only): -1 = by shape (default), 0 = never, 1 = whenever possible */
+#define VBNN_DEBUG_V3_SPLIT 8      /* two-pass kernel's pair-split + split-K launch for few-tile parameter gradients: -1 = by shape (default), 0 = never, 1 = whenever possible */
+#define VBNN_DEBUG_FAKE_NOISE 7    /* TIMING ONLY, wrong results: 1 = the two-pass kernel's forward fold skips the Philox draw */
 #define VBNN_DEBUG_KMAJOR 6        /* K-major operands (gemm_v3.h AK / BK): 1 = use when the shape allows (default), 0 = never, 2 = gemm_v3 only */
 int vbnn_debug_set(int key, int value);
 
@@ -70,7 +72,10 @@ int vbnn_debug_set(int key, int value);
 int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K);
 /* The same question for accGradParameters of an I -> O layer on N rows, which has a second K-major form (the pair-split
  * launch for outputs with few tiles). bias_row = 1: the bias gradient is to come from the GEMM (vbnn_dw_args.gradBias),
- * K-major that means column I of x is all ones (and ld_x > I). */
+ * K-major that means column I of x is all ones (and ld_x > I). Returns 0 (no: pass xT / gT), 1 (yes) or 2: yes, on the
+ * two-pass kernel's pair-split + split-K launch, which reads x and x.x in whole 256-column tiles -- allocate them with
+ * ld_x >= the row length (ones column included) rounded up to a multiple of 256, zero filled past the data; with a
+ * smaller ld_x the call still works, on the slower launch. */
 int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
@@ -199,6 +204,11 @@ typedef struct vbnn_dw_args {
      * gradInput GEMMs hold them. When vbnn_kmajor_supported(I, O, N) says so the GEMM reads these (transpose reads in
      * LDS) and xT / x2T / gT / gvT may be NULL: no epilogue has to write transposed copies. Otherwise xT.. are used. */
     const void* x; const void* x2; const void* g; const void* gv; int64_t ld_x; int64_t ld_g;
+    /* optional (fused total gradients only, dtype BF16): the packed operand shadows mu_s, var_s = exp(lvars) (O x ld_w,
+     * as vbnn_prepare / vbnn_update leave them). When given, the epilogue reads mu and sigma^2 FROM THEM -- 4 B per weight
+     * instead of 8, and no exp -- i.e. d/dlvars = (gv^T x.x) . s2 + KL'(s2), d/dmeans = g^T x + KL'(mu) with s2, mu the
+     * values the forward GEMMs multiplied by (bf16-rounded); means / lvars are then not read. NULL: fp32 means / lvars. */
+    const void* mu_s; const void* var_s; int64_t ld_w;
 } vbnn_dw_args;
 
 /* accGradParameters (VBLinear.lua:112-118), one GEMM instead of the reference's two. */

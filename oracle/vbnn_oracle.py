@@ -354,11 +354,18 @@ class OracleMLP:
             m._map = False
             m.sample(self.opt)
 
-    def run(self, inputs, targets):                                      # mlp.lua:76-84
+    def run(self, inputs, targets, masks=None):                          # mlp.lua:76-84
+        """masks (tests only): per VB layer a boolean N x O array that REPLACES the ReLU's own `y > 0` in both
+        directions -- the on/off pattern another implementation took -- so that a comparison against reduced-precision
+        arithmetic measures rounding, not the discontinuity of the few units whose sign the rounding flipped."""
         acts = [inputs.reshape(inputs.shape[0], -1)]                     # nn.Reshape, mlp.lua:12
         pre = []
-        for m in self.vb:
+        for k, m in enumerate(self.vb):
             y = m.updateOutput(acts[-1])
+            if masks is not None:
+                pre.append(np.where(masks[k], np.float32(1), np.float32(-1)))     # relu_backward keys on pre > 0
+                acts.append(np.where(masks[k], y, np.float32(0)).astype(np.float32))
+                continue
             pre.append(y)
             acts.append(relu_forward(y))
         logits = self.last.updateOutput(acts[-1])

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""One steady-state step of bench.py out of a rocprofv3 --kernel-trace database (rocpd): every dispatch between two
+k_pack_input launches, with duration and the gap to its predecessor; plus the median span over the late steps.
+python tools/step_timeline.py <results.db> [step index from the end, default 8]"""
+import sqlite3, statistics, sys
+db = sqlite3.connect(sys.argv[1])
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+cur = db.cursor()
+tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+rows = list(cur.execute(f"select k.kernel_name, d.start, d.end, d.grid_size_x, d.workgroup_size_x from {disp} d join {sym} k on d.kernel_id=k.id order by d.start"))
+idx = [i for i, r in enumerate(rows) if "k_pack_input" in r[0]]
+if len(idx) < back + 2:
+    print("too few steps in the trace"); sys.exit(1)
+i0, i1 = idx[-back - 1], idx[-back]
+prev = None
+for r in rows[i0:i1]:
+    gap = (r[1] - prev) / 1e3 if prev else 0.0
+    print(f"{(r[2] - r[1]) / 1e3:8.1f} us  gap {gap:5.1f}  grid {r[3] // max(r[4], 1):5d} x {r[4]:4d}  {r[0][:96]}")
+    prev = r[2]
+print(f"step span {(rows[i1][1] - rows[i0][1]) / 1e3:.1f} us")
+spans = [(rows[idx[k + 1]][1] - rows[idx[k]][1]) / 1e3 for k in range(len(idx) - 21, len(idx) - 1)]
+print(f"median span of the last 20 steps: {statistics.median(spans):.1f} us (min {min(spans):.1f}, max {max(spans):.1f})")

@@ -131,7 +131,7 @@ struct EpiFwd {
     struct Pre { f32x4 b; };
     struct Lane { int nl, ml; unsigned oh, orr; };
     __host__ __device__ bool fast_ok() const {
-        return !y && !r && h && (ld_h % 4 == 0) && (!r_t || (r_vec && ld_r % 4 == 0)) &&
+        return !y && !r && h && (ld_h % 4 == 0) && (!r_t || (r_vec && ld_r % 8 == 0 && (((uintptr_t)r_t & 15u) == 0))) &&
                (!bias || (((uintptr_t)bias & 15u) == 0)) && (int64_t)N * ld_h < (1ll << 31) && (int64_t)N * ld_r < (1ll << 31);
     }
     __device__ __forceinline__ Lane lane_init(int nl, int ml) const {
@@ -179,6 +179,33 @@ struct EpiFwd {
     static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 1;          // m-blocks per batch of fold loads (only the bias here)
     static constexpr int FOLD_SERIAL = 1;         // a Philox block per quad: at most this many in flight (0 = no limit; 2 spills 24 registers and is no faster)
+    // FOLD_STAGE: the fold's own output (r, N x O in the operand type) leaves through a per-wave LDS tile as whole
+    // 128-byte row segments (gemm_v3.h) instead of one 8-byte store per lane straight from the MFMA layout -- 16 rows x
+    // 32 bytes per wave-instruction, which ran at 1.9 TB/s (lab: 18 of the fold's 37 us at 4096 x 4096 outputs).
+    static constexpr int FOLD_STAGE = 1;
+    typedef T fold_st_t;
+    __host__ __device__ __forceinline__ T* fold_st_ptr() const { return r_t; }
+    __host__ __device__ __forceinline__ int64_t fold_st_ld() const { return ld_r; }
+    __host__ __device__ __forceinline__ const float* fold_bias_ptr() const { return bias; }   // per-m addend of the fold, or NULL
+    __device__ __forceinline__ f32x4 fold_s(int um, int un, const Lane& ln, f32x4 v, const f32x4& b4, float (&rv)[4]) const {
+        vbnn_f32x4 z;
+        if (noise == 2) {                         // A/B only (vbnn_debug_set key 7): what the draw itself costs
+            const float f = (float)((um + ln.ml + un + ln.nl) & 7) * 0.25f - 0.875f;
+            z.v[0] = f; z.v[1] = -f; z.v[2] = 0.5f * f; z.v[3] = -0.5f * f;
+        } else {
+            z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        }
+        f32x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = v[j] > 0.f;
+            const float rs = __builtin_amdgcn_rsqf(v[j]);
+            const float sd = pos ? v[j] * rs : 0.f;
+            out[j] = fmaf(sd, z.v[j], b4[j]);
+            rv[j] = pos ? 0.5f * z.v[j] * rs : 0.f;
+        }
+        return out;
+    }
     struct FPre { f32x4 b; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         (void)un;
@@ -187,7 +214,13 @@ struct EpiFwd {
         return p;
     }
     __device__ __forceinline__ f32x4 fold(int um, int un, const Lane& ln, f32x4 v, const FPre& fp) const {
-        const vbnn_f32x4 z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        vbnn_f32x4 z;
+        if (noise == 2) {                         // A/B only (vbnn_debug_set key 7): what the draw itself costs
+            const float f = (float)((um + ln.ml + un + ln.nl) & 7) * 0.25f - 0.875f;
+            z.v[0] = f; z.v[1] = -f; z.v[2] = 0.5f * f; z.v[3] = -0.5f * f;
+        } else {
+            z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        }
         f32x4 out;
         float rv[4];
 #pragma unroll
@@ -220,6 +253,7 @@ struct EpiFwd {
     static constexpr bool PARK = true;
     static constexpr int FOLD_BATCH = 1;
     static constexpr int FOLD_SERIAL = 0;
+    static constexpr int FOLD_STAGE = 0;
     struct FPre { f32x4 b; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         (void)un;
@@ -338,6 +372,7 @@ struct EpiDx {
     static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 8;          // all 32 quads' x loads (64 registers) in flight together
     static constexpr int FOLD_SERIAL = 0;
+    static constexpr int FOLD_STAGE = 0;
     struct FPre { typename V4<T>::type x; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         FPre p;
@@ -377,6 +412,7 @@ struct EpiDw {
     float* grad_mu; float* grad_lv;
     const float* means; const double* stats; float B, S, kl_scale;
     float* gradBias;         // optional: the GEMM has one more A row (all ones) whose output row is the bias gradient
+    const bf16_t* mu_s; const bf16_t* var_s; int ld_w;    // optional bf16 shadows of means / exp(lvars): read instead of them
     int I, O;
     // d/dmeans depends on the first GEMM of the pair only and d/dlvars on the second only, so a kernel may compute the
     // two GEMMs in DIFFERENT workgroups (gemm_v2.h, pair split): part 1 = this workgroup holds the first GEMM (in a1)
@@ -423,7 +459,9 @@ struct EpiDw {
 #pragma unroll
             for (int j = 0; j < 4; ++j) e[j] = z.v[j];
         }
-        if (lvars && want_lv) {
+        if (var_s && want_lv && (grad_mu || grad_lv)) {
+            load4<bf16_t>(var_s + (int64_t)n * ld_w + m, var, valid, true);
+        } else if (lvars && want_lv) {
             float lv4[4];
             load4<float>(lvars + base, lv4, valid, vec);
 #pragma unroll
@@ -456,7 +494,8 @@ struct EpiDw {
             const float k_lv = kl_scale / (2.0f * B);               // d(KL/B)/dlvars  = (vars / var_hat - 1) / (2B)
             const float inv_vh = 1.0f / var_hat;
             float gm[4], gl[4], mu4[4] = {0.f, 0.f, 0.f, 0.f}, om4[4] = {0.f, 0.f, 0.f, 0.f}, ol4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (means && !accumulate && do_mu) load4<float>(means + base, mu4, valid, vec);
+            if (mu_s && !accumulate && do_mu) load4<bf16_t>(mu_s + (int64_t)n * ld_w + m, mu4, valid, true);
+            else if (means && !accumulate && do_mu) load4<float>(means + base, mu4, valid, vec);
             if (accumulate && grad_mu && do_mu) load4<float>(grad_mu + base, om4, valid, vec);
             if (accumulate && grad_lv && do_lv) load4<float>(grad_lv + base, ol4, valid, vec);
 #pragma unroll
@@ -478,19 +517,25 @@ struct EpiDw {
     }
 
     // ---- fast protocol: the fused total gradients of an LRT layer, first draw of the minibatch (the S = 1 step)
-    static constexpr int FAST_BATCH = 4;
-    struct Pre { f32x4 lv, mu; };
-    struct Lane { unsigned o; };
+    static constexpr int FAST_BATCH = 8;
+    struct Pre { bf16x4 lv, mu; };        // lv: sigma^2 itself (from the shadow); widened at use
+    struct Lane { unsigned o, os; };      // element offsets of the lane's quad in the O x I tensors / in the O x ld_w shadows
+    // The fast protocol reads mu and sigma^2 from the bf16 shadows ONLY (no runtime choice: a branch around a load makes
+    // hipcc wait for each load on its own, and the batches are the point of the protocol). Without shadows the guarded
+    // form above runs, on the fp32 parameters.
     __host__ __device__ bool fast_ok() const {
         return lrt && vec && !accumulate && grad_mu && grad_lv && means && lvars && !gradWeight && !gradSum &&
-               (int64_t)O * I < (1ll << 31);
+               (int64_t)O * I < (1ll << 31) && mu_s && var_s && ld_w % 4 == 0 && (int64_t)O * ld_w < (1ll << 31) &&
+               ((((uintptr_t)mu_s | (uintptr_t)var_s) & 7u) == 0);
     }
-    __device__ __forceinline__ Lane lane_init(int nl, int ml) const { return Lane{(unsigned)(nl * I + ml)}; }
+    __device__ __forceinline__ Lane lane_init(int nl, int ml) const { return Lane{(unsigned)(nl * I + ml), (unsigned)(nl * ld_w + ml)}; }
+    __device__ __forceinline__ bf16x4 shadow4(const bf16_t* p, int um, int un, const Lane& ln) const {
+        return *reinterpret_cast<const bf16x4*>(p + ((int64_t)un * ld_w + um) + ln.os);
+    }
     __device__ __forceinline__ Pre load_fast(int um, int un, const Lane& ln) const {
-        const int64_t ub = (int64_t)un * I + um;
         Pre p;
-        p.lv = part != 1 ? *reinterpret_cast<const f32x4*>(lvars + ub + ln.o) : f32x4{0.f, 0.f, 0.f, 0.f};
-        p.mu = part != 2 ? *reinterpret_cast<const f32x4*>(means + ub + ln.o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        p.lv = part != 1 ? shadow4(var_s, um, un, ln) : bf16x4{};
+        p.mu = part != 2 ? shadow4(mu_s, um, un, ln) : bf16x4{};
         return p;
     }
     __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre& pre, float (&t1)[4],
@@ -506,10 +551,10 @@ struct EpiDw {
         f32x4 gm, gl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float var = expf(pre.lv[j]);
+            const float var = (float)pre.lv[j];
             const float lm = scale * a1[j] * invS;
             const float ll = a2[j] * var * invS;
-            gm[j] = fmaf(k_mu, pre.mu[j], lm);
+            gm[j] = fmaf(k_mu, (float)pre.mu[j], lm);
             gl[j] = fmaf(k_lv, fmaf(var, inv_vh, -1.0f), ll);
         }
         if (part != 2) *reinterpret_cast<f32x4*>(grad_mu + ub + ln.o) = gm;
@@ -519,12 +564,13 @@ struct EpiDw {
     // ---- fold protocol: the two outputs depend on one accumulator each, so d/dlvars is FINISHED between the passes
     // (its stores drain under the second pass) and the second pass starts from zero
     static constexpr bool PARK = false;
-    static constexpr int FOLD_BATCH = 4;          // 16 quads' lvars loads (64 registers) in flight together
+    static constexpr int FOLD_BATCH = 8;          // all 32 quads' sigma^2 loads (64 registers) in flight together
     static constexpr int FOLD_SERIAL = 0;
-    struct FPre { f32x4 lv; };
+    static constexpr int FOLD_STAGE = 0;
+    struct FPre { bf16x4 lv; };
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         FPre p;
-        p.lv = *reinterpret_cast<const f32x4*>(lvars + ((int64_t)un * I + um) + ln.o);
+        p.lv = shadow4(var_s, um, un, ln);
         return p;
     }
     __device__ __forceinline__ f32x4 fold(int um, int un, const Lane& ln, f32x4 a2, const FPre& fp) const {
@@ -535,7 +581,7 @@ struct EpiDw {
         f32x4 gl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float var = expf(fp.lv[j]);
+            const float var = (float)fp.lv[j];
             gl[j] = fmaf(k_lv, fmaf(var, inv_vh, -1.0f), a2[j] * var * invS);
         }
         *reinterpret_cast<f32x4*>(grad_lv + ((int64_t)un * I + um) + ln.o) = gl;
@@ -543,8 +589,8 @@ struct EpiDw {
     }
     __device__ __forceinline__ Pre load_folded(int um, int un, const Lane& ln) const {
         Pre p;
-        p.mu = *reinterpret_cast<const f32x4*>(means + ((int64_t)un * I + um) + ln.o);
-        p.lv = f32x4{0.f, 0.f, 0.f, 0.f};
+        p.mu = shadow4(mu_s, um, un, ln);
+        p.lv = bf16x4{};
         return p;
     }
     __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre& pre, float (&t1)[4],
@@ -555,7 +601,7 @@ struct EpiDw {
         const float k_mu = kl_scale / (B * var_hat);
         f32x4 gm;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gm[j] = fmaf(k_mu, pre.mu[j], scale * a[j] * invS);
+        for (int j = 0; j < 4; ++j) gm[j] = fmaf(k_mu, (float)pre.mu[j], scale * a[j] * invS);
         *reinterpret_cast<f32x4*>(grad_mu + ((int64_t)un * I + um) + ln.o) = gm;
     }
 };

@@ -12,6 +12,7 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; 
 // Test / A-B hook: vbnn_debug_set(VBNN_DEBUG_GEMM_KERNEL, ..).
 static int g_force_kernel = 0;
 static int g_kmajor = 1;              // K-major operands when the shape allows (vbnn_debug_set key 6)
+static int g_fake_noise = 0;          // A/B only (key 7): the forward fold skips Philox + Box-Muller (wrong results, timing only)
 
 extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_GEMM_KERNEL && value >= 0 && value <= 3) { g_force_kernel = value; return VBNN_OK; }
@@ -21,6 +22,8 @@ extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_V3_MIN_K && value >= 64) { g_v3_min_k = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_PSPLIT && value >= -1 && value <= 1) { g_v2_psplit = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_KMAJOR && value >= 0 && value <= 2) { g_kmajor = value; return VBNN_OK; }   // 2: gemm_v3 only
+    if (key == VBNN_DEBUG_V3_SPLIT && value >= -1 && value <= 1) { g_v3_split = value; return VBNN_OK; }
+    if (key == VBNN_DEBUG_FAKE_NOISE && (value == 0 || value == 1)) { g_fake_noise = value; return VBNN_OK; }
     vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
     return VBNN_ERR_INVALID;
 }
@@ -40,8 +43,15 @@ static bool kmajor_dw_v2_selected(int64_t M, int64_t N, int64_t K) {
     return g_kmajor == 1 && K % V2_BK == 0 && (g_force_kernel == 0 || g_force_kernel == 2) && g_v2_tile != 128 && g_v2_tile != 64 &&
            g_v2_split != 1 && gemm_v2_eligible<bf16_t>(M, N, K, 64, 64) && gemm_v2_psplit_by_shape(M, N, K);
 }
+// 0: transposed copies needed; 1: K-major operands as the other GEMMs hold them; 2: K-major, and x / x.x must be allocated
+// with their row pitch padded to whole 256-column tiles (zero fill): the split launch of gemm_v3.h
+static bool kmajor_dw_v3_split_selected(int64_t M, int64_t N, int64_t K) {
+    return g_kmajor == 1 && g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_split_shape_ok(M, N, K) &&
+           K * gemm_v3_split_lda(M) < (1ll << 30) && K * (N + 64) < (1ll << 30);
+}
 extern "C" int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row) {
     if (!bias_row && kmajor_selected(I, O, N)) return 1;
+    if (I % 4 == 0 && kmajor_dw_v3_split_selected(I + (bias_row ? 1 : 0), O, N)) return 2;
     return kmajor_dw_v2_selected(I + (bias_row ? 1 : 0), O, N) ? 1 : 0;
 }
 
@@ -84,7 +94,7 @@ template <typename T>
 static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
     EpiFwd<T> e;
     e.bias = a->bias;
-    e.noise = a->w2 != nullptr;
+    e.noise = a->w2 != nullptr ? (g_fake_noise ? 2 : 1) : 0;
     e.seed = a->seed; e.layer = a->layer; e.draw = a->draw; e.row0 = a->row0;
     e.y = a->y; e.ld_y = a->ld_y; e.y_vec = a->y && aligned16(a->y) && (a->ld_y % 4 == 0);
     e.r = a->r_packed ? nullptr : (float*)a->r;
@@ -134,6 +144,9 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
     e.grad_mu = a->grad_mu; e.grad_lv = a->grad_lv;
     e.means = a->means; e.stats = a->stats; e.B = a->B; e.S = a->S; e.kl_scale = a->kl_scale;
     e.gradBias = a->gradBias;
+    const bool shadows = sizeof(T) == 2 && a->mu_s && a->var_s && (a->grad_mu || a->grad_lv) && a->ld_w >= a->I &&
+                         a->ld_w < (1ll << 31) / (a->O > 0 ? a->O : 1);
+    e.mu_s = shadows ? (const bf16_t*)a->mu_s : nullptr; e.var_s = shadows ? (const bf16_t*)a->var_s : nullptr; e.ld_w = shadows ? (int)a->ld_w : 0;
     e.I = (int)a->I; e.O = (int)a->O;
     const int64_t M = a->I + (a->gradBias ? 1 : 0);          // the ones row of xT (K-major: column I of x) rides along as one more output row
     const bool dual = e.lrt != 0;
@@ -142,6 +155,13 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
         (dual ? try_kmajor<T, true, true, true>(ctx, a->x, a->x2, a->ld_x, a->g, a->gv, a->ld_g, a->I, a->O, a->N, e, &st)
               : try_kmajor<T, false, true, true>(ctx, a->x, nullptr, a->ld_x, a->g, nullptr, a->ld_g, a->I, a->O, a->N, e, &st)))
         return st;
+    if constexpr (sizeof(T) == 2) {                          // ... or, for outputs with few tiles, pair split + split-K on gemm_v3
+        if (dual && a->x && a->x2 && a->g && a->gv && a->I % 4 == 0 && kmajor_dw_v3_split_selected(M, a->O, a->N)) {
+            st = launch_gemm_v3_split<T, EpiDw>(ctx, (const T*)a->x, (const T*)a->x2, a->ld_x, (const T*)a->g, (const T*)a->gv, a->ld_g,
+                                                (int)M, (int)a->O, (int)a->N, e);
+            if (st != VBNN_ERR_UNSUPPORTED) return st;
+        }
+    }
     if constexpr (sizeof(T) == 2) {                          // ... or the pair-split form of the pipelined kernel
         if (dual && a->x && a->x2 && a->g && a->gv && kmajor_dw_v2_selected(M, a->O, a->N)) {
             st = launch_gemm_v2<T, true, EpiDw>(ctx, (const T*)a->x, (const T*)a->x2, a->ld_x, (const T*)a->g, (const T*)a->gv, a->ld_g,

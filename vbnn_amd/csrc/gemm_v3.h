@@ -35,6 +35,15 @@ constexpr int V3_LDS = 4 * V3_APART + 3 * V3_BTILE;  // 163840: all of the CU's 
 
 static int g_v3_min_k = 704;        // shortest K the shape selection gives to this kernel (vbnn_debug_set key 4)
 
+// Diagnostic stamps (tools/split_lab.hip builds with -DV3_STAMP; the library never does): wave 0 of every workgroup
+// stores the 100 MHz real-time counter at a few points of the kernel into g_v3_stamp[blockIdx.x * 8 + k].
+#ifdef V3_STAMP
+__device__ unsigned long long* g_v3_stamp = nullptr;
+#define V3_ST(k) do { if (g_v3_stamp && threadIdx.x == 0) g_v3_stamp[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define V3_ST(k) do { } while (0)
+#endif
+
 template <> __device__ __forceinline__ void v2_wait_vmcnt<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
 template <> __device__ __forceinline__ void v2_wait_vmcnt<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
 
@@ -48,22 +57,54 @@ template <> __device__ __forceinline__ void v2_wait_vmcnt<10>() { asm volatile("
 //               8 k-rows x 32 B a half-wave's tr read touches fall on 8 distinct 32-byte bank slots
 //   fragment    lane 4 r + p of a 16-lane group addresses (k-row r, columns 4 p .. 4 p + 3) of the 4 x 16 block and
 //               receives column (lane & 15) of its four rows: k = 32 s + 8 q + 0..3, then + 4..7 with the second read
-template <bool DUAL, bool AK, bool BK, class Epi>
+// SPLIT (accGradParameters of a layer whose output has too few 256 x 256 tiles to fill the CUs: the 784 x 4096 gradient of
+// the input layer, 4 x 16 tiles): the grid is tiles x 2 x 2. A tile's PAIR is split over workgroups as in gemm_v2.h (each
+// computes one GEMM of the pair with the single-pass loop and writes only the outputs that depend on it, EpiDw::part), and
+// each of those is split again over two K halves whose partial tiles meet through a write-through slab + ticket (the
+// hand-off of gemm_v2.h's split-K: both halves store, the one whose ticket is 1 adds the other's -- a + b is commutative,
+// so the result does not depend on arrival order -- and runs the epilogue). 64 tiles -> 256 workgroups of 32 K steps on
+// this kernel's main loop (1.4 us per step against 0.9-1.2 us per HALF-size step of gemm_v2's single-accumulator tile).
+// The output may be ragged in M (rows past m_dim() are computed on zero padding and never stored; the row AT m_dim() is
+// the ones row: edge_row).
+template <bool DUAL, bool AK, bool BK, class Epi, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                      const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
-                                                     int M, int N, int nk, int tiles_m, int tiles_n, float* mscratch, Epi epi) {
+                                                     int M, int N, int nk, int tiles_m, int tiles_n, float* mscratch,
+                                                     unsigned* tickets, Epi epi_in) {
+    static_assert(!(SPLIT && DUAL), "the split form computes one GEMM of the pair per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    V3_ST(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform on the scalar side
     const int wr = wave >> 2, wc = wave & 3;
+    Epi epi = epi_in;
 
     // ---- block -> tile mapping: as gemm_v2.h (blocks that share an XCD get a compact 4 x 8 group of tiles)
-    const int nblk = tiles_m * tiles_n;
+    const int nblk = tiles_m * tiles_n * (SPLIT ? 4 : 1);
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int kslice = 0, unit = 0;                  // SPLIT: K half of this workgroup; (tile, part) id = ticket / slab index
+    if (SPLIT) {
+        // combination-major: the blocks that share an XCD (a contiguous range of remapped ids) all compute the SAME
+        // (GEMM of the pair, K half) for a compact group of tiles, so they share operand panels in its L2 exactly as the
+        // unsplit launch does (a tile's four blocks side by side would share none: 37 % of the panel reads unique instead
+        // of 19 %). The partner K halves then sit on different XCDs: their slabs are write-through anyway.
+        const int ntile = tiles_m * tiles_n;
+        const int combo = bid / ntile;
+        bid -= combo * ntile;
+        kslice = combo >> 1;
+        const int part = combo & 1;
+        unit = bid * 2 + part;
+        epi.set_part(1 + part);
+        if (part) { A = A2; B = B2; }
+        const int kt0 = kslice * (nk / 2);
+        nk = kslice ? nk - nk / 2 : nk / 2;
+        A += (int64_t)kt0 * (AK ? V2_BK * lda : V2_BK);
+        B += (int64_t)kt0 * (BK ? V2_BK * ldb : V2_BK);
     }
     int tm, tn;
     {
@@ -451,10 +492,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         zero_acc();
         prologue();
         run_pass();
+        V3_ST(5);
         // Pass 2's pipeline fill is issued BEFORE the fold, so its DMAs land while the fold computes. (The fold's own
         // loads and stores are younger than those DMAs on the in-order vmcnt counter: the counted waits of run_pass
         // only get stricter.)
         __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
+        if constexpr (Epi::FOLD_STAGE != 0) {
+            // FOLD_STAGE functors (see the fold below): the per-m addend (the bias) of the wave's 128 m is parked in the
+            // wave's LDS staging area NOW, before pass 2's fill is issued -- ONE global load per lane whose wait covers
+            // nothing else. (Beside LDS-DMAs in flight hipcc waits vmcnt(0) for any plain load's result, i.e. also for
+            // the fold's own stores: a bias load per quad drained the store queue 32 times per fold.)
+            constexpr int PITCH0 = 64 * (int)sizeof(typename Epi::fold_st_t) + 16, WSTG0 = 16 * PITCH0 + 512;
+            const unsigned stg0 = (unsigned)(uintptr_t)(ldsb_t)(wave < 7 ? lds + 4 * V3_APART + 2 * V3_BTILE + wave * WSTG0
+                                                                        : lds + 3 * V3_APART);
+            int sl = lane;
+            asm volatile("" : "+v"(sl));
+            const float* bp = epi.fold_bias_ptr();
+            f32x4 bq = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bp) bq = *reinterpret_cast<const f32x4*>(bp + (m0 + wr * 128) + 4 * (sl & 31));
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(stg0 + 16 * (sl & 31)), "v"(bq), "n"(16 * PITCH0) : "memory");
+        }
         V3_SET_OPERANDS(A, B);
         prologue();
         // opaque to the optimiser from here on: otherwise the fold's address / counter arithmetic is hoisted above
@@ -494,6 +551,55 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 }
         };
         static_assert(8 % Epi::FOLD_BATCH == 0, "FOLD_BATCH divides the 8 m-blocks of a wave tile");
+        if constexpr (Epi::FOLD_STAGE != 0) {
+            // The fold's own output tensor ([n][m], element type ST) leaves through a per-wave LDS tile [16 n][64 m]: the
+            // four quads of an (n-block, four m-blocks) group are written as they stand (lane (n = c16, 4 m)), read back
+            // as rows and stored as whole 128-byte (2-byte ST) row segments. Free LDS while pass 2's fill is in flight:
+            // B slot 2 and A part 3 (the first K step refills them only behind its barrier, which every wave reaches after
+            // its fold). LDS accesses go through inline asm: beside LDS-DMAs in flight hipcc would drain vmcnt(0) -- and
+            // with it this fold's own stores -- in front of every plain LDS read (see tr_load4).
+            typedef typename Epi::fold_st_t ST;
+            static_assert(sizeof(ST) == 2, "staging tile geometry: 64 m x 2 bytes = one 128-byte row segment");
+            constexpr int PITCH = 64 * (int)sizeof(ST) + 16;                   // bytes; 16 rows x 144 B = 2304 B per wave
+            constexpr int WSTG = 16 * PITCH + 512;                             // + the wave's 128 per-m addends (fp32)
+            static_assert(7 * WSTG <= V3_BTILE && WSTG <= V3_APART, "staging tiles must fit the free LDS");
+            const unsigned stg = (unsigned)(uintptr_t)(ldsb_t)(wave < 7 ? lds + 4 * V3_APART + 2 * V3_BTILE + wave * WSTG
+                                                                       : lds + 3 * V3_APART);
+            const unsigned wr_a = stg + fc16 * PITCH + 8 * fq4;                // this lane's 4 m of m-block b: + 32 b
+            int flane = lane;
+            asm volatile("" : "+v"(flane));
+            const unsigned bias_a = stg + 16 * fq4;                            // m-block i: + 16 PITCH + 64 i
+            const unsigned rd_a = stg + (flane >> 3) * PITCH + (flane & 7) * 16;   // row (lane >> 3) (+ 8), m chunk lane & 7
+            ST* const outp = epi.fold_st_ptr();
+            const int64_t old = epi.fold_st_ld();
+            const unsigned olane = (unsigned)((flane >> 3) * (int)old + (flane & 7) * 8);
+            auto fold_group = [&](auto g_c) {
+                constexpr int G = decltype(g_c)::value;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        f32x4 b4;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b4) : "v"(bias_a), "n"(16 * PITCH + 64 * (4 * G + b)) : "memory");
+                        float sv[4];
+                        acc[4 * G + b][j] = epi.fold_s(fm0 + 16 * (4 * G + b), fn0 + 16 * j, fln, acc[4 * G + b][j], b4, sv);
+                        const bf16x4 pk = bf16x4{Elt<ST>::to(sv[0]), Elt<ST>::to(sv[1]), Elt<ST>::to(sv[2]), Elt<ST>::to(sv[3])};
+                        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wr_a), "v"(pk), "n"(32 * b) : "memory");
+                        if (Epi::FOLD_SERIAL > 0)
+                            asm volatile("" : "+s"(fn0), "+s"(fm0)
+                                         : "v"(acc[4 * G + b][j][0]), "v"(acc[4 * G + b][j][1]), "v"(acc[4 * G + b][j][2]), "v"(acc[4 * G + b][j][3]));
+                    }
+                    bf16x8 r0, r1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r0), "=&v"(r1) : "v"(rd_a), "n"(8 * PITCH) : "memory");
+                    ST* const row0p = outp + ((int64_t)(fn0 + 16 * j) * old + fm0 + 64 * G);
+                    *reinterpret_cast<bf16x8*>(row0p + olane) = r0;
+                    *reinterpret_cast<bf16x8*>(row0p + 8 * old + olane) = r1;
+                }
+            };
+            fold_group(std::integral_constant<int, 0>());
+            fold_group(std::integral_constant<int, 1>());
+        } else {
         fold_batch(std::integral_constant<int, 0>());
         if constexpr (Epi::FOLD_BATCH < 8) fold_batch(std::integral_constant<int, Epi::FOLD_BATCH>());
         if constexpr (Epi::FOLD_BATCH < 4) {
@@ -503,6 +609,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             fold_batch(std::integral_constant<int, 4>()); fold_batch(std::integral_constant<int, 5>());
             fold_batch(std::integral_constant<int, 6>()); fold_batch(std::integral_constant<int, 7>());
         }
+        }
+        V3_ST(6);
         run_pass();
     } else {
         zero_acc();
@@ -510,6 +618,55 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         run_pass();
     }
     __syncthreads();
+    V3_ST(1);
+
+    if constexpr (SPLIT) {
+        // ---- split-K hand-off (gemm_v2.h's protocol: cdna_hip_programming.md Guideline 16 R1 in its ticket form). Both K
+        // halves store their partial tile as it stands in the MFMA layout (thread-private 16-byte slots, write-through),
+        // drain, take a ticket; ticket 0 is done; ticket 1 acquires, adds the other half's partial and goes on.
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        f32x4* mine = reinterpret_cast<f32x4*>(mscratch) + (size_t)(unit * 2 + kslice) * (32 * 512);
+        const f32x4* other = reinterpret_cast<const f32x4*>(mscratch) + (size_t)(unit * 2 + (kslice ^ 1)) * (32 * 512);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 32 * 512 * 16, 0x00020000);
+        // one lane offset for all 32 quads; the quad's slab offset rides in the scalar operand
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, acc[i][j]), rs, tid * 16, (i * 4 + j) * 8192, 16);
+        int* flag = reinterpret_cast<int*>(lds + V3_LDS - 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, then the barrier, then ONE ticket
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(tickets + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 1u) {
+                __hip_atomic_store(tickets + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flag = (int)t;
+        }
+        __syncthreads();
+        V3_ST(2);
+        if (*flag == 0) return;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(other), 0, 32 * 512 * 16, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, tid * 16, (i * 4 + j) * 8192, 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] += o[j];
+                // the sum is formed HERE: left to itself the optimiser sinks the adds into the epilogue and keeps all 32
+                // loaded quads alive beside the accumulators (it spilled)
+                asm volatile("" : "+v"(acc[i][j]));
+            }
+        }
+        __syncthreads();                                          // the flag's LDS word is staging space from here on
+        V3_ST(3);
+    }
 
     ET* tp1 = epi.t1_ptr();
     ET* tp2 = epi.t2_ptr();
@@ -518,6 +675,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         constexpr int HH = decltype(hh_c)::value, JJ = decltype(jj_c)::value;
         const int wm0 = m0 + wr * 128 + HH * 64, wn0 = n0 + wc * 64 + JJ * 32;
         (void)qq;
+        if constexpr (SPLIT) { if (wm0 > epi.m_dim()) return; }   // a quarter wholly past the ones row: nothing to store
         f32x4 r1[8], av[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -540,6 +698,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         // the functor's FAST protocol (epilogues.h): every tile of this kernel is interior and vector-aligned (the
         // launcher checks), so the epilogue's global loads are issued a batch at a time, ahead of their first use
         constexpr int FB = Epi::FAST_BATCH;
+        if constexpr (SPLIT) {
+            // ragged in M (gemm_v2.h's EDGE_FAST form): lanes whose quad lies past the last row are off, the lane ON row
+            // m_dim() hands its first value (the ones row's sum) to edge_row. m_dim() % 4 == 0: quads never straddle.
+            const int lm = wm0 + 4 * c16;
+            const bool lane_in = lm + 4 <= epi.m_dim(), lane_edge = lm == epi.m_dim();
+#pragma unroll
+            for (int p0 = 0; p0 < 8; p0 += FB) {
+                if (lane_in) {
+                    typename Epi::Pre pre[FB];
+#pragma unroll
+                    for (int b = 0; b < FB; ++b) pre[b] = epi.load_fast(wm0, wn0 + 4 * (p0 + b), eln);
+#pragma unroll
+                    for (int b = 0; b < FB; ++b) {
+                        float t1[4], t2[4];
+                        epi.apply_fast(wm0, wn0 + 4 * (p0 + b), eln, r1[p0 + b], f32x4{0.f, 0.f, 0.f, 0.f}, pre[b], t1, t2);
+                    }
+                }
+                if (lane_edge) {
+#pragma unroll
+                    for (int b = 0; b < FB; ++b) epi.edge_row(wn0 + 4 * (p0 + b) + q4, r1[p0 + b][0]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int p0 = 0; p0 < 8; p0 += FB) {
             typename Epi::Pre pre[FB];
@@ -582,6 +764,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             }
         }
     });
+    V3_ST(4);
 }
 
 // The kernel has no ragged-edge or general-output path: whole 256 x 256 tiles, 32-bit element offsets, the functor's
@@ -661,9 +844,66 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         int nk_ = nk, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
         int64_t lda_ = lda, ldb_ = ldb;
         Epi epi_ = epi;
-        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &park, &epi_};
+        unsigned* tickets_ = nullptr;
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &park, &tickets_, &epi_};
         hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n), dim3(512), args, V3_LDS, ctx->stream);
         if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v3 failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
         return vbnn_check_launch("gemm_nt_v3");
+    }
+}
+
+// ---- the SPLIT launch (K-major operands only: accGradParameters reading x and g as the other GEMMs hold them)
+static int g_v3_split = -1;         // -1 by shape, 0 never, 1 whenever possible (vbnn_debug_set key 8)
+// shape part: M rows of output (the ones row included) on N columns, K deep. Wanted when the pair split alone would leave
+// half the CUs idle and both K halves are long enough to amortise the pipeline fill and the hand-off.
+static inline bool gemm_v3_split_shape_ok(int64_t M, int64_t N, int64_t K) {
+    if (g_v3_split == 0 || N % V3_BN || K % (2 * V2_BK)) return false;
+    const int64_t tiles = ((M + V3_BM - 1) / V3_BM) * (N / V3_BN);
+    if (tiles * 2 > VBNN_CNT_TILES_MAX) return false;
+    if (g_v3_split == 1) return true;
+    return tiles * 2 <= 160 && tiles * 4 >= 192 && K >= 2048;
+}
+// the pitch of the K rows of A the split launch needs: whole 256-column tiles (the columns past M are zero padding)
+static inline int64_t gemm_v3_split_lda(int64_t M) { return (M + V3_BM - 1) / V3_BM * V3_BM; }
+
+template <typename T, class Epi>
+static int launch_gemm_v3_split(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, const T* B, const T* B2, int64_t ldb, int M, int N,
+                                int K, const Epi& epi) {
+    if constexpr (sizeof(T) != 2 || !Epi::SPLITTABLE || !Epi::EDGE_FAST) {
+        return VBNN_ERR_UNSUPPORTED;
+    } else {
+        Epi e0 = epi;
+        if (!A || !A2 || !B || !B2 || !gemm_v3_split_shape_ok(M, N, K) || !epi.fast_ok() || e0.t1_ptr() || e0.t2_ptr() ||
+            (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15u) != 0 || lda % 8 || ldb % 8 ||
+            lda < gemm_v3_split_lda(M) || ldb < N || (int64_t)K * lda >= (1ll << 30) || (int64_t)K * ldb >= (1ll << 30))
+            return VBNN_ERR_UNSUPPORTED;
+        const int tiles_m = (M + V3_BM - 1) / V3_BM, tiles_n = N / V3_BN;
+        const size_t need = (size_t)tiles_m * tiles_n * 2 * 2 * V3_BM * V3_BN * sizeof(float);     // a partial tile per K half
+        if (need > ctx->park_bytes) {
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->park) (void)hipFree(ctx->park);
+            ctx->park = nullptr; ctx->park_bytes = 0;
+            hipError_t e = hipMalloc((void**)&ctx->park, need);
+            if (e != hipSuccess) { vbnn_set_error("hipMalloc(gemm_v3 split-K slabs, %zu bytes): %s", need, hipGetErrorString(e)); return VBNN_ERR_NOMEM; }
+            ctx->park_bytes = need;
+        }
+        const void* kern = (const void*)gemm_nt_v3<false, true, true, Epi, true>;
+        static bool configured = false;
+        if (!configured) {
+            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+            if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+            configured = true;
+        }
+        const bf16_t* a = (const bf16_t*)A; const bf16_t* a2 = (const bf16_t*)A2;
+        const bf16_t* b = (const bf16_t*)B; const bf16_t* b2 = (const bf16_t*)B2;
+        int nk_ = K / V2_BK, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
+        int64_t lda_ = lda, ldb_ = ldb;
+        float* park = ctx->park;
+        unsigned* tickets_ = ctx->counters + VBNN_CNT_TILES;
+        Epi epi_ = epi;
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &park, &tickets_, &epi_};
+        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * 4), dim3(512), args, V3_LDS, ctx->stream);
+        if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v3 (split) failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+        return vbnn_check_launch("gemm_nt_v3 split");
     }
 }

@@ -38,6 +38,7 @@ class FusedMLP:
         self.reduce = world_size > 1 or force_reduce
         self._exchange = None                 # made on first use (vbnn_amd/comm.py): RCCL through the C ABI
         self.fuse_kl = bool(opt.get("fuse_kl", True))
+        self.kl_from_shadows = self.dtype == "bf16" and bool(opt.get("kl_from_shadows", True))
         # optional second HIP stream (+ its own context, hence its own reduction scratch) for the accGradParameters
         # GEMMs. Measured on MI355X (wide config): 1.32 ms with, 1.29 ms without -- two 512-block GEMMs sharing the
         # CUs thrash each other's L2 panels more than the staggered epilogues save -- so it is off by default.
@@ -128,8 +129,10 @@ class FusedMLP:
         for li, v in enumerate(self.vb):
             last_fused = (v is self.vb[-1]) and self.n_classes <= 16
             v.bias_from_dw = (v.I % 256 != 0) and not last_fused
-            v.dw_km = bool(km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1 and
-                           lib.vbnn_kmajor_supported_dw(v.I, v.O, N, 1 if v.bias_from_dw else 0))
+            km = lib.vbnn_kmajor_supported_dw(v.I, v.O, N, 1 if v.bias_from_dw else 0) if (
+                km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1) else 0
+            v.dw_km = km > 0
+            v.x_pad256 = km == 2         # the split launch of gemm_v3 reads x / x.x in whole 256-column tiles
             v.dx_km = bool(km_ok and li > 0 and lib.vbnn_kmajor_supported(v.I, N, v.O))
             use_muT = (li > 0) and not v.dx_km
             if use_muT and not getattr(v, "use_muT", True):
@@ -142,8 +145,11 @@ class FusedMLP:
             # K-major the row of ones is COLUMN I of x (in the K padding of the forward operand, where the packed
             # weights are zero, so the forward does not see it).
             extra = 1 if v.bias_from_dw else 0
-            v.x_s = _Packed(N, v.I + (extra if v.dw_km else 0), tdt, dev)
-            v.x2_s = _Packed(N, v.I + (extra if v.dw_km else 0), tdt, dev)
+            xcols = v.I + (extra if v.dw_km else 0)
+            if v.x_pad256:
+                xcols = (xcols + 255) // 256 * 256
+            v.x_s = _Packed(N, xcols, tdt, dev)
+            v.x2_s = _Packed(N, xcols, tdt, dev)
             if v.dw_km and v.bias_from_dw:
                 v.x_s.t[:, v.I] = 1.0
             if v.dw_km:
@@ -319,6 +325,10 @@ class FusedMLP:
             d.grad_mu, d.grad_lv = _p(v.gradWeight), _p(v.gradSum)
             d.means, d.stats = _p(v.means), _p(v.stats)
             d.B, d.S, d.kl_scale = self.B, self.S, partition.scales(1, self.world)["kl_scale"]
+            if self.kl_from_shadows and lrt:
+                # the epilogue reads mu, sigma^2 from the bf16 operand shadows (4 B per weight instead of 8, no exp): the
+                # values the forward GEMMs multiplied by
+                d.mu_s, d.var_s, d.ld_w = v.mu_s.ptr, v.var_s.ptr, v.mu_s.ld
         else:
             d.gradWeight, d.gradSum = _p(v.gradWeight), _p(v.gradSum)
         d.gradBias = _p(v.gradBias) if v.bias_from_dw else None
