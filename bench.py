@@ -34,10 +34,13 @@ CONFIGS = {
     # BASELINE.json configs[1]: the fp32 numerics configuration (launch-bound)
     "small": dict(input_size=784, hidden=[400, 400], n_classes=10, batch=256, dtype="f32",
                   name="784-400-400-10 VBLinear MLP, batch 256 per GPU, LRT, S=1"),
-    # BASELINE.json configs[4], with the reference's own criterion (10 classes) in place of a regression loss the
-    # reference does not have: the deep-stack KL / bandwidth stress
-    "deep": dict(input_size=4096, hidden=[4096] * 8, n_classes=10, batch=4096, dtype="bf16",
-                 name="4096-(4096 x 8)-10 VBLinear stack, batch 4096 per GPU, LRT, S=1"),
+    # BASELINE.json configs[4]: 8 x 4096-wide VBLinear stack on a synthetic 4096-dimensional regression (final Linear
+    # 4096 -> 4096 + nn.MSECriterion, target x R / sqrt(4096): BASELINE.md section 2 config 5): deep-stack KL / bandwidth stress
+    "deep": dict(input_size=4096, hidden=[4096] * 8, n_classes=4096, batch=4096, dtype="bf16", criterion="mse",
+                 name="4096-(4096 x 8)-4096 VBLinear stack, MSE regression, batch 4096 per GPU, LRT, S=1"),
+    # the same stack under the reference's own criterion (10 classes, LogSoftMax + ClassNLL): round 1's "deep" row
+    "deep-nll": dict(input_size=4096, hidden=[4096] * 8, n_classes=10, batch=4096, dtype="bf16",
+                     name="4096-(4096 x 8)-10 VBLinear stack, batch 4096 per GPU, LRT, S=1"),
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md: dense MFMA peaks
 LIVE_NAMES = {"forward": "forward(dual GEMM + LRT epilogue)",

@@ -348,6 +348,16 @@ int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const in
                         int64_t N, int64_t C, float inv_n, float* out, float* g_logits,
                         double* loss_sum_dev, int32_t* correct_dev);
 
+/* nn.MSECriterion (sizeAverage) on an N x D output, for BASELINE.json configs[4] ("synthetic 4096-dim regression"; the
+ * reference itself only ever uses ClassNLL, mlp.lua:32): criterion:forward + :backward in ONE pass over y and target,
+ *   loss_sum_dev[0] (+)= inv_nd * sum (y - t)^2;   g[n][d] = 2 inv_nd (y - t)   (g optional),
+ * inv_nd = 1 / (GLOBAL rows x D). The sum is formed in a fixed order (block partials + one finish block: bitwise
+ * reproducible); accumulate = 0 stores it, 1 adds to it (the S draws of a minibatch). vbnn_mse_backward: g alone. */
+int vbnn_mse_forward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* target, int64_t ld_t, int64_t N, int64_t D,
+                     float inv_nd, float* g, int64_t ld_g, int accumulate, double* loss_sum_dev);
+int vbnn_mse_backward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* target, int64_t ld_t, int64_t N, int64_t D,
+                      float inv_nd, float* g, int64_t ld_g);
+
 /* mlp.lua:29-32 fused for a small class count (C <= 16): final nn.Linear + nn.LogSoftMax +
  * nn.ClassNLLCriterion as streaming kernels over the packed N x H activation `h` (dtype) and the packed
  * final weight `w3` (C x ld_w, dtype). Forward: logits = h w3^T + bias, out = logsoftmax,

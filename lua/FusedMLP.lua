@@ -1,0 +1,248 @@
+-- lua/FusedMLP.lua -- the DEVICE-RESIDENT form of mlp.lua's step for MI355X: what replaces `mlp:run` when the
+-- minibatch is to stay in HBM from the input packer to the gradients (the module-level lua/VBLinear.lua keeps
+-- mlp.lua unchanged but crosses PCIe at every module). Same protocol as the reference's mlp.lua --
+--     mlp:resetGradients()  (mlp.lua:62-67)      mlp:sample()   (:69-74)      mlp:run(inputs, targets)  (:76-84)
+--     mlp:calc_lc(opt)      (:109-115)           mlp:update(opt) (:117-142)
+-- -- over the C ABI of include/vbnn_hip.h, call for call the sequence of vbnn_amd/engine.py:FusedMLP (run: lines
+-- "forward" / "fused classifier head" / "backward"), which is what the GPU parity tests execute. LRT mode, total
+-- gradients from the accGradParameters epilogue (VBLinear.lua:90-98 folded in), S draws accumulate in place.
+-- Data-parallel: one process per GPU; `opt.world` / `opt.rank` / `opt.comm_id` (the 128 bytes of
+-- vbnn_comm_unique_id, handed to every rank by the launcher) switch on the RCCL exchange of the gradient buckets.
+--
+-- NOT EXECUTED in the build image (no LuaJIT / Torch7 there); tests/test_abi.py lints it structurally: every
+-- C.vbnn_* it calls is declared in the header with that many parameters, and the call ORDER of `run` is the one
+-- engine.py issues.
+local vb = require('vbnn_ffi')
+local ffi, C, check = vb.ffi, vb.C, vb.check
+
+local FusedMLP = {}
+FusedMLP.__index = FusedMLP
+
+local function f32(p) return ffi.cast('float*', p) end
+local function packed(rows, cols, esize)
+    local ld = vb.pad_ld(cols)
+    return { p = vb.alloc(rows * ld * esize), ld = ld }
+end
+
+-- opt: input_size, hidden = {..}, n_classes (<= 16: the fused classifier head), var_init, B, S, seed, dtype ('bf16')
+function FusedMLP.new(opt)
+    local self = setmetatable({}, FusedMLP)
+    self.opt = opt
+    self.dtype = (opt.dtype == 'f32') and C.VBNN_F32 or C.VBNN_BF16
+    self.esize = (self.dtype == C.VBNN_BF16) and 2 or 4
+    self.seed, self.B, self.S = opt.seed or 3, opt.B, opt.S or 1
+    self.world, self.rank = opt.world or 1, opt.rank or 0
+    self.n_classes = opt.n_classes
+    assert(self.n_classes <= 16, 'FusedMLP.lua drives the fused classifier head (mlp.lua:29-32); see engine.py for wider ones')
+    local sizes = { opt.input_size }
+    for _, h in ipairs(opt.hidden) do sizes[#sizes + 1] = h end
+    self.sizes = sizes
+    -- gradient arena: [d/dmeans | d/dlvars | d/dbias] per VB layer, then the final Linear (vbnn_amd/partition.py)
+    local total = 0
+    for li = 1, #sizes - 1 do total = total + 2 * sizes[li] * sizes[li + 1] + sizes[li + 1] end
+    total = total + sizes[#sizes] * self.n_classes + self.n_classes
+    self.n_grads = total
+    self.grads = vb.alloc(total * 4)
+    local off = 0
+    local function take(n) local p = f32(self.grads) + off; off = off + n; return p end
+    self.vb = {}
+    for li = 1, #sizes - 1 do
+        local I, O = sizes[li], sizes[li + 1]
+        local v = { I = I, O = O, layer_id = li - 1, bucket_off = off }
+        v.means, v.lvars, v.bias = vb.alloc(O * I * 4), vb.alloc(O * I * 4), vb.alloc(O * 4)
+        v.m_mu, v.v_mu, v.m_lv, v.v_lv = vb.alloc(O * I * 4), vb.alloc(O * I * 4), vb.alloc(O * I * 4), vb.alloc(O * I * 4)
+        v.grad_mu, v.grad_lv, v.gradBias = take(O * I), take(O * I), take(O)
+        v.bucket_n = off - v.bucket_off
+        v.stats = vb.alloc(32)
+        v.mu_s, v.var_s = packed(O, I, self.esize), packed(O, I, self.esize)
+        v.muT_s, v.varT_s = packed(I, O, self.esize), packed(I, O, self.esize)
+        v.t = 0
+        -- VBLinear.lua:18,22-28 + the He rule of mlp.lua:47-55 for the means (stream 5 = VBNN_STREAM_HEINIT)
+        check(C.vbnn_fill_normal(vb.ctx, f32(v.means), O, I, I, self.seed, 5, v.layer_id, 0, 0, math.sqrt(2 / I)))
+        local lv0 = torch.FloatTensor(O * I):fill(math.log(opt.msr_init and 2 / I or opt.var_init))
+        check(C.vbnn_buf_upload(vb.ctx, v.lvars, lv0:data(), O * I * 4))
+        self.vb[li] = v
+    end
+    local H = sizes[#sizes]
+    self.weight3, self.bias3 = vb.alloc(self.n_classes * H * 4), vb.alloc(self.n_classes * 4)
+    self.gradWeight3, self.gradBias3 = take(self.n_classes * H), take(self.n_classes)
+    check(C.vbnn_fill_normal(vb.ctx, f32(self.weight3), self.n_classes, H, H, self.seed, 5, #self.vb, 0, 0, math.sqrt(2 / H)))
+    self.w3_s = packed(self.n_classes, H, self.esize)
+    self.acc, self.corr = vb.alloc(16), vb.alloc(4)
+    self.draw, self.first = 0, true
+    if self.world > 1 then                                        -- the exchange (include/vbnn_hip.h: vbnn_comm_*)
+        local box = ffi.new('vbnn_comm*[1]')
+        check(C.vbnn_comm_create(vb.ctx, self.rank, self.world, opt.comm_id, box))
+        self.comm = ffi.gc(box[0], C.vbnn_comm_destroy)
+    end
+    self:prepare()
+    return self
+end
+
+-- buffers that depend on the local batch size (engine.py:_alloc_batch)
+function FusedMLP:_alloc_batch(N)
+    if self.N == N then return end
+    self.N = N
+    for li, v in ipairs(self.vb) do
+        local last = li == #self.vb
+        v.bias_from_dw = (v.I % 256 ~= 0) and not last          -- the ones column of x: bias gradient from the GEMM
+        local km = C.vbnn_kmajor_supported_dw(v.I, v.O, N, v.bias_from_dw and 1 or 0)
+        v.dw_km = km > 0
+        v.dx_km = li > 1 and C.vbnn_kmajor_supported(v.I, N, v.O) ~= 0
+        local xcols = v.I + ((v.dw_km and v.bias_from_dw) and 1 or 0)
+        if km == 2 then xcols = math.floor((xcols + 255) / 256) * 256 end
+        v.x_s, v.x2_s = packed(N, xcols, self.esize), packed(N, xcols, self.esize)
+        v.g_s, v.gv_s = packed(N, v.O, self.esize), packed(N, v.O, self.esize)
+        v.r = vb.alloc(N * v.O * self.esize)
+        assert(v.dw_km and (li == 1 or v.dx_km), 'FusedMLP.lua covers the K-major configuration (no transposed copies); ' ..
+               'shapes the library answers 0 for need the xT / gT / muT operands engine.py allocates')
+        if v.bias_from_dw then                                    -- column I of x is all ones, written once
+            local ones, ones_dev = torch.FloatTensor(N):fill(1), vb.alloc(N * 4)
+            check(C.vbnn_buf_upload(vb.ctx, ones_dev, ones:data(), N * 4))
+            check(C.vbnn_pack(vb.ctx, self.dtype, C.VBNN_PACK_COPY, f32(ones_dev), nil, 1, N, 1,
+                              ffi.cast('char*', v.x_s.p) + v.I * self.esize, v.x_s.ld, nil, 0))
+        end
+    end
+    self.h_s = packed(N, self.sizes[#self.sizes], self.esize)
+    self.logits, self.out, self.g_logits = vb.alloc(N * self.n_classes * 4), vb.alloc(N * self.n_classes * 4), vb.alloc(N * self.n_classes * 4)
+end
+
+function FusedMLP:resetGradients() self.first = true end          -- mlp.lua:62-67: the first draw overwrites
+
+-- VBLinear:compute_prior (VBLinear.lua:77-88) + the operand shadows, once; afterwards vbnn_update maintains both
+function FusedMLP:prepare()
+    local n = #self.vb
+    local d = ffi.new('vbnn_prep_desc[?]', n)
+    for k, v in ipairs(self.vb) do
+        local e = d[k - 1]
+        e.means, e.lvars, e.O, e.I = f32(v.means), f32(v.lvars), v.O, v.I
+        e.mu_s, e.var_s, e.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
+        e.muT_s, e.varT_s, e.ld_wT = nil, nil, 0
+        e.stats = ffi.cast('double*', v.stats)
+    end
+    local w3 = ffi.new('vbnn_pack_desc[1]')
+    w3[0].src, w3[0].rows, w3[0].cols, w3[0].ld_src = f32(self.weight3), self.n_classes, self.sizes[#self.sizes], self.sizes[#self.sizes]
+    w3[0].dst, w3[0].ld_dst, w3[0].dstT, w3[0].ld_dstT = self.w3_s.p, self.w3_s.ld, nil, 0
+    check(C.vbnn_prepare(vb.ctx, self.dtype, n, d, w3))
+end
+
+function FusedMLP:sample() self.draw = self.draw + 1 end          -- mlp.lua:69-74: LRT draws its noise in the forward epilogue
+
+-- mlp.lua:76-84, fused. inputs: DEVICE pointer to N x input_size floats (row pitch ld), targets: device int32[N], 0-based
+function FusedMLP:run(inputs, ld, targets, N)
+    self:_alloc_batch(N)
+    local accumulate = self.first and 0 or 1
+    local inv_n = 1 / (N * self.world)
+    local row0 = self.rank * N
+    local v0 = self.vb[1]
+    check(C.vbnn_pack_input(vb.ctx, self.dtype, f32(inputs), ld, N, v0.I, v0.x_s.p, v0.x2_s.p, v0.x_s.ld, nil, nil, 0))
+    -- forward: dual GEMM + noise / ReLU / operand packing in the epilogue
+    for li, v in ipairs(self.vb) do
+        local nxt = self.vb[li + 1]
+        local fa = ffi.new('vbnn_fwd_args')
+        fa.w, fa.w2, fa.x, fa.x2, fa.ld_w, fa.ld_x = v.mu_s.p, v.var_s.p, v.x_s.p, v.x2_s.p, v.mu_s.ld, v.x_s.ld
+        fa.N, fa.I, fa.O, fa.bias = N, v.I, v.O, f32(v.bias)
+        fa.seed, fa.layer, fa.draw, fa.row0 = self.seed, v.layer_id, self.draw, row0
+        fa.r, fa.ld_r, fa.r_packed, fa.relu = v.r, v.O, 1, 1
+        fa.h = nxt and nxt.x_s.p or self.h_s.p
+        fa.h2 = nxt and nxt.x2_s.p or nil
+        fa.ld_h = nxt and nxt.x_s.ld or self.h_s.ld
+        check(C.vbnn_forward(vb.ctx, self.dtype, fa))
+    end
+    -- final Linear + LogSoftMax + ClassNLL (mlp.lua:29-32), forward and backward
+    local vl, H = self.vb[#self.vb], self.sizes[#self.sizes]
+    check(C.vbnn_head_forward(vb.ctx, self.dtype, self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.bias3),
+                              ffi.cast('const int32_t*', targets), N, H, self.n_classes, inv_n, f32(self.logits), f32(self.out),
+                              f32(self.g_logits), accumulate, ffi.cast('double*', self.acc), ffi.cast('int32_t*', self.corr)))
+    check(C.vbnn_head_backward(vb.ctx, self.dtype, self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.g_logits), N, H,
+                               self.n_classes, accumulate, self.gradWeight3, self.gradBias3, vl.gradBias, 1, vl.r, vl.O, 1,
+                               vl.g_s.p, vl.gv_s.p, vl.g_s.ld, nil, nil, 0))
+    -- backward, last VB layer first: accGradParameters (+ its bucket's all-reduce), then updateGradInput
+    for li = #self.vb, 1, -1 do
+        local v = self.vb[li]
+        local d = ffi.new('vbnn_dw_args')
+        d.N, d.I, d.O, d.scale, d.accumulate = N, v.I, v.O, 1, accumulate
+        d.seed, d.layer, d.draw, d.lvars = self.seed, v.layer_id, self.draw, f32(v.lvars)
+        d.grad_mu, d.grad_lv, d.means, d.stats = v.grad_mu, v.grad_lv, f32(v.means), ffi.cast('double*', v.stats)
+        d.B, d.S, d.kl_scale = self.B, self.S, 1 / self.world
+        d.gradBias = v.bias_from_dw and v.gradBias or nil
+        d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_s.p, v.x2_s.p, v.g_s.p, v.gv_s.p, v.x_s.ld, v.g_s.ld
+        d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
+        check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, d))
+        if li < #self.vb and not v.bias_from_dw then
+            check(C.vbnn_acc_grad_bias(vb.ctx, self.dtype, v.g_s.p, v.g_s.ld, N, v.O, 1, accumulate, v.gradBias))
+        end
+        if self.comm then                                         -- the final Linear's gradients ride in the last layer's message
+            local n = (li == #self.vb) and (self.n_grads - v.bucket_off) or v.bucket_n
+            check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + v.bucket_off, n))
+        end
+        if li > 1 then
+            local p = self.vb[li - 1]
+            local xa = ffi.new('vbnn_dx_args')
+            xa.g, xa.gv, xa.ld_g, xa.N, xa.I, xa.O = v.g_s.p, v.gv_s.p, v.g_s.ld, N, v.I, v.O
+            xa.x, xa.ld_x, xa.relu_mask = v.x_s.p, v.x_s.ld, 1
+            xa.r_prev, xa.ld_r_prev, xa.r_prev_packed = p.r, p.O, 1
+            xa.g_prev, xa.gv_prev, xa.ld_gp = p.g_s.p, p.gv_s.p, p.g_s.ld
+            xa.w, xa.w2, xa.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
+            check(C.vbnn_grad_input(vb.ctx, self.dtype, xa))
+        end
+    end
+    self.first = false
+end
+
+function FusedMLP:finish()                                        -- end of the minibatch: gradients complete on the stream
+    if self.comm then check(C.vbnn_comm_finish(self.comm)) end
+end
+
+-- mlp:update + VBLinear:update (mlp.lua:117-142, VBLinear.lua:124-166) in one call, which also leaves the operand
+-- shadows and prior statistics of the next minibatch; `log` (a FloatTensor-free double[14 * layers] on the device)
+function FusedMLP:update(opt, log14)
+    self:finish()
+    local lr = opt.state.learningRate
+    local H = self.sizes[#self.sizes]
+    check(C.vbnn_sgd_step(vb.ctx, f32(self.weight3), self.gradWeight3, self.n_classes * H, lr))
+    check(C.vbnn_sgd_step(vb.ctx, f32(self.bias3), self.gradBias3, self.n_classes, lr))
+    local n = #self.vb
+    local d = ffi.new('vbnn_update_desc[?]', n)
+    for k, v in ipairs(self.vb) do
+        v.t = v.t + 1
+        local e = d[k - 1]
+        e.means, e.lvars, e.O, e.I = f32(v.means), f32(v.lvars), v.O, v.I
+        e.mu_s, e.var_s, e.ld_w, e.muT_s, e.varT_s, e.ld_wT = v.mu_s.p, v.var_s.p, v.mu_s.ld, nil, nil, 0
+        e.stats, e.grad_mu, e.grad_lv = ffi.cast('double*', v.stats), v.grad_mu, v.grad_lv
+        e.m_mu, e.v_mu, e.m_lv, e.v_lv = f32(v.m_mu), f32(v.v_mu), f32(v.m_lv), f32(v.v_lv)
+        for key, st in pairs({ mu = opt.meanState, lv = opt.varState }) do
+            e[key].lr, e[key].beta1, e[key].beta2 = st.learningRate, st.beta1 or 0.9, st.beta2 or 0.999
+            e[key].eps, e[key].lambda, e[key].t = st.epsilon or 1e-8, st.lambda or 1, v.t
+        end
+        e.bias, e.grad_bias, e.lr_bias, e.B = f32(v.bias), v.gradBias, lr, self.B
+        e.log14 = log14 and (ffi.cast('double*', log14) + 14 * (k - 1)) or nil
+    end
+    local w3 = ffi.new('vbnn_pack_desc[1]')
+    w3[0].src, w3[0].rows, w3[0].cols, w3[0].ld_src = f32(self.weight3), self.n_classes, H, H
+    w3[0].dst, w3[0].ld_dst, w3[0].dstT, w3[0].ld_dstT = self.w3_s.p, self.w3_s.ld, nil, 0
+    check(C.vbnn_update(vb.ctx, self.dtype, n, d, w3))
+end
+
+-- mlp:calc_lc (mlp.lua:109-115): sum over the VB layers of VBLinear:calc_lc (VBLinear.lua:99-103), fresh statistics
+function FusedMLP:calc_lc(opt)
+    local lc, box, dev = 0, ffi.new('double[1]'), vb.alloc(8)
+    for _, v in ipairs(self.vb) do
+        check(C.vbnn_calc_lc(vb.ctx, f32(v.means), f32(v.lvars), nil, nil, ffi.cast('double*', v.stats), (opt or self.opt).B, nil,
+                             ffi.cast('double*', dev), v.O * v.I))
+        check(C.vbnn_buf_download(vb.ctx, box, dev, 8))
+        lc = lc + box[0]
+    end
+    return lc
+end
+
+-- error (mean NLL over the GLOBAL batch, this rank's share) and hit count of the last run(s); synchronises
+function FusedMLP:loss_and_accuracy()
+    self:finish()
+    local a, c = ffi.new('double[2]'), ffi.new('int32_t[1]')
+    check(C.vbnn_buf_download(vb.ctx, a, self.acc, 16))
+    check(C.vbnn_buf_download(vb.ctx, c, self.corr, 4))
+    return a[0], c[0]
+end
+
+return FusedMLP

@@ -143,6 +143,10 @@ int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx,
 int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const int32_t* target,
                         int64_t N, int64_t C, float inv_n, float* out, float* g_logits,
                         double* loss_sum_dev, int32_t* correct_dev);
+int vbnn_mse_forward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* target, int64_t ld_t, int64_t N, int64_t D,
+                     float inv_nd, float* g, int64_t ld_g, int accumulate, double* loss_sum_dev);
+int vbnn_mse_backward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* target, int64_t ld_t, int64_t N, int64_t D,
+                      float inv_nd, float* g, int64_t ld_g);
 int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
                       float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,

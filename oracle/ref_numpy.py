@@ -123,7 +123,7 @@ class ReferenceCpuMLP:
 
 
 # ---- the fused LRT step with explicit rounding points -------------------------------------------------
-def emulate_lrt_step(layers, w3, b3, x, t, zetas, rnd=lambda a: a, S=1.0, B=1e6, inv_n=None, kl_shadows=False):
+def emulate_lrt_step(layers, w3, b3, x, t, zetas, rnd=lambda a: a, S=1.0, B=1e6, inv_n=None, kl_shadows=False, criterion="nll"):
     """One LRT draw of the whole MLP in float64 with the engine's rounding points made explicit:
     `rnd` is applied wherever the HIP path stores a GEMM operand (x, x.x, mu, sigma^2, relu(y), its
     square, g, g.r and the final Linear's operands). rnd = identity gives the exact fp32-free reference
@@ -147,11 +147,17 @@ def emulate_lrt_step(layers, w3, b3, x, t, zetas, rnd=lambda a: a, S=1.0, B=1e6,
         xs.append(h.astype(f8))
         x2s.append(rnd(h * h).astype(f8))
     logits = (xs[-1] @ rnd(w3).astype(f8).T + b3).astype(np.float32)
-    out = log_softmax(logits)
-    loss = float(-out[np.arange(N), t].sum() * inv_n)
-    onehot = np.zeros_like(out)
-    onehot[np.arange(N), t] = 1.0
-    g3 = ((np.exp(out) - onehot) * np.float32(inv_n)).astype(np.float32)
+    if criterion == "mse":                      # nn.MSECriterion over N x D outputs; inv_n = 1 / (global rows)
+        D = logits.shape[1]
+        diff = logits.astype(f8) - t.astype(f8)
+        loss = float((diff * diff).sum() * inv_n / D)
+        g3 = (2.0 * (logits - t.astype(np.float32)) * np.float32(inv_n / D)).astype(np.float32)
+    else:
+        out = log_softmax(logits)
+        loss = float(-out[np.arange(N), t].sum() * inv_n)
+        onehot = np.zeros_like(out)
+        onehot[np.arange(N), t] = 1.0
+        g3 = ((np.exp(out) - onehot) * np.float32(inv_n)).astype(np.float32)
     g3r = rnd(g3).astype(f8)
     gw3 = g3r.T @ xs[-1]
     gb3 = g3.astype(f8).sum(axis=0)

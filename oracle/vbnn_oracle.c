@@ -325,6 +325,18 @@ VBO_API void vbo_nll_backward(const int32_t* target, float* g, int64_t N, int64_
     memset(g, 0, (size_t)(N * C) * sizeof(float));
     for (int64_t n = 0; n < N; ++n) g[n * C + target[n]] = -1.0f / (float)N;
 }
+/* nn.MSECriterion, sizeAverage = true [recalled, torch/nn; not used by the reference itself: it is the criterion of
+ * BASELINE.json configs[4], "synthetic 4096-dim regression", a build-side configuration]:
+ * loss = (1 / (N D)) sum (y - t)^2;  gradInput = 2 (y - t) / (N D). */
+VBO_API double vbo_mse_forward(const float* y, const float* target, int64_t N, int64_t D) {
+    double s = 0.0;
+    for (int64_t i = 0; i < N * D; ++i) { const double d = (double)y[i] - (double)target[i]; s += d * d; }
+    return s / (double)(N * D);
+}
+VBO_API void vbo_mse_backward(const float* y, const float* target, float* g, int64_t N, int64_t D) {
+    const float k = 2.0f / (float)(N * D);
+    for (int64_t i = 0; i < N * D; ++i) g[i] = k * (y[i] - target[i]);
+}
 /* utils.get_accuracy -- utils.lua:11-27: percentage of rows whose arg-max equals the target
  * (first maximum wins, as Tensor:max does [recalled]). */
 VBO_API double vbo_get_accuracy(const float* out, const int32_t* target, int64_t N, int64_t C) {

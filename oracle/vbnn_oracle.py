@@ -40,6 +40,7 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.vbo_calc_lc.restype = C.c_double
         _lib.vbo_nll_forward.restype = C.c_double
+        _lib.vbo_mse_forward.restype = C.c_double
         _lib.vbo_get_accuracy.restype = C.c_double
         _lib.vbo_det_logf.restype = C.c_float
         _lib.vbo_det_logf.argtypes = [C.c_float]
@@ -207,6 +208,16 @@ def nll_backward(target, N, Cn):
     return g
 
 
+def mse_forward(y, target):
+    return float(lib().vbo_mse_forward(_f(y), _f(target), _i64(y.shape[0]), _i64(y.shape[1])))
+
+
+def mse_backward(y, target):
+    g = np.empty_like(y)
+    lib().vbo_mse_backward(_f(y), _f(target), _f(g), _i64(y.shape[0]), _i64(y.shape[1]))
+    return g
+
+
 def get_accuracy(out, target):
     return float(lib().vbo_get_accuracy(_f(out), _i32(target), _i64(out.shape[0]), _i64(out.shape[1])))
 
@@ -369,6 +380,16 @@ class OracleMLP:
             pre.append(y)
             acts.append(relu_forward(y))
         logits = self.last.updateOutput(acts[-1])
+        if self.opt.get("criterion", "nll") == "mse":
+            # BASELINE.json configs[4] (regression; not in the reference): no LogSoftMax, nn.MSECriterion on the outputs
+            outputs = logits
+            g = mse_backward(outputs, targets)
+            g = self.last.backward(acts[-1], g)
+            for k in range(len(self.vb) - 1, -1, -1):
+                g = relu_backward(pre[k], g)
+                g = self.vb[k].backward(acts[k], g, 1.0, want_gx=True)
+            self.outputs = outputs
+            return mse_forward(outputs, targets), 0.0
         outputs = logsoftmax_forward(logits)
         df_do = nll_backward(targets, outputs.shape[0], outputs.shape[1])  # criterion:backward, :78
         g = logsoftmax_backward(outputs, df_do)                            # model:backward, :79

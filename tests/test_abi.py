@@ -141,3 +141,87 @@ def test_lua_shim_structure():
     need = {"__init", "sample", "clamp_to_map", "resetAcc", "updateOutput", "updateGradInput", "accGradParameters",
             "compute_prior", "compute_mugrads", "compute_vargrads", "calc_lc", "update"}
     assert need <= methods, need - methods
+
+
+def _split_args(argtxt):
+    """Top-level comma split of a Lua argument list."""
+    out, depth, cur = [], 0, ""
+    for ch in argtxt:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def _calls(txt):
+    """(name, n_args) of every C.vbnn_*(...) call, in source order."""
+    res = []
+    for m in re.finditer(r"\bC\.(vbnn_[a-z0-9_]+)\s*\(", txt):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(txt[i], 0)
+            i += 1
+        res.append((m.group(1), len(_split_args(txt[m.end():i - 1]))))
+    return res
+
+
+def test_lua_fused_mlp_structure():
+    """lua/FusedMLP.lua is the device-resident Lua caller; no interpreter exists here, so it is
+    linted: blocks balance; every C.vbnn_* call is declared in the header and passes that many arguments; every field it
+    sets on a vbnn_* argument block exists in that struct; and `run` issues the library calls in the ORDER
+    vbnn_amd/engine.py:FusedMLP.run does (the sequence the GPU parity tests execute)."""
+    path = os.path.join(ROOT, "lua", "FusedMLP.lua")
+    txt, toks = _lua_tokens(path)
+    opens = sum(toks.count(k) for k in ("function", "if", "for", "while"))
+    bare_do = toks.count("do") - toks.count("for") - toks.count("while")
+    assert bare_do >= 0 and opens + bare_do == toks.count("end"), (opens, bare_do, toks.count("end"))
+    assert txt.count("(") == txt.count(")") and txt.count("{") == txt.count("}") and txt.count("[") == txt.count("]")
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos = {m.group(1): len([p for p in m.group(2).split(",") if p.strip() and p.strip() != "void"])
+              for m in re.finditer(r"(vbnn_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)}
+    calls = _calls(txt)
+    assert len(calls) >= 20
+    for name, n in calls:
+        assert name in protos, f"{name} is not declared in include/vbnn_hip.h"
+        assert n == protos[name], f"{name}: {n} arguments in FusedMLP.lua, {protos[name]} parameters in the header"
+    # struct fields
+    structs = {m.group(2): set(re.findall(r"(\w+)\s*(?:,|;)", re.sub(r"\b(?:const|void|float|double|int|int64_t|uint64_t|uint32_t|vbnn_adam_cfg)\b|\*", " ", m.group(1))))
+               for m in re.finditer(r"typedef struct \w+ \{(.*?)\}\s*(vbnn_\w+);", hdr, flags=re.S)}
+    raw = open(path).read()
+    checked = 0
+    for chunk in re.split(r"\n(?=function |local function )", raw):          # variable names are per function
+        types = {}
+        for m in re.finditer(r"local\s+(\w+)\s*=\s*ffi\.new\('(vbnn_\w+?)(?:\[[^']*\])?'", chunk):
+            types[m.group(1)] = m.group(2)
+        for m in re.finditer(r"local\s+(\w+)\s*=\s*(\w+)\[[^\]]*\]\s*\n", chunk):
+            if m.group(2) in types:
+                types[m.group(1)] = types[m.group(2)]
+        for var, st in types.items():
+            if st not in structs:
+                continue
+            for m in re.finditer(r"(?<![\w.])%s(?:\[0\])?\.(\w+)" % re.escape(var), chunk):
+                assert m.group(1) in structs[st], f"{var}.{m.group(1)}: no such field in {st}"
+                checked += 1
+    assert checked >= 60, checked
+    # call order of run == engine.py's
+    body = raw[raw.index("function FusedMLP:run"):raw.index("function FusedMLP:finish")]
+    lua_order = []
+    for name, _ in _calls(body):
+        if not lua_order or lua_order[-1] != name:
+            lua_order.append(name)
+    eng = open(os.path.join(ROOT, "vbnn_amd", "engine.py")).read()
+    run = eng[eng.index("    def run(self, inputs, targets"):eng.index("            main, side, ctx2 =")]
+    run = run[:run.index("            self._generic_head(")] + run[run.index("        # ---------------- backward: VB layers"):]
+    py_order = []
+    for m in re.finditer(r"lib\.(vbnn_[a-z0-9_]+)\(|self\.(_reduce)\(", run):
+        name = m.group(1) or "vbnn_allreduce_grads"
+        if not py_order or py_order[-1] != name:
+            py_order.append(name)
+    assert lua_order == py_order, (lua_order, py_order)

@@ -1027,6 +1027,97 @@ def test_rccl_exchange_through_the_c_abi_one_rank(nnmod):
     ex.close()
 
 
+# ------------------------------------------------------------------------------------------- MSE head (BASELINE configs[4])
+@pytest.mark.parametrize("N,D", [(1, 1), (37, 70), (64, 256)])
+def test_mse_criterion_matches_oracle(nnmod, oracle, N, D):
+    """vbnn_mse_forward / _backward == nn.MSECriterion restated (oracle vbo_mse_*): loss 1e-6, gradient 1e-6 relative;
+    the loss accumulates over draws and is bitwise reproducible."""
+    from vbnn_amd import _lib as L
+    from vbnn_amd.engine import _p
+    rng = np.random.default_rng(N * 100 + D)
+    y = rng.normal(0, 1, (N, D)).astype(np.float32)
+    t = rng.normal(0, 1, (N, D)).astype(np.float32)
+    ctx = nnmod.Context.get()
+    yd, td = dev(y), dev(t)
+    g = torch.zeros(N, D, dtype=torch.float32, device="cuda")
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    inv = 1.0 / (N * D)
+    L.check(L.lib().vbnn_mse_forward(ctx.h, _p(yd), D, _p(td), D, N, D, inv, _p(g), D, 0, _p(loss)))
+    l1 = float(host(loss)[0])
+    want = oracle.mse_forward(y, t)
+    assert abs(l1 - want) <= 1e-6 * abs(want) + 1e-12
+    np.testing.assert_allclose(host(g), oracle.mse_backward(y, t), rtol=1e-6, atol=1e-9)
+    L.check(L.lib().vbnn_mse_forward(ctx.h, _p(yd), D, _p(td), D, N, D, inv, None, 0, 1, _p(loss)))
+    assert abs(float(host(loss)[0]) - 2 * l1) <= 1e-12 * abs(l1)
+    g2 = torch.zeros_like(g)
+    L.check(L.lib().vbnn_mse_backward(ctx.h, _p(yd), D, _p(td), D, N, D, inv, _p(g2), D))
+    assert torch.equal(g, g2)
+
+
+@pytest.mark.parametrize("mode", ["lrt", "wn"])
+def test_engine_regression_head_matches_oracle_f32(oracle, nnmod, mode):
+    """The fused engine with the regression head (final Linear to D outputs + MSE, the criterion of BASELINE configs[4])
+    against the module-by-module oracle with the same criterion: fp32, ragged shapes, two draws."""
+    from vbnn_amd.engine import FusedMLP
+    hidden, I0, N, D = [50, 34], 70, 37, 24
+    opt = opt_for(mode, "f32", input_size=I0, hidden=hidden, S=2, fuse_kl=True, n_classes=D, criterion="mse")
+    eng, onet = FusedMLP(opt), oracle.OracleMLP(opt)
+    rng = np.random.default_rng(9)
+    for k, v in enumerate(eng.vb):
+        om = onet.vb[k]
+        lv = rng.normal(np.log(1e-3), 0.3, om.lvars.shape).astype(np.float32)
+        om.means[:] = om.weight; om.lvars[:] = lv
+        v.lvars.copy_(dev(lv))
+        om.compute_prior()
+    x = oracle.fill_normal(N, I0, SEED, 4, 0, 0)
+    t = rng.normal(0, 1, (N, D)).astype(np.float32)
+    eng.resetGradients(); eng.prepare(); onet.resetGradients()
+    werr = 0.0
+    for _ in range(2):
+        eng.sample(); onet.sample()
+        eng.run(dev(x), dev(t))
+        werr += onet.run(x, t)[0]
+    loss, _ = eng.loss_and_accuracy()
+    assert abs(loss - werr) <= 3e-5 * abs(werr) + 1e-6, (loss, werr)
+    for k, v in enumerate(eng.vb):
+        om = onet.vb[k]
+        mle, mlc = om.compute_mugrads(opt)
+        vle, vlc = om.compute_vargrads(opt)
+        np.testing.assert_allclose(host(v.gradWeight), mle + mlc, rtol=0, atol=3e-5 * np.abs(mle + mlc).max() + 1e-10)
+        np.testing.assert_allclose(host(v.gradSum), vle + vlc, rtol=0, atol=2e-4 * np.abs(vle + vlc).max() + 1e-10)
+        np.testing.assert_allclose(host(v.gradBias), om.gradBias, rtol=0, atol=3e-5 * np.abs(om.gradBias).max() + 1e-10)
+    np.testing.assert_allclose(host(eng.gradWeight3), onet.last.gradWeight, rtol=0, atol=3e-5 * np.abs(onet.last.gradWeight).max() + 1e-10)
+    np.testing.assert_allclose(host(eng.gradBias3), onet.last.gradBias, rtol=0, atol=3e-5 * np.abs(onet.last.gradBias).max() + 1e-9)
+
+
+def test_engine_regression_head_bf16_against_rounding_emulation(oracle, nnmod):
+    """configs[4]'s head in bf16 (final Linear 256 -> 256 on the GEMM kernels, MSE) against the float64 emulation."""
+    from oracle.ref_numpy import bf16_round, emulate_lrt_step
+    from vbnn_amd.engine import FusedMLP
+    hidden, I0, N, D = [512, 256], 256, 512, 256
+    opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True, n_classes=D, criterion="mse")
+    eng, onet = FusedMLP(opt), oracle.OracleMLP(opt)
+    for k, v in enumerate(eng.vb):
+        onet.vb[k].means[:] = onet.vb[k].weight
+    x = oracle.fill_normal(N, I0, SEED, 4, 0, 0)
+    xt = dev(x)
+    t = eng.synthetic_targets(xt)
+    eng.resetGradients(); eng.prepare(); eng.sample()
+    eng.run(xt, t)
+    loss, _ = eng.loss_and_accuracy()
+    layers = [dict(means=om.means, lvars=om.lvars, bias=om.bias) for om in onet.vb]
+    zetas = [oracle.fill_normal(N, om.O, SEED, 2, k, 1, 0).astype(np.float64) for k, om in enumerate(onet.vb)]
+    wloss, res, gw3, gb3 = emulate_lrt_step(layers, onet.last.weight, onet.last.bias, x, host(t), zetas, bf16_round, S=1.0, B=opt["B"],
+                                            kl_shadows=eng.kl_from_shadows, criterion="mse")
+    assert abs(loss - wloss) <= 1e-4 * abs(wloss), (loss, wloss)
+    for k, v in enumerate(eng.vb):
+        for got, want, what in ((v.gradWeight, res[k]["grad_mu"], "d/dmeans"), (v.gradSum, res[k]["grad_lv"], "d/dlvars"), (v.gradBias, res[k]["gradBias"], "gradBias")):
+            fro = np.linalg.norm(host(got) - want) / np.linalg.norm(want)
+            assert fro <= 2e-3, f"layer {k} {what}: {fro:.3e}"
+    assert np.linalg.norm(host(eng.gradWeight3) - gw3) <= 2e-3 * np.linalg.norm(gw3)
+    assert np.linalg.norm(host(eng.gradBias3) - gb3) <= 2e-3 * np.linalg.norm(gb3)
+
+
 # ------------------------------------------------------------------------------------------- errors
 def test_error_convention(nnmod):
     """Non-zero status + message instead of a crash (SURVEY 8b error convention)."""

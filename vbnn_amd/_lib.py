@@ -117,6 +117,8 @@ _SIGS = {
     "vbnn_head_forward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _f, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "vbnn_head_backward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp,
                            _vp, _i64, _vp, _vp, _i64], _i),
+    "vbnn_mse_forward": ([_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f, _vp, _i64, _i, _vp], _i),
+    "vbnn_mse_backward": ([_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f, _vp, _i64], _i),
     "vbnn_nll_forward": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp], _i),
     "vbnn_nll_backward": ([_vp, _vp, _i64, _i64, _f, _vp], _i),
     "vbnn_logsoftmax_backward": ([_vp, _vp, _vp, _vp, _i64, _i64], _i),

@@ -468,6 +468,67 @@ extern "C" int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t l
     VBNN_API_END
 }
 
+// ---------------------------------------------------------------------------------- MSE criterion (configs[4])
+// One pass over y and target (8 B read + 4 B written per output element, HBM-bound): g = 2 inv_nd (y - t) and the block
+// partials of sum (y - t)^2; the last launch of the pair adds the partials in a fixed order.
+__global__ __launch_bounds__(256) void k_mse(const float* __restrict__ y, int64_t ld_y, const float* __restrict__ t, int64_t ld_t,
+                                             int64_t N, int64_t D, float inv_nd, float* g, int64_t ld_g, double* partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    const bool vec = ((D & 3) == 0) && ((ld_y & 3) == 0) && ((ld_t & 3) == 0) && ((ld_g & 3) == 0) &&
+                     ((((uintptr_t)y | (uintptr_t)t | (uintptr_t)g) & 15u) == 0);
+    const int64_t D4 = (D + 3) >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N * D4; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / D4, d = (i - n * D4) * 4;
+        const int valid = (int)min((int64_t)4, D - d);
+        float yv[4], tv[4], gv[4];
+        load4<float>(y + n * ld_y + d, yv, valid, vec);
+        load4<float>(t + n * ld_t + d, tv, valid, vec);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float df = (j < valid) ? yv[j] - tv[j] : 0.f;
+            acc += (double)df * (double)df;
+            gv[j] = 2.0f * inv_nd * df;
+        }
+        if (g) store4<float>(g + n * ld_g + d, gv[0], gv[1], gv[2], gv[3], valid, vec);
+    }
+    if (partial) {
+        const double r = block_sum(acc, sh);
+        if (threadIdx.x == 0) partial[blockIdx.x] = r;
+    }
+}
+__global__ __launch_bounds__(256) void k_mse_finish(const double* partial, int nb, double scale, int accumulate, double* loss) {
+    __shared__ double sh[4];
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) a += partial[b];
+    const double r = block_sum(a, sh);
+    if (threadIdx.x == 0) loss[0] = (accumulate ? loss[0] : 0.0) + scale * r;
+}
+static int mse_launch(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* t, int64_t ld_t, int64_t N, int64_t D, float inv_nd,
+                      float* g, int64_t ld_g, int accumulate, double* loss) {
+    const int nb = grid_for(N * ((D + 3) / 4), 256 * 4);
+    if ((size_t)nb > ctx->scratch_doubles) { vbnn_set_error("scratch"); return VBNN_ERR_INVALID; }
+    hipLaunchKernelGGL(k_mse, dim3(nb), dim3(256), 0, ctx->stream, y, ld_y, t, ld_t, N, D, inv_nd, g, ld_g, loss ? ctx->scratch : nullptr);
+    if (loss) hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(256), 0, ctx->stream, ctx->scratch, nb, (double)inv_nd, accumulate, loss);
+    return vbnn_check_launch("k_mse");
+}
+extern "C" int vbnn_mse_forward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* target, int64_t ld_t, int64_t N, int64_t D,
+                                float inv_nd, float* g, int64_t ld_g, int accumulate, double* loss_sum_dev) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && y && target && loss_sum_dev, "null argument");
+    VBNN_REQUIRE(N > 0 && D > 0 && ld_y >= D && ld_t >= D && (!g || ld_g >= D), "shape");
+    return mse_launch(ctx, y, ld_y, target, ld_t, N, D, inv_nd, g, ld_g, accumulate, loss_sum_dev);
+    VBNN_API_END
+}
+extern "C" int vbnn_mse_backward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* target, int64_t ld_t, int64_t N, int64_t D,
+                                 float inv_nd, float* g, int64_t ld_g) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && y && target && g, "null argument");
+    VBNN_REQUIRE(N > 0 && D > 0 && ld_y >= D && ld_t >= D && ld_g >= D, "shape");
+    return mse_launch(ctx, y, ld_y, target, ld_t, N, D, inv_nd, g, ld_g, 0, nullptr);
+    VBNN_API_END
+}
+
 // ---------------------------------------------------------------------------------- separate criterion modules
 // nn.ClassNLLCriterion (sizeAverage): forward value, backward gradient; nn.LogSoftMax:updateGradInput.
 // Used by the module-level path (mlp.lua:78-80 call order); the fused kernel above is the fast path.

@@ -38,6 +38,10 @@ class FusedMLP:
         self.reduce = world_size > 1 or force_reduce
         self._exchange = None                 # made on first use (vbnn_amd/comm.py): RCCL through the C ABI
         self.fuse_kl = bool(opt.get("fuse_kl", True))
+        # "nll": LogSoftMax + ClassNLLCriterion (mlp.lua:30-32); "mse": nn.MSECriterion on the final Linear's outputs
+        # (BASELINE.json configs[4], a regression target of n_classes dimensions -- not in the reference)
+        self.criterion = opt.get("criterion", "nll")
+        assert self.criterion in ("nll", "mse")
         self.kl_from_shadows = self.dtype == "bf16" and bool(opt.get("kl_from_shadows", True))
         # optional second HIP stream (+ its own context, hence its own reduction scratch) for the accGradParameters
         # GEMMs. Measured on MI355X (wide config): 1.32 ms with, 1.29 ms without -- two 512-block GEMMs sharing the
@@ -127,7 +131,7 @@ class FusedMLP:
         km_ok = (self.opt.get("dtype", "f32") == "bf16") and not self.opt.get("keep_transposes", False)
         need_prepare = False
         for li, v in enumerate(self.vb):
-            last_fused = (v is self.vb[-1]) and self.n_classes <= 16
+            last_fused = (v is self.vb[-1]) and self.n_classes <= 16 and self.criterion == "nll"
             v.bias_from_dw = (v.I % 256 != 0) and not last_fused
             km = lib.vbnn_kmajor_supported_dw(v.I, v.O, N, 1 if v.bias_from_dw else 0) if (
                 km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1) else 0
@@ -268,18 +272,27 @@ class FusedMLP:
                                       v.muT_s.ld if v.muT_s else 0))
 
     # ---- final Linear + criterion through the generic GEMM kernels (class counts above 16)
-    def _generic_head(self, N, targets, inv_n, accumulate):
+    def _generic_head(self, N, targets, inv_n, accumulate, backward=True):
         lib, ctx, code = L.lib(), self.ctx.h, self.code
         lrt = self._lrt()
         H, Cn = self.sizes[-1], self.n_classes
         a = L.FwdArgs(w=self.w3_s.ptr, w2=None, x=self.h_s.ptr, x2=None, ld_w=self.w3_s.ld, ld_x=self.h_s.ld,
                       N=N, I=H, O=Cn, bias=_p(self.bias3), y=_p(self.logits), ld_y=Cn)
         L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
-        if not accumulate:                          # vbnn_logsoftmax_nll adds into its accumulators
-            L.check(lib.vbnn_buf_zero(ctx, _p(self._acc), 16))
-            L.check(lib.vbnn_buf_zero(ctx, _p(self._corr), 4))
-        L.check(lib.vbnn_logsoftmax_nll(ctx, _p(self.logits), Cn, _p(targets), N, Cn, inv_n, _p(self.out),
-                                        _p(self.g_logits), _p(self._acc), _p(self._corr)))
+        if self.criterion == "mse":
+            assert targets.dtype == torch.float32 and tuple(targets.shape) == (N, Cn) and targets.is_contiguous()
+            L.check(lib.vbnn_mse_forward(ctx, _p(self.logits), Cn, _p(targets), Cn, N, Cn, inv_n / Cn, _p(self.g_logits), Cn,
+                                         accumulate, _p(self._acc)))
+            if not accumulate:
+                L.check(lib.vbnn_buf_zero(ctx, _p(self._corr), 4))
+        else:
+            if not accumulate:                          # vbnn_logsoftmax_nll adds into its accumulators
+                L.check(lib.vbnn_buf_zero(ctx, _p(self._acc), 16))
+                L.check(lib.vbnn_buf_zero(ctx, _p(self._corr), 4))
+            L.check(lib.vbnn_logsoftmax_nll(ctx, _p(self.logits), Cn, _p(targets), N, Cn, inv_n, _p(self.out),
+                                            _p(self.g_logits), _p(self._acc), _p(self._corr)))
+        if not backward:
+            return
         L.check(lib.vbnn_pack(ctx, code, L.PACK_COPY, _p(self.g_logits), None, Cn, N, Cn, self.g3_s.ptr, self.g3_s.ld,
                               self.g3T_s.ptr, self.g3T_s.ld))
         d = L.DwArgs(xT=self.hT_s.ptr, x2T=None, gT=self.g3T_s.ptr, gvT=None, ld_n=self.hT_s.ld, N=N, I=H, O=Cn,
@@ -307,7 +320,7 @@ class FusedMLP:
                          h=self.h_s.ptr if last else nxt.x_s.ptr,
                          h2=None if (last or not lrt) else nxt.x2_s.ptr,
                          ld_h=self.h_s.ld if last else nxt.x_s.ld,
-                         hT=(None if self.n_classes <= 16 else self.hT_s.ptr) if last else (nxt.xT_s.ptr if nxt.xT_s else None),
+                         hT=(None if (self.n_classes <= 16 and self.criterion == "nll") else self.hT_s.ptr) if last else (nxt.xT_s.ptr if nxt.xT_s else None),
                          h2T=None if (last or not lrt or not nxt.x2T_s) else nxt.x2T_s.ptr,
                          ld_hT=self.hT_s.ld if last else (nxt.xT_s.ld if nxt.xT_s else 0))
 
@@ -370,7 +383,7 @@ class FusedMLP:
                 L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
         H, Cn = self.sizes[-1], self.n_classes
         vl = self.vb[-1]
-        fused_head = Cn <= 16
+        fused_head = Cn <= 16 and self.criterion == "nll"
         if fused_head:
             # ---------------- fused classifier head (mlp.lua:29-32): streaming kernels, no 10-wide MFMA tiles
             L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
@@ -386,7 +399,10 @@ class FusedMLP:
                                            vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr if vl.gT_s else None,
                                            vl.gvT_s.ptr if (lrt and vl.gvT_s) else None, vl.gT_s.ld if vl.gT_s else 0))
         else:
-            self._generic_head(N, targets, inv_n, accumulate)
+            self._generic_head(N, targets, inv_n, accumulate, backward)
+            if not backward:
+                self._first = False
+                return
         # ---------------- backward: VB layers, last to first. accGradParameters (+ bias gradient + the bucket's
         # all-reduce) of layer li and updateGradInput of layer li are independent of each other (both consume
         # g_li): with `overlap` they run on two HIP streams, so the HBM-bound epilogue of one GEMM sits beside the
@@ -477,8 +493,14 @@ class FusedMLP:
         return out
 
     def synthetic_targets(self, x, row0=0):
-        """bench / tests: class targets uniform in 0..n_classes-1 by GLOBAL row (data.lua:16 convention, 0-based)."""
+        """bench / tests: class targets uniform in 0..n_classes-1 by GLOBAL row (data.lua:16 convention, 0-based); for the
+        regression criterion y* = x R / sqrt(I) with a fixed Philox-drawn R -- data
+        preparation outside the timed step, so a plain torch matmul."""
         N = x.shape[0]
+        if self.criterion == "mse":
+            R = torch.empty(x.shape[1], self.n_classes, dtype=torch.float32, device=x.device)
+            fill_normal(R, self.seed, L.STREAM_DATA, 1, 0)
+            return (x @ R / math.sqrt(x.shape[1])).contiguous()
         return ((torch.arange(N, device=x.device, dtype=torch.int64) + row0) * 2654435761 % self.n_classes).to(torch.int32)
 
     # ---- mlp:update + VBLinear:update (mlp.lua:117-142, VBLinear.lua:124-166) on the device: the dW epilogue
