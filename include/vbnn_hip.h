@@ -209,6 +209,12 @@ typedef struct vbnn_dw_args {
      * instead of 8, and no exp -- i.e. d/dlvars = (gv^T x.x) . s2 + KL'(s2), d/dmeans = g^T x + KL'(mu) with s2, mu the
      * values the forward GEMMs multiplied by (bf16-rounded); means / lvars are then not read. NULL: fp32 means / lvars. */
     const void* mu_s; const void* var_s; int64_t ld_w;
+    /* 0 (default): both GEMMs of the LRT pair, every output. 1: only the first GEMM (g^T x) and what depends on it
+     * (gradWeight / grad_mu, gradBias); 2: only the second (gv^T x.x) and what depends on it (gradSum / grad_lv). Calling
+     * with part = 2 and then part = 1 gives bit for bit the outputs of part = 0 (each output depends on ONE accumulator)
+     * as two launches -- so that a data-parallel host can start the exchange of the finished d/dlvars while the d/dmeans
+     * GEMM still runs (vbnn_allreduce_grads between the two calls). LRT pairs only. */
+    int part;
 } vbnn_dw_args;
 
 /* accGradParameters (VBLinear.lua:112-118), one GEMM instead of the reference's two. */

@@ -37,7 +37,7 @@ function FusedMLP.new(opt)
     local sizes = { opt.input_size }
     for _, h in ipairs(opt.hidden) do sizes[#sizes + 1] = h end
     self.sizes = sizes
-    -- gradient arena: [d/dmeans | d/dlvars | d/dbias] per VB layer, then the final Linear (vbnn_amd/partition.py)
+    -- gradient arena: [d/dlvars | d/dmeans | d/dbias] per VB layer, then the final Linear (vbnn_amd/partition.py)
     local total = 0
     for li = 1, #sizes - 1 do total = total + 2 * sizes[li] * sizes[li + 1] + sizes[li + 1] end
     total = total + sizes[#sizes] * self.n_classes + self.n_classes
@@ -51,7 +51,7 @@ function FusedMLP.new(opt)
         local v = { I = I, O = O, layer_id = li - 1, bucket_off = off }
         v.means, v.lvars, v.bias = vb.alloc(O * I * 4), vb.alloc(O * I * 4), vb.alloc(O * 4)
         v.m_mu, v.v_mu, v.m_lv, v.v_lv = vb.alloc(O * I * 4), vb.alloc(O * I * 4), vb.alloc(O * I * 4), vb.alloc(O * I * 4)
-        v.grad_mu, v.grad_lv, v.gradBias = take(O * I), take(O * I), take(O)
+        v.grad_lv, v.grad_mu, v.gradBias = take(O * I), take(O * I), take(O)
         v.bucket_n = off - v.bucket_off
         v.stats = vb.alloc(32)
         v.mu_s, v.var_s = packed(O, I, self.esize), packed(O, I, self.esize)
@@ -168,13 +168,23 @@ function FusedMLP:run(inputs, ld, targets, N)
         d.gradBias = v.bias_from_dw and v.gradBias or nil
         d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_s.p, v.x2_s.p, v.g_s.p, v.gv_s.p, v.x_s.ld, v.g_s.ld
         d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
+        local msg_off, early = v.bucket_off, self.comm and v.O * v.I >= 2 ^ 22
+        if early then
+            -- two launches (vbnn_dw_args.part): the sigma^2 GEMM and d/dlvars first, whose exchange then starts while the
+            -- mu GEMM still runs (d/dlvars is the first block of the layer's bucket)
+            d.part = 2
+            check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, d))
+            check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + v.bucket_off, v.O * v.I))
+            d.part = 1
+            msg_off = v.bucket_off + v.O * v.I
+        end
         check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, d))
         if li < #self.vb and not v.bias_from_dw then
             check(C.vbnn_acc_grad_bias(vb.ctx, self.dtype, v.g_s.p, v.g_s.ld, N, v.O, 1, accumulate, v.gradBias))
         end
         if self.comm then                                         -- the final Linear's gradients ride in the last layer's message
-            local n = (li == #self.vb) and (self.n_grads - v.bucket_off) or v.bucket_n
-            check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + v.bucket_off, n))
+            local n = ((li == #self.vb) and self.n_grads or (v.bucket_off + v.bucket_n)) - msg_off
+            check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + msg_off, n))
         end
         if li > 1 then
             local p = self.vb[li - 1]

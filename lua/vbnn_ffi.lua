@@ -87,6 +87,7 @@ typedef struct vbnn_dw_args {
     float* gradBias;
     const void* x; const void* x2; const void* g; const void* gv; int64_t ld_x; int64_t ld_g;
     const void* mu_s; const void* var_s; int64_t ld_w;
+    int part;
 } vbnn_dw_args;
 int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
 int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O,

@@ -55,7 +55,7 @@ def _rank_step(rank, world, layers, w3, b3, x, t, outs, B):
     zetas = [vo.fill_normal(n_loc, O, 3, vo.STREAM_ZETA, k, 1, r0).astype(np.float64) for k, O in enumerate(outs)]
     loss, res, gw3, gb3 = emulate_lrt_step(layers, w3, b3, xs, ts, zetas, S=1.0, B=B, inv_n=sc["inv_n"])
     sizes = [x.shape[1]] + list(outs)
-    lay, fin, total, buckets = partition.arena_layout(sizes, w3.shape[0])
+    lay, fin, total, buckets = partition.arena_layout(sizes, w3.shape[0], early_lv=[False] + [True] * (len(sizes) - 2))
     arena = np.zeros(total, np.float64)
 
     def put(span, a):
@@ -90,7 +90,8 @@ def _worker(rank, world, port, q):
     buf = torch.from_numpy(flat.copy())
     lbuf = torch.tensor([loss], dtype=torch.float64)
     ex = TorchExchange()
-    assert sorted(buckets) == [(0, buckets[-1][1]), (buckets[0][0], flat.size)] and buckets[0][0] == buckets[-1][1]   # the whole arena, once
+    cov = sorted(buckets)
+    assert cov[0][0] == 0 and cov[-1][1] == flat.size and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))   # the whole arena, once
     partition.exchange_step(buf, buckets, ex)                 # the messages of FusedMLP.run + finish, in issue order
     ex.allreduce(lbuf); ex.finish()
     if rank == 0:
@@ -139,3 +140,10 @@ def test_partition_host_logic():
     assert buckets[0] == (lay[1]["bucket"][0], total)           # last VB layer + final Linear first
     deep = partition.arena_layout([4096] * 9, 10)
     assert len(deep[3]) == 8 and deep[2] == 8 * (2 * 4096 * 4096 + 4096) + 10 * 4096 + 10
+    # early d/dlvars messages: the last layer's d/dlvars leaves first, then [d/dmeans | d/dbias | final Linear]
+    lay, fin, total, buckets = partition.arena_layout([784, 4096, 4096], 10, early_lv=[False, True])
+    W = 4096 * 4096
+    assert buckets[0] == (lay[1]["lv"][0], lay[1]["lv"][0] + W) and buckets[1] == (lay[1]["mu"][0], total)
+    assert buckets[2] == lay[0]["bucket"] and len(buckets) == 3
+    covered = sorted(buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))

@@ -1118,6 +1118,34 @@ def test_engine_regression_head_bf16_against_rounding_emulation(oracle, nnmod):
     assert np.linalg.norm(host(eng.gradBias3) - gb3) <= 2e-3 * np.linalg.norm(gb3)
 
 
+@pytest.mark.parametrize("dtype,hidden,I0,N", [("f32", [50, 34], 70, 37), ("bf16", [512, 256], 256, 512), ("bf16", [4096, 4096], 784, 4096)])
+def test_early_dlvars_message_is_bitwise_the_fused_launch(oracle, nnmod, dtype, hidden, I0, N):
+    """The data-parallel overlap lever: accGradParameters as TWO launches (vbnn_dw_args.part = 2, then 1),
+    so that the exchange of the finished d/dlvars starts while the d/dmeans GEMM still runs. Every output depends on one
+    accumulator of the pair, so the gradients must equal the single launch's BIT FOR BIT (general kernel, pipelined kernel
+    and the two-pass kernel at the bench's size); with a world of one the RCCL exchange runs between the launches."""
+    from vbnn_amd.engine import FusedMLP
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    arenas = []
+    for early, reduce in ((False, False), (True, False), (True, True)):
+        opt = opt_for("lrt", dtype, input_size=I0, hidden=hidden, S=1, fuse_kl=True, early_lv=early)
+        eng = FusedMLP(opt, force_reduce=reduce)
+        assert eng.early_lv == [early] * len(hidden)
+        t = eng.synthetic_targets(x)
+        eng.prepare(); eng.resetGradients(); eng.sample()
+        eng.run(x, t)
+        eng.finish()
+        loss, _ = eng.loss_and_accuracy()
+        if reduce:
+            assert eng.comm_backend() == "vbnn_comm/rccl" and len(eng.buckets()) == len(hidden) + sum(eng._early(v) for v in eng.vb)
+            assert eng._early(eng.vb[-1])
+        arenas.append((eng.grads.clone(), loss))
+        del eng
+    for g, l in arenas[1:]:
+        assert torch.equal(g, arenas[0][0]) and l == arenas[0][1]
+
+
 # ------------------------------------------------------------------------------------------- errors
 def test_error_convention(nnmod):
     """Non-zero status + message instead of a crash (SURVEY 8b error convention)."""

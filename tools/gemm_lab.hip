@@ -11,6 +11,7 @@
 #include <algorithm>
 #include "../vbnn_amd/csrc/common.h"
 void vbnn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
+int vbnn_cu_count() { return 256; }
 #include "../vbnn_amd/csrc/gemm_v2.h"
 #include "../vbnn_amd/csrc/gemm_v3.h"
 

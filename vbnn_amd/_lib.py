@@ -69,7 +69,7 @@ class DwArgs(C.Structure):
                 ("lvars", _vp), ("grad_mu", _vp), ("grad_lv", _vp), ("means", _vp), ("stats", _vp),
                 ("B", _f), ("S", _f), ("kl_scale", _f), ("gradBias", _vp),
                 ("x", _vp), ("x2", _vp), ("g", _vp), ("gv", _vp), ("ld_x", _i64), ("ld_g", _i64),
-                ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64)]
+                ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64), ("part", _i)]
 
 
 _SIGS = {

@@ -11,6 +11,19 @@ void vbnn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int vbnn_cu_count() {
+    static int cus = 0;
+    if (cus <= 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        else
+            return 256;                                       // no device visible (host-side shape queries): MI355X
+    }
+    return cus;
+}
+
 extern "C" int vbnn_abi_version(void) { return VBNN_ABI_VERSION; }
 extern "C" const char* vbnn_last_error(void) { return g_err; }
 

@@ -27,6 +27,17 @@ constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TILES = 16, VBNN_CNT_TILES_MAX = 1
 
 void vbnn_set_error(const char* fmt, ...);
 
+// hipFuncSetAttribute (the dynamic-LDS opt-in of the pipelined kernels) is per DEVICE: a per-instantiation flag that
+// remembers "done" must remember it per device, or the second GPU of a process launches unconfigured kernels.
+constexpr int VBNN_MAX_DEVICES = 64;
+struct vbnn_per_device_flag {
+    bool done[VBNN_MAX_DEVICES] = {};
+    bool& operator[](int device) { return done[(device >= 0 && device < VBNN_MAX_DEVICES) ? device : 0]; }
+};
+// compute units of the device the shape heuristics plan for (all GPUs of a node are one model): read once from the
+// current device instead of assuming MI355X's 256
+int vbnn_cu_count();
+
 #define VBNN_CHECK_HIP(expr)                                                             \
     do {                                                                                 \
         hipError_t _e = (expr);                                                          \

@@ -533,9 +533,13 @@ struct EpiDw {
         return *reinterpret_cast<const bf16x4*>(p + ((int64_t)un * ld_w + um) + ln.os);
     }
     __device__ __forceinline__ Pre load_fast(int um, int un, const Lane& ln) const {
+        // two UNCONDITIONAL loads whatever the part (a branch around a load costs one load latency per position): a
+        // one-GEMM launch reads its one tensor twice from the same address instead
+        const bf16_t* pa = part == 1 ? mu_s : var_s;
+        const bf16_t* pb = part == 2 ? var_s : mu_s;
         Pre p;
-        p.lv = part != 1 ? shadow4(var_s, um, un, ln) : bf16x4{};
-        p.mu = part != 2 ? shadow4(mu_s, um, un, ln) : bf16x4{};
+        p.lv = shadow4(pa, um, un, ln);
+        p.mu = shadow4(pb, um, un, ln);
         return p;
     }
     __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre& pre, float (&t1)[4],

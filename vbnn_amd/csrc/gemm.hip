@@ -149,8 +149,22 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
     e.mu_s = shadows ? (const bf16_t*)a->mu_s : nullptr; e.var_s = shadows ? (const bf16_t*)a->var_s : nullptr; e.ld_w = shadows ? (int)a->ld_w : 0;
     e.I = (int)a->I; e.O = (int)a->O;
     const int64_t M = a->I + (a->gradBias ? 1 : 0);          // the ones row of xT (K-major: column I of x) rides along as one more output row
-    const bool dual = e.lrt != 0;
-    int st = VBNN_OK;                                        // K-major x, g first (no transposed copies needed)
+    int st = VBNN_OK;
+    if (a->part == 1 || a->part == 2) {
+        // ONE GEMM of the pair and the outputs that depend on it (vbnn_dw_args.part): single-accumulator launches with the
+        // functor told which accumulator it holds (EpiDw::part, as the pair-split launches do inside one grid)
+        e.part = a->part;
+        const bool second = a->part == 2;
+        const void* xk = second ? a->x2 : a->x;   const void* gk = second ? a->gv : a->g;
+        const void* xt = second ? a->x2T : a->xT; const void* gt = second ? a->gvT : a->gT;
+        if (second) e.gradBias = nullptr;
+        const int64_t Mp = second ? a->I : M;
+        if (!(a->gradBias && !second) &&
+            try_kmajor<T, false, true, true>(ctx, xk, nullptr, a->ld_x, gk, nullptr, a->ld_g, a->I, a->O, a->N, e, &st))
+            return st;
+        return launch_gemm<T, false>(ctx, xt, nullptr, a->ld_n, gt, nullptr, a->ld_n, Mp, a->O, a->N, e);
+    }
+    const bool dual = e.lrt != 0;                            // K-major x, g first (no transposed copies needed)
     if (!a->gradBias &&
         (dual ? try_kmajor<T, true, true, true>(ctx, a->x, a->x2, a->ld_x, a->g, a->gv, a->ld_g, a->I, a->O, a->N, e, &st)
               : try_kmajor<T, false, true, true>(ctx, a->x, nullptr, a->ld_x, a->g, nullptr, a->ld_g, a->I, a->O, a->N, e, &st)))
@@ -226,6 +240,7 @@ extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_
     VBNN_REQUIRE(!((a->x2T || a->x2) && (a->gradSum || a->grad_lv)) || a->lvars, "LRT gradSum/grad_lv need lvars");
     VBNN_REQUIRE(!(a->grad_mu || a->grad_lv) || (a->means && a->lvars && a->stats && a->B > 0 && a->S > 0),
                  "fused total gradients need means, lvars, stats, B, S");
+    VBNN_REQUIRE(a->part >= 0 && a->part <= 2 && (a->part == 0 || a->x2T || a->x2), "part: 0, or 1 / 2 of an LRT pair");
     if (dtype == VBNN_F32) return acc_grad_t<float>(ctx, a);
     if (dtype == VBNN_BF16) return acc_grad_t<bf16_t>(ctx, a);
     vbnn_set_error("unsupported dtype %d", dtype);

@@ -645,13 +645,12 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
                  : sched == 2 ? (const void*)gemm_nt_v2<DUAL, 2, 4, 3, Epi> : (const void*)gemm_nt_v2<DUAL, 4, 4, 3, Epi>;
             threads = 512; lds_bytes = v2_lds(4, 3); bm = 256;
         }
-        static bool configured[5][3] = {{false, false, false}, {false, false, false}, {false, false, false}, {false, false, false},
-                                        {false, false, false}};   // per instantiation
+        static vbnn_per_device_flag configured[5][3];      // per instantiation and device
         const int vi = psplit ? (kmajor ? 4 : 3) : vi0;
-        if (!configured[vi][si]) {
+        if (!configured[vi][si][ctx->device]) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
-            configured[vi][si] = true;
+            configured[vi][si][ctx->device] = true;
         }
         const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + V2_BN - 1) / V2_BN;
         int ksplit_ = split ? 2 : 1;

@@ -788,18 +788,18 @@ static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t K, int64_t lda
 // shape part of the choice (also answers vbnn_kmajor_supported: the host decides from it whether to keep transposed copies)
 static inline bool gemm_v3_shape_ok(int64_t M, int64_t N, int64_t K) {
     if (M % V3_BM || N % V3_BN || K < g_v3_min_k) return false;
-    const int64_t cus = 256;
+    const int64_t cus = vbnn_cu_count();
     const int64_t t3 = (M / V3_BM) * (N / V3_BN), t2 = 2 * t3;
-    if (t3 < 192) return false;
+    if (4 * t3 < 3 * cus) return false;
     const int64_t r3 = (t3 + cus - 1) / cus, r2 = (t2 + cus - 1) / cus;
     return 185 * r3 <= 100 * r2;
 }
 template <class Epi>
 static inline bool gemm_v3_eligible(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, bool ak, bool bk, const Epi& epi) {
     if (!gemm_v3_possible(M, N, K, lda, ldb, ak, bk, epi) || K < g_v3_min_k) return false;
-    const int64_t cus = 256;
+    const int64_t cus = vbnn_cu_count();
     const int64_t t3 = (M / V3_BM) * (N / V3_BN), t2 = 2 * t3;
-    if (t3 < 192) return false;                               // fewer than 3/4 of the CUs busy: the half-size tiles win
+    if (4 * t3 < 3 * cus) return false;                       // fewer than 3/4 of the CUs busy: the half-size tiles win
     const int64_t r3 = (t3 + cus - 1) / cus, r2 = (t2 + cus - 1) / cus;
     return 185 * r3 <= 100 * r2;
 }
@@ -833,7 +833,8 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         }
         float* park = ctx->park;
         const void* kern = (const void*)gemm_nt_v3<DUAL, AK, BK, Epi>;
-        static bool configured = false;                      // per instantiation
+        static vbnn_per_device_flag configured_on;           // per instantiation and device
+        bool& configured = configured_on[ctx->device];
         if (!configured) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
@@ -861,7 +862,8 @@ static inline bool gemm_v3_split_shape_ok(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + V3_BM - 1) / V3_BM) * (N / V3_BN);
     if (tiles * 2 > VBNN_CNT_TILES_MAX) return false;
     if (g_v3_split == 1) return true;
-    return tiles * 2 <= 160 && tiles * 4 >= 192 && K >= 2048;
+    const int64_t cus = vbnn_cu_count();
+    return tiles * 16 <= 5 * cus && tiles * 16 >= 3 * cus && K >= 2048;      // pair split alone <= 5/8 of the CUs, with the K split >= 3/4
 }
 // the pitch of the K rows of A the split launch needs: whole 256-column tiles (the columns past M are zero padding)
 static inline int64_t gemm_v3_split_lda(int64_t M) { return (M + V3_BM - 1) / V3_BM * V3_BM; }
@@ -888,7 +890,8 @@ static int launch_gemm_v3_split(vbnn_ctx* ctx, const T* A, const T* A2, int64_t 
             ctx->park_bytes = need;
         }
         const void* kern = (const void*)gemm_nt_v3<false, true, true, Epi, true>;
-        static bool configured = false;
+        static vbnn_per_device_flag configured_on;
+        bool& configured = configured_on[ctx->device];
         if (!configured) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }

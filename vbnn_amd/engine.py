@@ -58,7 +58,17 @@ class FusedMLP:
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         # ---- gradient arena: [gradWeight | gradSum | gradBias] per VB layer, then the final Linear (partition.arena_layout)
-        lay, fin, n_g, self._bucket_ranges = partition.arena_layout(sizes, self.n_classes)
+        # early_lv: layers whose accGradParameters runs as two launches (d/dlvars first) so that its exchange starts one
+        # GEMM earlier; default: the big layers of a data-parallel run
+        el = opt.get("early_lv", None)
+        if el is None:
+            el = [(world_size > 1 or force_reduce) and self.mode == "lrt" and bool(opt.get("fuse_kl", True)) and
+                  sizes[i] * sizes[i + 1] >= (1 << 22) for i in range(len(hidden))]
+        elif isinstance(el, bool):
+            el = [el and self.mode == "lrt"] * len(hidden)
+        self.early_lv = list(el)
+        lay, fin, n_g, self._bucket_ranges = partition.arena_layout(sizes, self.n_classes, self.early_lv)
+        self._lay = lay
         self.grads = torch.zeros(n_g, **f32)
 
         def take(span, shape):
@@ -97,6 +107,9 @@ class FusedMLP:
         # the final Linear's gradients sit right behind the last VB layer's in the arena: ONE all-reduce covers both (the
         # head's backward finishes before that layer's accGradParameters is even launched), a collective fewer per step
         self.bucket_tail = self.grads[lay[-1]["bucket"][0]:fin["bucket"][1]]
+        for li, v in enumerate(self.vb):                         # the layer's message(s): [d/dlvars] early (optional), the rest late
+            v.msg_early = self.grads[lay[li]["early"][0]:lay[li]["early"][1]] if lay[li]["early"] else None
+            v.msg_late = self.grads[lay[li]["late"][0]:lay[li]["late"][1]]
         self.w3_s = _Packed(self.n_classes, H, self.tdt, dev)
         self.w3T_s = _Packed(H, self.n_classes, self.tdt, dev)
         self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -137,6 +150,9 @@ class FusedMLP:
                 km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1) else 0
             v.dw_km = km > 0
             v.x_pad256 = km == 2         # the split launch of gemm_v3 reads x / x.x in whole 256-column tiles
+            # the two-launch form of accGradParameters (early d/dlvars message) needs either the transposed operands or the
+            # plain K-major launch of the two-pass kernel; the few-tile K-major launches compute both GEMMs in one grid
+            v.early_ok = (not v.dw_km) or bool(not v.bias_from_dw and lib.vbnn_kmajor_supported(v.I, v.O, N))
             v.dx_km = bool(km_ok and li > 0 and lib.vbnn_kmajor_supported(v.I, N, v.O))
             use_muT = (li > 0) and not v.dx_km
             if use_muT and not getattr(v, "use_muT", True):
@@ -303,8 +319,8 @@ class FusedMLP:
         dx = L.DxArgs(wT=self.w3T_s.ptr, w2T=None, g=self.g3_s.ptr, gv=None, ld_wT=self.w3T_s.ld, ld_g=self.g3_s.ld,
                       N=N, I=H, O=Cn, x=self.h_s.ptr, ld_x=self.h_s.ld, gx=None, ld_gx=0, relu_mask=1,
                       r_prev=_p(vl.r) if lrt else None, ld_r_prev=vl.O, r_prev_packed=1, g_prev=vl.g_s.ptr,
-                      gv_prev=vl.gv_s.ptr if lrt else None, ld_gp=vl.g_s.ld, gT_prev=vl.gT_s.ptr,
-                      gvT_prev=vl.gvT_s.ptr if lrt else None, ld_gpT=vl.gT_s.ld)
+                      gv_prev=vl.gv_s.ptr if lrt else None, ld_gp=vl.g_s.ld, gT_prev=vl.gT_s.ptr if vl.gT_s else None,
+                      gvT_prev=vl.gvT_s.ptr if (lrt and vl.gvT_s) else None, ld_gpT=vl.gT_s.ld if vl.gT_s else 0)
         L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
 
     # ---- argument blocks of the three GEMM families for VB layer `li` (also used by bench.py to time
@@ -412,11 +428,18 @@ class FusedMLP:
                 v = self.vb[li]
                 d = self._dw_args(li, N, accumulate)
                 with self._probed("accGradParameters", li):
+                    if self._early(v, lrt):
+                        # two launches (vbnn_dw_args.part): the sigma^2 GEMM and d/dlvars first -- its exchange starts while the
+                        # mu GEMM still runs
+                        d.part = 2
+                        L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+                        self._reduce(v.msg_early)
+                        d.part = 1
                     L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
                 # the fused head already summed the last layer's g columns; ones-row layers got theirs from the GEMM
                 if not (fused_head and li == nl - 1) and not v.bias_from_dw:
                     L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
-                self._reduce(self.bucket_tail if li == nl - 1 else v.bucket)
+                self._reduce(v.msg_late if self._early(v, lrt) else (self.bucket_tail if li == nl - 1 else v.bucket))
                 if li > 0:
                     dx = self._dx_args(li, N)
                     with self._probed("updateGradInput", li):
@@ -466,9 +489,19 @@ class FusedMLP:
         if self._exchange is not None:
             self._exchange.finish()
 
+    def _early(self, v, lrt=True):
+        return v.msg_early is not None and lrt and self.fuse_kl and getattr(v, "early_ok", True)
+
     def buckets(self):
         """The all-reduce messages of one step, in issue order (last VB layer + final Linear first)."""
-        return [self.grads[s:e] for s, e in self._bucket_ranges]
+        out, nl = [], len(self.vb)
+        for li in range(nl - 1, -1, -1):
+            v = self.vb[li]
+            if self._early(v):
+                out += [v.msg_early, v.msg_late]
+            else:
+                out.append(self.bucket_tail if li == nl - 1 else v.bucket)
+        return out
 
     def time_buckets(self, reps=5):
         """Each bucket's all-reduce alone on an otherwise idle GPU: milliseconds (host clock around reps exchanges,

@@ -24,26 +24,35 @@ def scales(n_local, world):
     return {"inv_n": 1.0 / (n_local * world), "kl_scale": 1.0 / world}
 
 
-def arena_layout(sizes, n_classes):
-    """The flat fp32 gradient arena: per VB layer [d/dmeans (O x I) | d/dlvars (O x I) | d/dbias (O)], then the final
+def arena_layout(sizes, n_classes, early_lv=None):
+    """The flat fp32 gradient arena: per VB layer [d/dlvars (O x I) | d/dmeans (O x I) | d/dbias (O)], then the final
     Linear [gradWeight (C x H) | gradBias (C)].
+    early_lv: per VB layer, True where accGradParameters runs as TWO launches (vbnn_dw_args.part = 2, then 1) so that the
+    finished d/dlvars can leave while the d/dmeans GEMM still runs: that layer then has two messages, [d/dlvars] and
+    [d/dmeans | d/dbias] (d/dlvars comes first in the arena so that both are contiguous).
     Returns (layers, final, total, buckets):
-      layers[k] = dict(I, O, mu=(off, n), lv=(off, n), bias=(off, n), bucket=(start, end))
+      layers[k] = dict(I, O, lv=(off, n), mu=(off, n), bias=(off, n), bucket=(start, end),
+                       early=(start, end) or None, late=(start, end))   -- the layer's message(s)
       final     = dict(weight=(off, n), bias=(off, n), bucket=(start, end))
-      buckets   = the all-reduce messages of a step as (start, end), in ISSUE order: backward runs last layer first, and
+      buckets   = every all-reduce message of a step as (start, end), in ISSUE order: backward runs last layer first, and
                   the final Linear's gradients (adjacent in the arena, finished before the last VB layer's
-                  accGradParameters is launched) ride in that layer's message."""
+                  accGradParameters is launched) ride in that layer's LAST message."""
+    n_layers = len(sizes) - 1
+    early_lv = list(early_lv) if early_lv is not None else [False] * n_layers
+    assert len(early_lv) == n_layers
     off, layers = 0, []
-    for i in range(len(sizes) - 1):
+    for i in range(n_layers):
         I, O = sizes[i], sizes[i + 1]
         start = off
-        d = {"I": I, "O": O, "mu": (off, O * I)}
+        d = {"I": I, "O": O, "lv": (off, O * I)}
         off += O * I
-        d["lv"] = (off, O * I)
+        d["mu"] = (off, O * I)
         off += O * I
         d["bias"] = (off, O)
         off += O
         d["bucket"] = (start, off)
+        d["early"] = (start, start + O * I) if early_lv[i] else None
+        d["late"] = (start + O * I, off) if early_lv[i] else (start, off)
         layers.append(d)
     H = sizes[-1]
     start = off
@@ -52,10 +61,12 @@ def arena_layout(sizes, n_classes):
     final["bias"] = (off, n_classes)
     off += n_classes
     final["bucket"] = (start, off)
+    layers[-1]["late"] = (layers[-1]["late"][0], off)          # the final Linear rides in the last VB layer's last message
     buckets = []
-    for k in range(len(layers) - 1, -1, -1):
-        s, e = layers[k]["bucket"]
-        buckets.append((s, final["bucket"][1]) if k == len(layers) - 1 else (s, e))
+    for k in range(n_layers - 1, -1, -1):
+        if layers[k]["early"]:
+            buckets.append(layers[k]["early"])
+        buckets.append(layers[k]["late"])
     return layers, final, off, buckets
 
 
