@@ -164,7 +164,14 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
             return st;
         return launch_gemm<T, false>(ctx, xt, nullptr, a->ld_n, gt, nullptr, a->ld_n, Mp, a->O, a->N, e);
     }
-    const bool dual = e.lrt != 0;                            // K-major x, g first (no transposed copies needed)
+    const bool dual = e.lrt != 0;
+    // MIXED operands: x, x.x K-major as the forward holds them, g, gv TRANSPOSED (gT, gvT: O x ld_n, K-contiguous) as
+    // their producer's epilogue can write them -- the transpose read of the 256-column B tile is the slower of the two
+    // (lab: 104 vs 93 us per pass at 4096^3), a transposed g costs its producer one more pair of stores
+    if (dual && !a->gradBias && a->x && a->x2 && a->gT && a->gvT && g_kmajor &&
+        try_kmajor<T, true, true, false>(ctx, a->x, a->x2, a->ld_x, a->gT, a->gvT, a->ld_n, a->I, a->O, a->N, e, &st))
+        return st;
+    // K-major x, g (no transposed copies needed)
     if (!a->gradBias &&
         (dual ? try_kmajor<T, true, true, true>(ctx, a->x, a->x2, a->ld_x, a->g, a->gv, a->ld_g, a->I, a->O, a->N, e, &st)
               : try_kmajor<T, false, true, true>(ctx, a->x, nullptr, a->ld_x, a->g, nullptr, a->ld_g, a->I, a->O, a->N, e, &st)))
@@ -232,9 +239,10 @@ extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) 
 extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && a, "null ctx/args");
-    VBNN_REQUIRE((a->xT && a->gT) || (a->x && a->g), "xT and gT (or the K-major x and g) are required");
-    VBNN_REQUIRE((a->x2T == nullptr) == (a->gvT == nullptr), "x2T and gvT go together (LRT pair)");
-    VBNN_REQUIRE((a->x2 == nullptr) == (a->gv == nullptr), "x2 and gv go together (LRT pair)");
+    VBNN_REQUIRE((a->xT && a->gT) || (a->x && a->g) || (a->x && a->gT), "xT and gT (or the K-major x and g, or x with gT) are required");
+    VBNN_REQUIRE((a->x2T != nullptr || a->x2 != nullptr) == (a->gvT != nullptr || a->gv != nullptr), "x.x and gv operands go together (LRT pair)");
+    VBNN_REQUIRE(!a->xT || ((a->x2T == nullptr) == (a->gvT == nullptr)), "x2T and gvT go together (LRT pair)");
+    VBNN_REQUIRE(!a->g || ((a->x2 == nullptr) == (a->gv == nullptr)), "x2 and gv go together (LRT pair)");
     VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
     VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
     VBNN_REQUIRE(!((a->x2T || a->x2) && (a->gradSum || a->grad_lv)) || a->lvars, "LRT gradSum/grad_lv need lvars");

@@ -172,8 +172,15 @@ class FusedMLP:
             v.x2_s = _Packed(N, xcols, tdt, dev)
             if v.dw_km and v.bias_from_dw:
                 v.x_s.t[:, v.I] = 1.0
+            # opt.mixed_g (A/B, off): the last VB layer below the fused head gets g, gv from vbnn_head_backward TRANSPOSED as
+            # well, and accGradParameters reads x K-major with g K-contiguous. Measured in the step (r02): the GEMM 220 ->
+            # 216 us, the head's backward 32 -> 40 us for the extra stores: a net loss, so it stays off.
+            v.mixed_g = bool(v.dw_km and v is self.vb[-1] and self.n_classes <= 16 and self.criterion == "nll" and
+                             self.opt.get("mixed_g", False) and lib.vbnn_kmajor_supported(v.I, v.O, N) and not v.bias_from_dw)
             if v.dw_km:
                 v.xT_s = v.x2T_s = v.gT_s = v.gvT_s = None
+                if v.mixed_g:
+                    v.gT_s, v.gvT_s = _Packed(v.O, N, tdt, dev), _Packed(v.O, N, tdt, dev)
             else:
                 v.xT_s, v.x2T_s = _Packed(v.I + extra, N, tdt, dev), _Packed(v.I + extra, N, tdt, dev)
                 v.gT_s, v.gvT_s = _Packed(v.O, N, tdt, dev), _Packed(v.O, N, tdt, dev)
@@ -343,9 +350,10 @@ class FusedMLP:
     def _dw_args(self, li, N, accumulate):
         v, lrt = self.vb[li], self._lrt()
         has_t = v.xT_s is not None
+        has_gt = v.gT_s is not None
         d = L.DwArgs(xT=v.xT_s.ptr if has_t else None, x2T=v.x2T_s.ptr if (lrt and has_t) else None,
-                     gT=v.gT_s.ptr if has_t else None, gvT=v.gvT_s.ptr if (lrt and has_t) else None,
-                     ld_n=v.xT_s.ld if has_t else 0, N=N, I=v.I, O=v.O, scale=1.0,
+                     gT=v.gT_s.ptr if has_gt else None, gvT=v.gvT_s.ptr if (lrt and has_gt) else None,
+                     ld_n=v.gT_s.ld if has_gt else 0, N=N, I=v.I, O=v.O, scale=1.0,
                      accumulate=accumulate, seed=self.seed, layer=v.layer_id, draw=self.draw, lvars=_p(v.lvars),
                      x=v.x_s.ptr, x2=v.x2_s.ptr if lrt else None, g=v.g_s.ptr, gv=v.gv_s.ptr if lrt else None,
                      ld_x=v.x_s.ld, ld_g=v.g_s.ld)
