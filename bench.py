@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--mode", default="lrt", choices=["lrt", "wn"])
     ap.add_argument("--batch", type=int, default=0, help="exploration only: rows per GPU instead of the configuration's")
     ap.add_argument("--S", type=int, default=1, help="Monte-Carlo draws per minibatch (main.lua:32-37); the metric is quoted at 1")
+    ap.add_argument("--stack-draws", action="store_true", help="with --S > 1: the draws as rows of ONE pass (FusedMLP.run_draws) instead of S passes")
     ap.add_argument("--prepare-each-step", action="store_true", help="round 1's protocol: the parameter sweep inside every step")
     ap.add_argument("--with-update", action="store_true", help="also time step + optimiser update (reported beside the metric)")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
@@ -227,7 +228,7 @@ def main():
         cfg["batch"] = args.batch
         cfg["name"] += f" [batch overridden: {args.batch}]"
     if args.S != 1:
-        cfg["name"] = cfg["name"].replace("S=1", f"S={args.S}")
+        cfg["name"] = cfg["name"].replace("S=1", f"S={args.S}" + (" (draws stacked as rows)" if args.stack_draws else ""))
     N = cfg["batch"]
     opt = dict(var_init=1e-3, B=1e6, S=args.S, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
                hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap,
@@ -246,9 +247,12 @@ def main():
         eng.resetGradients()
         if args.prepare_each_step:
             eng.prepare()
-        for _ in range(args.S):
-            eng.sample()
-            eng.run(x, t)
+        if args.stack_draws and args.S > 1:
+            eng.run_draws(x, t, args.S)
+        else:
+            for _ in range(args.S):
+                eng.sample()
+                eng.run(x, t)
         eng.finish()
 
     def train_step():

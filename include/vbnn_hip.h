@@ -145,6 +145,10 @@ typedef struct vbnn_fwd_args {
     int relu;                       /* apply ReLU before writing the packed outputs below        */
     void* h;  void* h2;  int64_t ld_h;     /* next layer's packed input and its square, N x ld_h  */
     void* hT; void* h2T; int64_t ld_hT;    /* their transposes, O x ld_hT                         */
+    /* > 0: the N rows are SEVERAL Monte-Carlo draws of one minibatch stacked (main.lua:32-37's S loop as rows): row n is
+     * minibatch row n % rows_per_draw of draw `draw + n / rows_per_draw`, and its noise is addressed accordingly -- bit
+     * for bit the z of that draw's own launch. The backward GEMMs then sum over all draws in one pass (K = N). 0: off. */
+    int64_t rows_per_draw;
 } vbnn_fwd_args;
 
 /* updateOutput. WN/MAP: y = x w^T + b  (inherited nn.Linear:updateOutput, VBLinear.lua:7).

@@ -51,6 +51,7 @@ typedef struct vbnn_fwd_args {
     int relu;
     void* h;  void* h2;  int64_t ld_h;
     void* hT; void* h2T; int64_t ld_hT;
+    int64_t rows_per_draw;
 } vbnn_fwd_args;
 int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a);
 typedef struct vbnn_dx_args {

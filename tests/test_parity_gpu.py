@@ -1146,6 +1146,36 @@ def test_early_dlvars_message_is_bitwise_the_fused_launch(oracle, nnmod, dtype, 
         assert torch.equal(g, arenas[0][0]) and l == arenas[0][1]
 
 
+@pytest.mark.parametrize("dtype,hidden,I0,N,S", [("f32", [50, 34], 70, 1, 30), ("f32", [400, 400], 784, 100, 5), ("bf16", [512, 256], 256, 128, 4)])
+def test_stacked_draws_equal_sequential_draws(oracle, nnmod, dtype, hidden, I0, N, S):
+    """FusedMLP.run_draws -- the S Monte-Carlo draws of a minibatch (main.lua:32-37) as rows of ONE pass, noise addressed by
+    (draw, minibatch row) -- against S sequential sample() / run() calls with in-place accumulation: the noise-dependent
+    residual r of every draw BITWISE (same z, same GEMM chain per output), loss and gradients to fp32 summation order.
+    The first case is the reference's own operating point: batchSize 1, S = 30 (config.lua:11,32)."""
+    from vbnn_amd.engine import FusedMLP
+    opt = opt_for("lrt", dtype, input_size=I0, hidden=hidden, S=S, fuse_kl=True)
+    x = dev(oracle.fill_normal(N, I0, SEED, 4, 0, 0))
+    t = dev((np.arange(N) * 7 % 10).astype(np.int32))
+    seq, stk = FusedMLP(opt), FusedMLP(opt)
+    seq.prepare(); seq.resetGradients()
+    rs = []
+    for _ in range(S):
+        seq.sample(); seq.run(x, t)
+        rs.append([v.r[:N].clone() for v in seq.vb])
+    loss_a, corr_a = seq.loss_and_accuracy()
+    stk.prepare(); stk.resetGradients()
+    stk.run_draws(x, t, S)
+    loss_b, corr_b = stk.loss_and_accuracy()
+    assert stk.draw == seq.draw == S
+    for s_ in range(S):
+        for k, v in enumerate(stk.vb):
+            assert torch.equal(v.r[s_ * N:(s_ + 1) * N], rs[s_][k]), (s_, k)
+    assert abs(loss_a - loss_b) <= 2e-6 * abs(loss_a) and corr_a == corr_b
+    tol = 2e-5 if dtype == "f32" else 2e-3
+    rel = float((stk.grads - seq.grads).norm() / seq.grads.norm())
+    assert rel <= tol, rel
+
+
 # ------------------------------------------------------------------------------------------- errors
 def test_error_convention(nnmod):
     """Non-zero status + message instead of a crash (SURVEY 8b error convention)."""

@@ -45,6 +45,7 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
         *reinterpret_cast<f32x4*>(out + ((size_t)un * M + um) + ln.o) = a;
     }
     __host__ __device__ bool fast_ok() const { return true; }
+    __host__ __device__ bool v3_ok() const { return true; }
     __device__ __forceinline__ Lane lane_init(int nl, int ml) const { return Lane{(unsigned)(nl * M + ml)}; }
     __device__ __forceinline__ Pre load_fast(int, int, const Lane&) const { return Pre{}; }
     __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre&, float (&)[4], float (&)[4]) const {

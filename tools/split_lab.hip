@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(w2, hw.data(), ew * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(xx2, hxx.data(), ex * 2, hipMemcpyHostToDevice));
         CK(hipMemset(bias, 0, O * 4));
         EpiFwd<bf16_t> f{};
-        f.bias = bias; f.noise = getenv("LAB_FAKE_NOISE") ? 2 : 1; f.seed = 3; f.layer = 0; f.draw = 1; f.row0 = 0;
+        f.rpd = 0; f.bias = bias; f.noise = getenv("LAB_FAKE_NOISE") ? 2 : 1; f.seed = 3; f.layer = 0; f.draw = 1; f.row0 = 0;
         f.r_t = r; f.ld_r = O; f.r_vec = 1; f.relu = 1; f.h = hh; f.h2 = h2; f.ld_h = O; f.O = O; f.N = N;
         const int nb = (O / 256) * (N / 256);
         auto fl = [&] {

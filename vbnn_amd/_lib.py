@@ -29,7 +29,7 @@ class FwdArgs(C.Structure):
                 ("N", _i64), ("I", _i64), ("O", _i64), ("bias", _vp),
                 ("seed", _u64), ("layer", _u32), ("draw", _u32), ("row0", _i64),
                 ("y", _vp), ("ld_y", _i64), ("r", _vp), ("ld_r", _i64), ("r_packed", _i), ("relu", _i),
-                ("h", _vp), ("h2", _vp), ("ld_h", _i64), ("hT", _vp), ("h2T", _vp), ("ld_hT", _i64)]
+                ("h", _vp), ("h2", _vp), ("ld_h", _i64), ("hT", _vp), ("h2T", _vp), ("ld_hT", _i64), ("rows_per_draw", _i64)]
 
 
 class DxArgs(C.Structure):

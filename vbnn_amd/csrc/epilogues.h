@@ -52,6 +52,7 @@ struct EpiFwd {
     const float* bias;
     int noise;
     uint64_t seed; uint32_t layer, draw; int64_t row0;
+    int rpd;                                         // > 0: stacked draws, vbnn_fwd_args.rows_per_draw
     float* y; int64_t ld_y; int y_vec;
     float* r; T* r_t; int64_t ld_r; int r_vec;       // r as f32 (module path) or as T (fused path), never both
     int relu;
@@ -68,6 +69,14 @@ struct EpiFwd {
     __host__ __device__ __forceinline__ int64_t t_ld() const { return ld_hT; }
     __device__ __forceinline__ int m_dim() const { return O; }
     __device__ __forceinline__ int n_dim() const { return N; }
+    // the two-pass kernel's fold addresses the noise by launch-wide (draw, row0): stacked draws stay with the other kernels
+    __host__ __device__ __forceinline__ bool v3_ok() const { return rpd == 0; }
+    // the four normals of output units 4 q .. 4 q + 3 of operand row n: (draw, minibatch row) of that row
+    __device__ __forceinline__ vbnn_f32x4 zeta4(int n, uint32_t quad) const {
+        uint32_t nn = (uint32_t)n, d = draw;
+        if (rpd > 0) { const uint32_t k = nn / (uint32_t)rpd; d += k; nn -= k * (uint32_t)rpd; }
+        return vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, d, (uint32_t)(row0 + nn), quad);
+    }
 
     template <bool STORE_T>
     __device__ __forceinline__ void apply(int m, int n, f32x4 a1, f32x4 a2, float (&t1)[4], float (&t2)[4]) const {
@@ -78,7 +87,7 @@ struct EpiFwd {
         float yv[4], rv[4], bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias) load4<float>(bias + m, bv, valid, (m & 3) == 0 && (((uintptr_t)bias & 15u) == 0));
         vbnn_f32x4 z;
-        if (noise) z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + n), (uint32_t)(m >> 2));
+        if (noise) z = zeta4(n, (uint32_t)(m >> 2));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float mb = a1[j] + bv[j];
@@ -147,7 +156,7 @@ struct EpiFwd {
                                                float (&t2)[4]) const {
         float yv[4], rv[4];
         vbnn_f32x4 z;
-        if (noise) z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        if (noise) z = zeta4(un + ln.nl, (uint32_t)((um + ln.ml) >> 2));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float mb = a1[j] + pre.b[j];
@@ -295,6 +304,7 @@ struct EpiDx {
     __host__ __device__ __forceinline__ int64_t t_ld() const { return ld_gpT; }
     __device__ __forceinline__ int m_dim() const { return I; }
     __device__ __forceinline__ int n_dim() const { return N; }
+    __host__ __device__ __forceinline__ bool v3_ok() const { return true; }
 
     template <bool STORE_T>
     __device__ __forceinline__ void apply(int m, int n, f32x4 a1, f32x4 a2, float (&t1)[4], float (&t2)[4]) const {
@@ -435,6 +445,7 @@ struct EpiDw {
     __host__ __device__ __forceinline__ int64_t t_ld() const { return 0; }
     __device__ __forceinline__ int m_dim() const { return I; }
     __device__ __forceinline__ int n_dim() const { return O; }
+    __host__ __device__ __forceinline__ bool v3_ok() const { return true; }
 
     template <bool STORE_T>
     __device__ __forceinline__ void apply(int m, int n, f32x4 a1, f32x4 a2, float (&t1)[4], float (&t2)[4]) const {

@@ -96,6 +96,7 @@ static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
     e.bias = a->bias;
     e.noise = a->w2 != nullptr ? (g_fake_noise ? 2 : 1) : 0;
     e.seed = a->seed; e.layer = a->layer; e.draw = a->draw; e.row0 = a->row0;
+    e.rpd = (int)a->rows_per_draw;
     e.y = a->y; e.ld_y = a->ld_y; e.y_vec = a->y && aligned16(a->y) && (a->ld_y % 4 == 0);
     e.r = a->r_packed ? nullptr : (float*)a->r;
     e.r_t = a->r_packed ? (T*)a->r : nullptr;
@@ -201,6 +202,7 @@ extern "C" int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a) {
     VBNN_REQUIRE((a->w2 == nullptr) == (a->x2 == nullptr), "w2 and x2 go together (LRT pair)");
     VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
     VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
+    VBNN_REQUIRE(a->rows_per_draw >= 0 && a->rows_per_draw < (1ll << 31), "rows_per_draw");
     VBNN_REQUIRE(!a->h2 || a->h, "h2 needs h");
     VBNN_REQUIRE(!a->h2T || a->hT, "h2T needs hT");
     VBNN_REQUIRE(!a->h || (a->ld_h >= a->O && a->ld_h % 4 == 0), "ld_h");

@@ -779,7 +779,7 @@ static inline bool gemm_v3_possible(int64_t M, int64_t N, int64_t K, int64_t lda
     // operand extents below 2^30 elements: the LDS-DMA goes out in buffer form with 32-bit BYTE offsets under a 2 GiB range
     const bool a_ok = ak ? (K % V2_BK == 0 && lda % 8 == 0 && lda >= M && K * lda < (1ll << 30)) : M * lda < (1ll << 30);
     const bool b_ok = bk ? (K % V2_BK == 0 && ldb % 8 == 0 && ldb >= N && K * ldb < (1ll << 30)) : N * ldb < (1ll << 30);
-    return (M % V3_BM == 0) && (N % V3_BN == 0) && a_ok && b_ok && epi.fast_ok() && t_ok && M * e.t_ld() < (1ll << 31);
+    return (M % V3_BM == 0) && (N % V3_BN == 0) && a_ok && b_ok && epi.fast_ok() && epi.v3_ok() && t_ok && M * e.t_ld() < (1ll << 31);
 }
 // Worth it when K is long enough to amortise the second pipeline fill and the fold between the passes (measured against
 // gemm_v2's dual tile on 4096 x 4096 outputs: K = 4096 forward 212 vs 252 us, K = 784 forward 93 vs 99 us) and the

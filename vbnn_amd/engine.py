@@ -119,6 +119,8 @@ class FusedMLP:
         self._map = False
         self._first = True
         self._N = None
+        self._rpd = 0            # > 0 inside run_draws: rows per Monte-Carlo draw of the stacked minibatch
+        self._draws = None
         self.init_parameters()
 
     # mlp.lua:47-55 (He rule for every weight, bias zero) + the bench's non-degenerate means
@@ -345,7 +347,7 @@ class FusedMLP:
                          ld_h=self.h_s.ld if last else nxt.x_s.ld,
                          hT=(None if (self.n_classes <= 16 and self.criterion == "nll") else self.hT_s.ptr) if last else (nxt.xT_s.ptr if nxt.xT_s else None),
                          h2T=None if (last or not lrt or not nxt.x2T_s) else nxt.x2T_s.ptr,
-                         ld_hT=self.hT_s.ld if last else (nxt.xT_s.ld if nxt.xT_s else 0))
+                         ld_hT=self.hT_s.ld if last else (nxt.xT_s.ld if nxt.xT_s else 0), rows_per_draw=self._rpd)
 
     def _dw_args(self, li, N, accumulate):
         v, lrt = self.vb[li], self._lrt()
@@ -361,7 +363,7 @@ class FusedMLP:
             d.gradWeight, d.gradSum = None, None
             d.grad_mu, d.grad_lv = _p(v.gradWeight), _p(v.gradSum)
             d.means, d.stats = _p(v.means), _p(v.stats)
-            d.B, d.S, d.kl_scale = self.B, self.S, partition.scales(1, self.world)["kl_scale"]
+            d.B, d.S, d.kl_scale = self.B, float(self._draws or self.S), partition.scales(1, self.world)["kl_scale"]
             if self.kl_from_shadows and lrt:
                 # the epilogue reads mu, sigma^2 from the bf16 operand shadows (4 B per weight instead of 8, no exp): the
                 # values the forward GEMMs multiplied by
@@ -391,10 +393,10 @@ class FusedMLP:
         assert x.shape[1] == self.sizes[0] and x.dtype == torch.float32 and x.is_cuda
         self._alloc_batch(N)
         if row0 is None:
-            row0 = self.rank * N
+            row0 = self.rank * (self._rpd or N)
         lrt = self._lrt()
         accumulate = 0 if self._first else 1
-        inv_n = partition.scales(N, self.world)["inv_n"]
+        inv_n = partition.scales(self._rpd or N, self.world)["inv_n"]       # per DRAW: stacked draws sum their criteria
         v0 = self.vb[0]
         L.check(lib.vbnn_pack_input(ctx, code, _p(x), x.stride(0), N, v0.I, v0.x_s.ptr, v0.x2_s.ptr if lrt else None,
                                     v0.x_s.ld, v0.xT_s.ptr if v0.xT_s else None,
@@ -475,6 +477,26 @@ class FusedMLP:
             done.record(side)
             main.wait_event(done)                            # the next launch on the main stream sees every gradient
         self._first = False
+
+    # ---- main.lua:32-37's S draws as ONE pass: the minibatch stacked S times as rows (draw s = rows [s N, (s + 1) N)), each
+    # row's noise addressed by (its draw, its minibatch row) -- vbnn_fwd_args.rows_per_draw -- so every draw sees bit for bit
+    # the z of its own sequential launch; the backward GEMMs sum over all draws at once (K = S N), the criterion over all
+    # stacked rows with the per-draw 1 / N. One launch per GEMM family instead of S; the gradients equal the S sequential
+    # draws' up to fp32 summation order. LRT only (weight noise draws a different weight matrix per draw). The gain is for the
+    # reference's own operating point -- a handful of rows, S = 30 (config.lua:11,32) -- which is launch-bound.
+    def run_draws(self, inputs, targets, S):
+        assert self.mode == "lrt" and not self._map and self._first, "run_draws: LRT, right after resetGradients()"
+        x = inputs.reshape(inputs.shape[0], -1)
+        N = x.shape[0]
+        xs = x.repeat(S, 1)
+        ts = targets.repeat(S) if targets.dim() == 1 else targets.repeat(S, 1)
+        self.draw += 1                                   # the first draw's counter; row n uses draw + n // N
+        self._rpd, self._draws = N, S
+        try:
+            self.run(xs, ts)
+        finally:
+            self._rpd, self._draws = 0, None
+        self.draw += S - 1
 
     # ---- data-parallel exchange: sum all-reduce of one layer's gradient bucket over RCCL/xGMI, issued
     # right after that layer's accGradParameters so it overlaps the rest of backward. The criterion
