@@ -60,8 +60,14 @@ VBNN_HD vbnn_u32x4 vbnn_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uin
         const uint64_t p1 = (uint64_t)VBNN_PHILOX_M1 * (uint64_t)c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__)
+        /* one three-input bitwise op (truth table 0x96 = a ^ b ^ c) instead of two v_xor: 20 fewer VALU slots per block */
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+#else
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
+#endif
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += VBNN_PHILOX_W0; k1 += VBNN_PHILOX_W1;
     }
@@ -91,10 +97,9 @@ VBNN_HD float vbnn_det_logf(float x) {
     uint32_t b = vbnn_f32_as_u32(x);
     int e = (int)(b >> 23) - 127;
     uint32_t mb = (b & 0x007FFFFFu) | 0x3F800000u;   /* m in [1,2) */
-    if (mb > 0x3FB504F3u) {                           /* m > sqrt(2): halve it (exact) */
-        mb -= 0x00800000u;
-        e += 1;
-    }
+    const uint32_t big = (mb > 0x3FB504F3u) ? 1u : 0u; /* m > sqrt(2): halve it (exact); branch-free on purpose -- */
+    mb -= big << 23;                                   /* on the GPU a lane-dependent branch here costs more than   */
+    e += (int)big;                                     /* both of its sides                                         */
     const float m = vbnn_u32_as_f32(mb);
     const float f = m - 1.0f;                         /* exact */
     const float den = 2.0f + f;
@@ -128,12 +133,16 @@ VBNN_HD void vbnn_det_sincos2pi(uint32_t k24, float* c_out, float* s_out) {
     cp = fmaf(a2, cp, 4.16666667e-2f);                      /* 1/4! */
     cp = fmaf(a2, cp, -0.5f);
     const float cs = fmaf(a2, cp, 1.0f);
-    float c, s;
-    if (q == 0u)      { c = cs;  s = sn;  }
-    else if (q == 1u) { c = -sn; s = cs;  }
-    else if (q == 2u) { c = -cs; s = -sn; }
-    else              { c = sn;  s = -cs; }
-    *c_out = c; *s_out = s;
+    /* quadrant q: (cos, sin)(a + q pi/2) = (cs, sn), (-sn, cs), (-cs, -sn), (sn, -cs). Branch-free: odd quadrants swap
+     * the two polynomial values, then a sign bit is flipped (exactly what unary minus does): cos negative for q = 1, 2,
+     * sin negative for q = 2, 3. Bit for bit the four-way if it replaces. */
+    const uint32_t swap = q & 1u;
+    const float bc = swap ? sn : cs;
+    const float bs = swap ? cs : sn;
+    const uint32_t sign_c = ((q + 1u) & 2u) << 30;
+    const uint32_t sign_s = (q & 2u) << 30;
+    *c_out = vbnn_u32_as_f32(vbnn_f32_as_u32(bc) ^ sign_c);
+    *s_out = vbnn_u32_as_f32(vbnn_f32_as_u32(bs) ^ sign_s);
 }
 
 /* Box-Muller on two 32-bit words: u1 in (0,1] from the top 24 bits (+1), u2 in [0,1). */
