@@ -1,26 +1,35 @@
 #!/bin/bash
-# One gpurun call's worth of checks ON the GPU box (from the repository root): bash tools/gpu_round.sh <tag>
+# One gpurun call's worth of the round's measurements ON the GPU box (from the repository root): bash tools/gpu_round.sh <tag>
+# tests, the bench lines (wide with --with-update, the driver's protocol, small, deep, one-rank RCCL), the rocprofv3 kernel
+# trace of the wide bench with one step's timeline, and the PMC passes (tools/collect_traffic.py). Copy what is to be kept
+# from gpurun_out/ into profiles/.
 set -o pipefail
 tag=${1:-r02}
 root=$(pwd)
 mkdir -p gpurun_out
 echo "== tests"; timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${tag}_tests.log
-echo "== bench"; timeout -k 10 300 python3 bench.py --with-update > gpurun_out/${tag}_bench_wide.json 2> gpurun_out/${tag}_bench.err; echo "rc=$?"
-timeout -k 10 300 python3 bench.py --no-cpu-baseline --prepare-each-step > gpurun_out/${tag}_bench_wide_prep.json 2>> gpurun_out/${tag}_bench.err; echo "rc=$?"
-timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_bench_wide_driver.json 2>> gpurun_out/${tag}_bench.err; echo "rc=$?"
+echo "== bench"
+timeout -k 10 300 python3 bench.py --with-update > gpurun_out/${tag}_bench_wide.json 2> gpurun_out/${tag}_bench.err; echo "wide rc=$?"
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_bench_wide_driver.json 2>> gpurun_out/${tag}_bench.err; echo "driver-protocol rc=$?"
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --prepare-each-step > gpurun_out/${tag}_bench_wide_prep.json 2>> gpurun_out/${tag}_bench.err; echo "prepare-each-step rc=$?"
+timeout -k 10 300 python3 bench.py --config small > gpurun_out/${tag}_bench_small.json 2>> gpurun_out/${tag}_bench.err; echo "small rc=$?"
+timeout -k 10 300 python3 bench.py --config small --S 30 --batch 1 --stack-draws --no-cpu-baseline > gpurun_out/${tag}_bench_small_S30.json 2>> gpurun_out/${tag}_bench.err; echo "small S30 rc=$?"
+timeout -k 10 400 python3 bench.py --config deep --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_bench_deep.json 2>> gpurun_out/${tag}_bench.err; echo "deep rc=$?"
 VBNN_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_bench_dist1.json 2>> gpurun_out/${tag}_bench.err; echo "dist1 rc=$?"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag} -o ${tag} -- python3 $root/bench.py --no-cpu-baseline --steps 20 --warmup 10 --repeats 1 > /dev/null 2>&1; echo "prof rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag} -o ${tag} -- python3 $root/bench.py --no-cpu-baseline --steps 20 --warmup 10 --repeats 2 > /dev/null 2>&1; echo "prof rc=$?"
 cd $root
-python3 profiles/summarize_db.py gpurun_out/prof_${tag}/${tag}_results.db 50 > gpurun_out/${tag}_wide_kernel_stats.txt 2>&1
-head -16 gpurun_out/${tag}_wide_kernel_stats.txt
+python3 profiles/summarize_db.py gpurun_out/prof_${tag}/${tag}_results.db 70 > gpurun_out/${tag}_wide_kernel_stats.txt 2>&1
+python3 tools/step_timeline.py gpurun_out/prof_${tag}/${tag}_results.db > gpurun_out/${tag}_wide_step_timeline.txt 2>&1
+head -14 gpurun_out/${tag}_wide_kernel_stats.txt; cat gpurun_out/${tag}_wide_step_timeline.txt
+VBNN_PMC_EXTRA="TCC_EA0_RDREQ_sum,TCC_EA0_RDREQ_32B_sum,TCC_EA0_RDREQ_DRAM_sum;TCC_REQ_sum,TCC_READ_sum,TCC_WRITE_sum" timeout -k 10 900 python3 tools/collect_traffic.py ${tag} > gpurun_out/${tag}_traffic.log 2>&1; tail -6 gpurun_out/${tag}_traffic.log
 python3 - <<PY
 import json
-for f in ("bench_wide", "bench_wide_prep", "bench_wide_driver", "bench_dist1"):
+for f in ("bench_wide", "bench_wide_driver", "bench_wide_prep", "bench_small", "bench_small_S30", "bench_deep", "bench_dist1"):
     try:
         d = json.loads(open("gpurun_out/${tag}_%s.json" % f).read().strip().splitlines()[-1])
-        print(f, d["ms_per_step"], d["config"]["repeats_wall_ms"], d["roofline"]["timed_region_kernels_ms"], d["config"].get("train"), d.get("comm"))
+        print(f, d["ms_per_step"], d["value"], d["config"]["repeats_wall_ms"], d["roofline"]["frac"], d["roofline"]["timed_region_kernels_ms"], d["config"].get("train", {}).get("ms_per_train_step"), (d.get("cpu_baseline") or {}).get("value"))
     except Exception as e:
         print(f, "unreadable:", e)
 PY
-tail -5 gpurun_out/${tag}_bench.err
+tail -3 gpurun_out/${tag}_bench.err
