@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="exploration only: rows per GPU instead of the configuration's")
     ap.add_argument("--S", type=int, default=1, help="Monte-Carlo draws per minibatch (main.lua:32-37); the metric is quoted at 1")
     ap.add_argument("--stack-draws", action="store_true", help="with --S > 1: the draws as rows of ONE pass (FusedMLP.run_draws) instead of S passes")
+    ap.add_argument("--host-input", action="store_true", help="the minibatch starts in (pinned) HOST memory every step: the PCIe-inclusive "
+                    "rate, reported beside the metric in config.pcie_inclusive -- never `value`")
     ap.add_argument("--prepare-each-step", action="store_true", help="round 1's protocol: the parameter sweep inside every step")
     ap.add_argument("--with-update", action="store_true", help="also time step + optimiser update (reported beside the metric)")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
@@ -307,6 +309,25 @@ def main():
     probed_ms = (time.perf_counter() - tp0) / args.steps * 1e3
     probe, eng.probe = eng.probe, None
 
+    pcie = None
+    if args.host_input:
+        xh, th = x.cpu().pin_memory(), t.cpu().pin_memory()
+        xd, td = torch.empty_like(x), torch.empty_like(t)
+
+        def host_step():
+            xd.copy_(xh, non_blocking=True); td.copy_(th, non_blocking=True)      # H2D on the launch stream, then the step
+            eng.resetGradients()
+            eng.sample()
+            eng.run(xd, td)
+            eng.finish()
+        for _ in range(3):
+            host_step()
+        hw, _ = timed_blocks(host_step, max(1, args.repeats))
+        hms = sorted(hw)[len(hw) // 2]
+        pcie = {"ms_per_step": round(hms, 4), "samples_per_s": round(N * world / (hms * 1e-3), 1),
+                "h2d_bytes_per_step": int(x.numel() * 4 + t.numel() * t.element_size()),
+                "note": "minibatch copied from pinned host memory at the head of every step (no overlap with the previous step)"}
+
     train = None
     if args.with_update:
         for _ in range(3):
@@ -356,6 +377,8 @@ def main():
         }
         if train:
             out["config"]["train"] = train
+        if pcie:
+            out["config"]["pcie_inclusive"] = pcie
         if comm:
             out["comm"] = comm
         if world == 1 and not args.no_cpu_baseline:
