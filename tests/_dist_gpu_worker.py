@@ -31,6 +31,7 @@ def main():
         eng.run(x, t)
         eng.finish()
     loss, _ = eng.loss_and_accuracy()
+    print(f"rank {rank}: local loss {loss!r} (exchange: {eng.comm_backend()})", flush=True)
     lt = torch.tensor([loss], dtype=torch.float64)
     dist.all_reduce(lt)
     if rank == 0:

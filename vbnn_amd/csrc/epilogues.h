@@ -581,8 +581,28 @@ struct EpiDw {
     static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 8;          // all 32 quads' sigma^2 loads (64 registers) in flight together
     static constexpr int FOLD_SERIAL = 0;
-    static constexpr int FOLD_STAGE = 0;
+    // FOLD_STAGE 2: the fold's output (d/dlvars, fp32 O x I) leaves through a per-wave LDS tile as whole 256-byte row
+    // segments (gemm_v3.h) instead of 16 rows x 64 bytes per wave-instruction straight from the MFMA layout
+    static constexpr int FOLD_STAGE = 2;
+    typedef float fold_st_t;
+    __host__ __device__ __forceinline__ float* fold_st_ptr() const { return grad_lv; }
+    __host__ __device__ __forceinline__ int64_t fold_st_ld() const { return I; }
     struct FPre { bf16x4 lv; };
+    // the fold's scalars, formed ONCE by the kernel (the staged fold's LDS accesses are asm statements with a memory
+    // clobber: left inside fold_s, the load of stats[2] and the divide were redone -- and waited for -- per quad)
+    struct FoldK { float k_lv, inv_vh, invS; };
+    __device__ __forceinline__ FoldK fold_k() const {
+        const float var_hat = (float)stats[2];
+        return FoldK{kl_scale / (2.0f * B), 1.0f / var_hat, 1.0f / S};
+    }
+    __device__ __forceinline__ f32x4 fold_s(const FoldK& k, f32x4 a2, const FPre& fp, f32x4& gl) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float var = (float)fp.lv[j];
+            gl[j] = fmaf(k.k_lv, fmaf(var, k.inv_vh, -1.0f), a2[j] * var * k.invS);
+        }
+        return f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
         FPre p;
         p.lv = shadow4(var_s, um, un, ln);

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         // loads and stores are younger than those DMAs on the in-order vmcnt counter: the counted waits of run_pass
         // only get stricter.)
         __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
-        if constexpr (Epi::FOLD_STAGE != 0) {
+        if constexpr (Epi::FOLD_STAGE == 1) {
             // FOLD_STAGE functors (see the fold below): the per-m addend (the bias) of the wave's 128 m is parked in the
             // wave's LDS staging area NOW, before pass 2's fill is issued -- ONE global load per lane whose wait covers
             // nothing else. (Beside LDS-DMAs in flight hipcc waits vmcnt(0) for any plain load's result, i.e. also for
@@ -551,7 +551,52 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 }
         };
         static_assert(8 % Epi::FOLD_BATCH == 0, "FOLD_BATCH divides the 8 m-blocks of a wave tile");
-        if constexpr (Epi::FOLD_STAGE != 0) {
+        if constexpr (Epi::FOLD_STAGE == 2) {
+            // fp32 form of the staged fold store below (EpiDw's d/dlvars): tile [16 n][64 m] f32, 256-byte rows + 16 B pad;
+            // every quad's operand load is issued up front (one batch: the only vmcnt wait of the fold), then per
+            // (n-block, four m-blocks): four ds_write_b128, four ds_read_b128, four 16-byte stores of 4 rows x 256 B.
+            constexpr int PITCH = 64 * 4 + 16, WSTG = 16 * PITCH;
+            static_assert(7 * WSTG <= V3_BTILE && WSTG <= V3_APART, "staging tiles must fit the free LDS");
+            const unsigned stg = (unsigned)(uintptr_t)(ldsb_t)(wave < 7 ? lds + 4 * V3_APART + 2 * V3_BTILE + wave * WSTG
+                                                                       : lds + 3 * V3_APART);
+            int flane = lane;
+            asm volatile("" : "+v"(flane));
+            const unsigned wr_a = stg + fc16 * PITCH + 16 * fq4;               // this lane's 4 m of m-block b: + 64 b
+            const unsigned rd_a = stg + (flane >> 4) * PITCH + (flane & 15) * 16;   // row (lane >> 4) (+ 4 i), 16-byte chunk lane & 15
+            float* const outp = epi.fold_st_ptr();
+            const int64_t old = epi.fold_st_ld();
+            const unsigned olane = (unsigned)((flane >> 4) * (int)old + (flane & 15) * 4);
+            typename Epi::FPre fp[8][4];
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fp[b][j] = epi.fold_load(fm0 + 16 * b, fn0 + 16 * j, fln);
+            const typename Epi::FoldK fk = epi.fold_k();
+            auto fold_group = [&](auto g_c) {
+                constexpr int G = decltype(g_c)::value;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        f32x4 sv;
+                        acc[4 * G + b][j] = epi.fold_s(fk, acc[4 * G + b][j], fp[4 * G + b][j], sv);
+                        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wr_a), "v"(sv), "n"(64 * b) : "memory");
+                    }
+                    f32x4 r0, r1, r2, r3;
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\t"
+                                 "ds_read_b128 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                                 : "v"(rd_a), "n"(4 * PITCH), "n"(8 * PITCH), "n"(12 * PITCH) : "memory");
+                    float* const row0p = outp + ((int64_t)(fn0 + 16 * j) * old + fm0 + 64 * G);
+                    *reinterpret_cast<f32x4*>(row0p + olane) = r0;
+                    *reinterpret_cast<f32x4*>(row0p + 4 * old + olane) = r1;
+                    *reinterpret_cast<f32x4*>(row0p + 8 * old + olane) = r2;
+                    *reinterpret_cast<f32x4*>(row0p + 12 * old + olane) = r3;
+                }
+            };
+            fold_group(std::integral_constant<int, 0>());
+            fold_group(std::integral_constant<int, 1>());
+        } else if constexpr (Epi::FOLD_STAGE != 0) {
             // The fold's own output tensor ([n][m], element type ST) leaves through a per-wave LDS tile [16 n][64 m]: the
             // four quads of an (n-block, four m-blocks) group are written as they stand (lane (n = c16, 4 m)), read back
             // as rows and stored as whole 128-byte (2-byte ST) row segments. Free LDS while pass 2's fill is in flight:

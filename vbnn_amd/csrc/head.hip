@@ -92,6 +92,16 @@ __global__ __launch_bounds__(64 * HEAD_FW) void k_head_forward(const T* __restri
     const int64_t k_lo = ksteps * wave / HEAD_FW, k_hi = ksteps * (wave + 1) / HEAD_FW;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int64_t ks = k_lo;
+    for (; ks + 16 <= k_hi; ks += 16) {               // sixteen K steps of loads in flight: at H = 4096 a wave's whole K range in
+        frag_t a[16], b[16];                          // ONE load round (two rounds of eight paid the load latency twice)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            a[u] = *reinterpret_cast<const frag_t*>(wp + (ks + u) * KE);
+            b[u] = *reinterpret_cast<const frag_t*>(hp + (ks + u) * KE);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = mfma_step<T>(a[u], b[u], acc);
+    }
     for (; ks + 8 <= k_hi; ks += 8) {                 // eight K steps of loads in flight (latency-bound otherwise)
         frag_t a[8], b[8];
 #pragma unroll
