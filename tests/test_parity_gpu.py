@@ -1176,6 +1176,52 @@ def test_stacked_draws_equal_sequential_draws(oracle, nnmod, dtype, hidden, I0, 
     assert rel <= tol, rel
 
 
+@pytest.mark.parametrize("hidden,I0,N", [([4096, 4096], 784, 1024), ([4096, 4096], 784, 4096), ([512, 256], 256, 512)])
+def test_staged_stores_stay_inside_their_tensors(oracle, nnmod, hidden, I0, N):
+    """Guard-band screen of the kernels that address their outputs by hand (the fold's staged stores of r and d/dlvars, the
+    split launch's slabs and ragged epilogue): every output tensor of a step is re-pointed into the middle of a larger
+    sentinel-filled allocation; after two steps the sentinels on both sides must be untouched."""
+    from vbnn_amd.engine import FusedMLP
+    opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True)
+    eng = FusedMLP(opt)
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = eng.synthetic_targets(x)
+    eng.prepare(); eng.resetGradients(); eng.sample(); eng.run(x, t)          # allocates the batch buffers
+    GUARD = 1 << 16
+    guards = []
+
+    def guarded(tensor, sentinel):
+        flat = tensor.reshape(-1)
+        big = torch.full((flat.numel() + 2 * GUARD,), sentinel, dtype=tensor.dtype, device="cuda")
+        big[GUARD:GUARD + flat.numel()] = flat
+        guards.append((big, flat.numel(), sentinel))
+        return big[GUARD:GUARD + flat.numel()].view(tensor.shape)
+
+    # the gradient arena (d/dlvars, d/dmeans, bias gradients are views into it) and every layer's r
+    arena = guarded(eng.grads, 12345.0)
+    eng.grads = arena
+    lay = eng._lay
+    for li, v in enumerate(eng.vb):
+        v.gradSum = arena[lay[li]["lv"][0]:lay[li]["lv"][0] + lay[li]["lv"][1]].view(v.O, v.I)
+        v.gradWeight = arena[lay[li]["mu"][0]:lay[li]["mu"][0] + lay[li]["mu"][1]].view(v.O, v.I)
+        v.gradBias = arena[lay[li]["bias"][0]:lay[li]["bias"][0] + lay[li]["bias"][1]]
+        v.r = guarded(v.r, 77.0)
+    off = lay[-1]["bucket"][1]
+    H, Cn = eng.sizes[-1], eng.n_classes
+    eng.gradWeight3 = arena[off:off + Cn * H].view(Cn, H)
+    eng.gradBias3 = arena[off + Cn * H:off + Cn * H + Cn]
+    eng._acc = guarded(eng._acc, 3.0e300)
+    for _ in range(2):
+        eng.resetGradients(); eng.sample(); eng.run(x, t)
+    loss, _ = eng.loss_and_accuracy()
+    torch.cuda.synchronize()
+    assert np.isfinite(loss) and 0.0 < loss < 1e3
+    for big, n, sentinel in guards:
+        lo, hi = big[:GUARD], big[GUARD + n:]
+        assert bool((lo == sentinel).all()) and bool((hi == sentinel).all()), "a kernel wrote outside its output tensor"
+
+
 # ------------------------------------------------------------------------------------------- errors
 def test_error_convention(nnmod):
     """Non-zero status + message instead of a crash (SURVEY 8b error convention)."""
