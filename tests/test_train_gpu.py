@@ -10,12 +10,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(tmp_path, mode, dtype="f32", epochs=3):
+def _run(tmp_path, mode, dtype="f32", epochs=3, **over):
     from vbnn_amd import data, train
     trainSet, testSet = data.synthetic_digits(2000, 500, seed=3, noise=2.0)
     opt = train.default_opt(network_name=str(tmp_path / f"exp_{mode}_{dtype}"), hidden=[64, 48], batchSize=100,
                             testBatchSize=100, trainSize=2000, testSize=500, S=2, testSamples=3, mode=mode, dtype=dtype,
-                            state={"learningRate": 5e-2}, meanState={"learningRate": 2e-3}, varState={"learningRate": 5e-2})
+                            state={"learningRate": 5e-2}, meanState={"learningRate": 2e-3}, varState={"learningRate": 5e-2}, **over)
     m = train.Main(opt)
     first = m.test(testSet)
     hist = m.run(trainSet, testSet, epochs=epochs)
@@ -39,8 +39,13 @@ def test_both_estimators_train_to_the_same_place(tmp_path, dtype):
 
 def test_run_directory_is_what_the_reference_tools_read(tmp_path):
     from vbnn_amd import logger, t7file
-    opt, _, hist = _run(tmp_path, "lrt", epochs=2)
+    opt, _, hist = _run(tmp_path, "lrt", epochs=2, log_update=True)
     d = opt["network_name"]
+    from vbnn_amd.train import UPDATE_SERIES
+    for series in UPDATE_SERIES:                                        # VBLinear.lua:149-164: per layer and minibatch
+        vals = logger.read_data(os.path.join(d, series))
+        assert len(vals) == 2 * 20 * 2 and all(np.isfinite(vals)), (series, len(vals))     # 2 epochs x 20 minibatches x 2 VB layers
+    assert min(logger.read_data(os.path.join(d, "min variance"))) > 0
     for series in ("devacc", "trainacc", "deverr", "trainerr", "lc"):  # main.lua:169-177 -> visualize.py:25-39
         vals = logger.read_data(os.path.join(d, series))
         assert len(vals) == 2 and vals[-1] == pytest.approx(hist[-1][series], rel=1e-12)

@@ -23,6 +23,10 @@ from . import utils as u
 from .engine import FusedMLP
 from .logger import Logger
 
+# the series VBLinear:update logs per layer and minibatch, in the order of its Log:add calls (VBLinear.lua:149-164)
+UPDATE_SERIES = ("vlc grad", "vle grad", "mlc grad", "mle grad", "min variance", "max variance", "mean variance", "var hat",
+                 "mean means", "std means", "min. means", "max. means", "mu normratio", "var normratio")
+
 
 def default_opt(**over):
     """config.lua's values under the engine's key names (config.lua:5-68)."""
@@ -60,18 +64,27 @@ class Main:
         if self.indices is None:
             self.indices = list(range(0, n - bs + 1, bs))                                 # torch.range(1, trainSize, batchSize)
         accuracy = error = 0.0
+        net.prepare()                     # once: afterwards update() maintains the operand shadows and prior statistics
+        stacked = net.mode == "lrt" and S > 1 and bool(opt.get("stack_draws", True))
         for batch_index in u.shuffle(self.indices, self.rng):
             inputs, targets = dataset.create_minibatch(batch_index, bs, n, opt.get("geometry"))
             x, t = self._to_device(inputs, targets)
             net.resetGradients()
-            net.prepare()
-            for _ in range(S):                                                            # main.lua:32-37
-                net.sample()
-                net.run(x, t)
+            if stacked:                                                                   # main.lua:32-37 as rows of one pass
+                net.run_draws(x, t, S)
+            else:
+                for _ in range(S):
+                    net.sample()
+                    net.run(x, t)
             loss, correct = net.loss_and_accuracy()           # sums over the S draws (the criterion accumulates)
             error += loss * net.world / S
             accuracy += 100.0 * correct / (bs * S)
-            net.update(opt)
+            log_update = bool(self.log and opt.get("log_update") and net.mode == "lrt")
+            net.update(opt, log=log_update)
+            if log_update:                                                                # VBLinear.lua:149-164, per layer
+                for row in net.update_log.cpu().tolist():
+                    for name, value in zip(UPDATE_SERIES, row):
+                        self.log.add(name, value)
         B = len(self.indices)
         return accuracy / B, error / B
 
