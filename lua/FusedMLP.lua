@@ -168,7 +168,9 @@ function FusedMLP:run(inputs, ld, targets, N)
         d.gradBias = v.bias_from_dw and v.gradBias or nil
         d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_s.p, v.x2_s.p, v.g_s.p, v.gv_s.p, v.x_s.ld, v.g_s.ld
         d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
-        local msg_off, early = v.bucket_off, self.comm and v.O * v.I >= 2 ^ 22
+        -- (the two-launch form needs the plain K-major launch of the two-pass kernel: engine.py's early_ok)
+        local msg_off = v.bucket_off
+        local early = self.comm and v.O * v.I >= 2 ^ 22 and not v.bias_from_dw and C.vbnn_kmajor_supported(v.I, v.O, N) ~= 0
         if early then
             -- two launches (vbnn_dw_args.part): the sigma^2 GEMM and d/dlvars first, whose exchange then starts while the
             -- mu GEMM still runs (d/dlvars is the first block of the layer's bucket)
