@@ -89,6 +89,9 @@ function FusedMLP:_alloc_batch(N)
         local km = C.vbnn_kmajor_supported_dw(v.I, v.O, N, v.bias_from_dw and 1 or 0)
         v.dw_km = km > 0
         v.dx_km = li > 1 and C.vbnn_kmajor_supported(v.I, N, v.O) ~= 0
+        -- the two-launch form of accGradParameters (early d/dlvars message) needs the plain K-major launch of the two-pass
+        -- kernel; the few-tile K-major launches compute both GEMMs in one grid (engine.py: early_ok)
+        v.early_ok = (not v.bias_from_dw) and C.vbnn_kmajor_supported(v.I, v.O, N) ~= 0
         local xcols = v.I + ((v.dw_km and v.bias_from_dw) and 1 or 0)
         if km == 2 then xcols = math.floor((xcols + 255) / 256) * 256 end
         v.x_s, v.x2_s = packed(N, xcols, self.esize), packed(N, xcols, self.esize)
@@ -168,9 +171,8 @@ function FusedMLP:run(inputs, ld, targets, N)
         d.gradBias = v.bias_from_dw and v.gradBias or nil
         d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_s.p, v.x2_s.p, v.g_s.p, v.gv_s.p, v.x_s.ld, v.g_s.ld
         d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
-        -- (the two-launch form needs the plain K-major launch of the two-pass kernel: engine.py's early_ok)
         local msg_off = v.bucket_off
-        local early = self.comm and v.O * v.I >= 2 ^ 22 and not v.bias_from_dw and C.vbnn_kmajor_supported(v.I, v.O, N) ~= 0
+        local early = self.comm and v.O * v.I >= 2 ^ 22 and v.early_ok
         if early then
             -- two launches (vbnn_dw_args.part): the sigma^2 GEMM and d/dlvars first, whose exchange then starts while the
             -- mu GEMM still runs (d/dlvars is the first block of the layer's bucket)
