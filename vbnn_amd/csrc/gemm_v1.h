@@ -59,8 +59,14 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * BT, n0 = blockIdx.y * BT;
 
+    // PD: register prefetch depth, in K steps. The 32 x 32 tile of latency-bound sizes does so little per step that each
+    // step is one exposed global-load latency (the 784-deep forward of the small MLP: 25 steps, 37 us); four steps of
+    // loads in flight cost 16 registers each and hide most of it. Larger tiles keep one step ahead.
+    constexpr int PD = (WR == 1) ? 4 : 1;
     const T* src[4] = {A, B, A2, B2};
-    uint4 stage[NOP][CPT];
+    // (a native vector type, not HIP's uint4 struct: an array of the latter is not promoted to registers -- it lived in scratch)
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t stage[PD][NOP][CPT];
     const T* gptr[NOP][CPT];
     int lds_off[CPT];
 #pragma unroll
@@ -84,26 +90,34 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
 
     const int nk = Kp / KE;
 #pragma unroll
-    for (int op = 0; op < NOP; ++op)
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) stage[op][c] = *reinterpret_cast<const uint4*>(gptr[op][c]);
-
-    const int a_row = (wm * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
-    const int b_row = (wn * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
-
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int d = 0; d < PD; ++d)
 #pragma unroll
         for (int op = 0; op < NOP; ++op)
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                *reinterpret_cast<uint4*>(lds + op * BT * PITCH + lds_off[c]) = stage[op][c];
+                stage[d][op][c] = *reinterpret_cast<const u32x4_t*>(gptr[op][c] + (int64_t)min(d, nk - 1) * KE);
+
+    const int a_row = (wm * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
+    const int b_row = (wn * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
+
+    // (the K walk is unrolled by PD so that every register set has a compile-time index; same k order as ever)
+    for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+#pragma unroll
+      for (int d = 0; d < PD; ++d) {
+        const int kt = kt0 + d;
+        if (kt < nk) {                                // block-uniform (no `break`: the unrolled body must keep constant indices)
+#pragma unroll
+        for (int op = 0; op < NOP; ++op)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                *reinterpret_cast<u32x4_t*>(lds + op * BT * PITCH + lds_off[c]) = stage[d][op][c];
         __syncthreads();
-        if (kt + 1 < nk) {
+        if (kt + PD < nk) {
 #pragma unroll
             for (int op = 0; op < NOP; ++op)
 #pragma unroll
                 for (int c = 0; c < CPT; ++c)
-                    stage[op][c] = *reinterpret_cast<const uint4*>(gptr[op][c] + (int64_t)(kt + 1) * KE);
+                    stage[d][op][c] = *reinterpret_cast<const u32x4_t*>(gptr[op][c] + (int64_t)(kt + PD) * KE);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {             // 64 bytes of K per row per sub-step
@@ -130,6 +144,8 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
             }
         }
         __syncthreads();
+        }
+      }
     }
 
     const int em = m0 + wm * WR * 16 + (lane >> 4) * 4;
