@@ -28,6 +28,7 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
         if (m < M && n < N) *reinterpret_cast<f32x4*>(out + (size_t)n * M + m) = a1 + a2;
     }
     static constexpr int FAST_BATCH = 8;
+    static constexpr int FAST_BATCH_V2 = 4;
     static constexpr bool PARK = false;
     static constexpr bool SPLITTABLE = false;
     static constexpr bool EDGE_FAST = false;

@@ -4,8 +4,20 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <type_traits>
 #include "../../include/vbnn_hip.h"
 #include "../../include/vbnn_philox.h"
+
+// A loop the compiler MUST unroll: `#pragma unroll` is silently dropped when the unrolled body exceeds LLVM's
+// pragma-unroll-threshold (16 K instructions), and a rolled loop indexing a register array sends the WHOLE array to
+// scratch (seen: gemm_nt_v2<.., EpiDw>'s generic epilogue, 528 B of scratch and 64 stores on every path).
+template <int I, int N, class F>
+__device__ __forceinline__ void vbnn_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        vbnn_static_for<I + 1, N>(f);
+    }
+}
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

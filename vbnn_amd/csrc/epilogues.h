@@ -137,9 +137,10 @@ struct EpiFwd {
 
     // ---- fast protocol
     static constexpr int FAST_BATCH = 8;
+    static constexpr int FAST_BATCH_V2 = 4;
     struct Pre { f32x4 b; };
     struct Lane { int nl, ml; unsigned oh, orr; };
-    __host__ __device__ bool fast_ok() const {
+    __host__ __device__ __forceinline__ bool fast_ok() const {
         return !y && !r && h && (ld_h % 4 == 0) && (!r_t || (r_vec && ld_r % 8 == 0 && (((uintptr_t)r_t & 15u) == 0))) &&
                (!bias || (((uintptr_t)bias & 15u) == 0)) && (int64_t)N * ld_h < (1ll << 31) && (int64_t)N * ld_r < (1ll << 31);
     }
@@ -346,9 +347,10 @@ struct EpiDx {
 
     // ---- fast protocol: the hand-off form (packed g_prev / gv_prev, packed r) of the fused engine
     static constexpr int FAST_BATCH = 8;
+    static constexpr int FAST_BATCH_V2 = 4;
     struct Pre { typename V4<T>::type x, r; };
     struct Lane { unsigned ox, orp, ogp; };
-    __host__ __device__ bool fast_ok() const {
+    __host__ __device__ __forceinline__ bool fast_ok() const {
         return x && !gx && g_prev && !r_prev && (ld_x % 4 == 0) && (ld_gp % 4 == 0) &&
                (!r_prev_t || (r_vec && ld_r_prev % 4 == 0)) && (!gv_prev || r_prev_t) &&
                ((((uintptr_t)x | (uintptr_t)g_prev | (uintptr_t)gv_prev | (uintptr_t)r_prev_t) & 7u) == 0) &&
@@ -529,12 +531,13 @@ struct EpiDw {
 
     // ---- fast protocol: the fused total gradients of an LRT layer, first draw of the minibatch (the S = 1 step)
     static constexpr int FAST_BATCH = 8;
+    static constexpr int FAST_BATCH_V2 = 4;
     struct Pre { bf16x4 lv, mu; };        // lv: sigma^2 itself (from the shadow); widened at use
     struct Lane { unsigned o, os; };      // element offsets of the lane's quad in the O x I tensors / in the O x ld_w shadows
     // The fast protocol reads mu and sigma^2 from the bf16 shadows ONLY (no runtime choice: a branch around a load makes
     // hipcc wait for each load on its own, and the batches are the point of the protocol). Without shadows the guarded
     // form above runs, on the fp32 parameters.
-    __host__ __device__ bool fast_ok() const {
+    __host__ __device__ __forceinline__ bool fast_ok() const {
         return lrt && vec && !accumulate && grad_mu && grad_lv && means && lvars && !gradWeight && !gradSum &&
                (int64_t)O * I < (1ll << 31) && mu_s && var_s && ld_w % 4 == 0 && (int64_t)O * ld_w < (1ll << 31) &&
                ((((uintptr_t)mu_s | (uintptr_t)var_s) & 7u) == 0);

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     auto issue_one_at = [&](auto pair_c, auto idx_c) {
         constexpr int P = decltype(pair_c)::value;
         constexpr int IDX = decltype(idx_c)::value;
-        (void)P;
+        (void)P; (void)IDX; (void)la_ka; (void)la_kb;             // (only the device pass uses them)
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (IDX < AG)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_ra[P], (lptr_t)(lds + la_stage + IDX * (NW * 1024) + wave * 1024), 16,
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         const typename Epi::Lane eln = epi.lane_init(q4, 4 * c16);
         const bool lane_in = fast_full || (wm0 + 4 * c16 + 4 <= epi.m_dim());
         const bool lane_edge = fast_edge && (wm0 + 4 * c16 == epi.m_dim());
-        constexpr int FB = Epi::FAST_BATCH / 2;
+        constexpr int FB = Epi::FAST_BATCH_V2;
 #pragma unroll
         for (int p0 = 0; p0 < 16; p0 += FB) {
             typename Epi::Pre pre[FB];
@@ -524,12 +524,12 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
             }
         }
     } else {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
+        vbnn_static_for<0, 16>([&](auto P) __attribute__((always_inline)) {     // (not `#pragma unroll`: see vbnn_static_for)
+            constexpr int p = decltype(P)::value;
             float t1[4], t2[4];
             epi.template apply<false>(wm0 + 4 * c16, wn0 + 4 * p + q4, r1[p], r2[p], t1, t2);
             if (any_t) stage_t(p, t1, t2);
-        }
+        });
     }
     if (any_t) {
         // rows of the transposed outputs: lane (row = lane >> 3 (+8 per pass), 8 consecutive n = 8 (lane & 7) ..)

@@ -230,7 +230,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     }
 
     // K-major operands: transpose reads. Lane j = lane & 15 of its group addresses k-row (j >> 2), columns 4 (j & 3) ..
-    typedef __attribute__((address_space(3))) bf16x4* lds4_t;
     const int trq = (lane & 15) >> 2, trp = lane & 3;
     const int thx = (trq | ((q & 1) << 2)) << 1;              // 2 h(k) of this lane's k-rows (same for both reads)
     int a_tr[4], b_tr[4];                                     // byte offset of the lane's 8 bytes, per 16-row block
@@ -544,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                     // FOLD_SERIAL quads at a time, also for the optimiser: the next group's coordinates "depend" on this
                     // result (32 interleaved Philox blocks beside 128 live accumulators spill; two at a time fit and
                     // give the VALU two independent dependency chains)
-                    if (Epi::FOLD_SERIAL > 0 && (j % Epi::FOLD_SERIAL) == Epi::FOLD_SERIAL - 1)
+                    if (Epi::FOLD_SERIAL > 0 && (j % (Epi::FOLD_SERIAL > 0 ? Epi::FOLD_SERIAL : 1)) == Epi::FOLD_SERIAL - 1)
                         asm volatile("" : "+s"(fn0), "+s"(fm0)
                                      : "v"(acc[i0 + b][j][0]), "v"(acc[i0 + b][j][1]), "v"(acc[i0 + b][j][2]), "v"(acc[i0 + b][j][3]),
                                        "v"(acc[i0 + b][j ? j - 1 : 0][0]));
