@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvbnn_hip.so")
+# VBNN_HIP_LIB: another build of the same library (A/B builds; the name lua/vbnn_ffi.lua reads too)
+LIB_PATH = os.environ.get("VBNN_HIP_LIB") or os.path.join(_HERE, "lib", "libvbnn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 OK = 0

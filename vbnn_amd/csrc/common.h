@@ -167,6 +167,16 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, floa
     }
 }
 
+// Output store of an epilogue in the SGPR-base form: `base` wave-uniform, `off` the lane's ELEMENT offset.
+// (One place to change the stores' cache policy. Tried in r02 as inline asm with `sc1` / `nt`: write-through stores do not
+// shorten the step -- the ~5 us between two large launches is not an L2 write-back -- and inline-asm VMEM behind a
+// v_readfirstlane'd base needs its own `s_nop 4`: the hazard recogniser does not look inside asm, the `nt` build
+// faulted on a stale SGPR base. Plain stores it is.)
+template <class V, class T>
+__device__ __forceinline__ void vbnn_store_out(T* base, unsigned off, V v) {
+    *reinterpret_cast<V*>(base + off) = v;
+}
+
 // load 4 consecutive elements as floats (p 4-element aligned when `vec` is true); lanes past `valid` read 0
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float (&v)[4], int valid, bool vec);

@@ -42,6 +42,11 @@
 template <typename T> struct V4;                 // four consecutive elements as one register-resident vector
 template <> struct V4<float> { typedef f32x4 type; };
 template <> struct V4<bf16_t> { typedef bf16x4 type; };
+// four values to [base + off .. + 3] as ONE vector store (base wave-uniform, off the lane's element offset)
+template <typename T>
+__device__ __forceinline__ void store4_out(T* base, unsigned off, float a, float b, float c, float d) {
+    vbnn_store_out(base, off, typename V4<T>::type{Elt<T>::to(a), Elt<T>::to(b), Elt<T>::to(c), Elt<T>::to(d)});
+}
 
 // ---- FWD: M = output units o, N = minibatch rows n ---------------------------------------------
 // WN/MAP: y = acc1 + b                      (inherited nn.Linear:updateOutput, VBLinear.lua:7)
@@ -172,7 +177,7 @@ struct EpiFwd {
                 rv[j] = 0.f;
             }
         }
-        if (r_t) store4<T>(r_t + ((int64_t)un * ld_r + um) + ln.orr, rv[0], rv[1], rv[2], rv[3], 4, true);
+        if (r_t) store4_out<T>(r_t + ((int64_t)un * ld_r + um), ln.orr, rv[0], rv[1], rv[2], rv[3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             t1[j] = relu ? fmaxf(yv[j], 0.f) : yv[j];
@@ -180,8 +185,8 @@ struct EpiFwd {
             t2[j] = hr * hr;
         }
         const int64_t ub = (int64_t)un * ld_h + um;
-        store4<T>(h + ub + ln.oh, t1[0], t1[1], t1[2], t1[3], 4, true);
-        if (h2) store4<T>(h2 + ub + ln.oh, t2[0], t2[1], t2[2], t2[3], 4, true);
+        store4_out<T>(h + ub, ln.oh, t1[0], t1[1], t1[2], t1[3]);
+        if (h2) store4_out<T>(h2 + ub, ln.oh, t2[0], t2[1], t2[2], t2[3]);
     }
 
     // ---- fold protocol (LRT only: acc2 = v)
@@ -241,7 +246,7 @@ struct EpiFwd {
             out[j] = fmaf(sd, z.v[j], fp.b[j]);
             rv[j] = pos ? 0.5f * z.v[j] * rs : 0.f;
         }
-        if (r_t) store4<T>(r_t + ((int64_t)un * ld_r + um) + ln.orr, rv[0], rv[1], rv[2], rv[3], 4, true);
+        if (r_t) store4_out<T>(r_t + ((int64_t)un * ld_r + um), ln.orr, rv[0], rv[1], rv[2], rv[3]);
         return out;
     }
     __device__ __forceinline__ Pre load_folded(int, int, const Lane&) const { return Pre{f32x4{0.f, 0.f, 0.f, 0.f}}; }
@@ -254,8 +259,8 @@ struct EpiFwd {
             t2[j] = hr * hr;
         }
         const int64_t ub = (int64_t)un * ld_h + um;
-        store4<T>(h + ub + ln.oh, t1[0], t1[1], t1[2], t1[3], 4, true);
-        if (h2) store4<T>(h2 + ub + ln.oh, t2[0], t2[1], t2[2], t2[3], 4, true);
+        store4_out<T>(h + ub, ln.oh, t1[0], t1[1], t1[2], t1[3]);
+        if (h2) store4_out<T>(h2 + ub, ln.oh, t2[0], t2[1], t2[2], t2[3]);
     }
 #else
     // -DVBNN_FWD_PARK (A/B only): the kernel parks the raw variance tile in a scratch tile, the accumulator continues
@@ -376,8 +381,8 @@ struct EpiDx {
             t2[j] = t1[j] * Elt<T>::from(pre.r[j]);
         }
         const int64_t ub = (int64_t)un * ld_gp + um;
-        store4<T>(g_prev + ub + ln.ogp, t1[0], t1[1], t1[2], t1[3], 4, true);
-        if (gv_prev) store4<T>(gv_prev + ub + ln.ogp, t2[0], t2[1], t2[2], t2[3], 4, true);
+        store4_out<T>(g_prev + ub, ln.ogp, t1[0], t1[1], t1[2], t1[3]);
+        if (gv_prev) store4_out<T>(gv_prev + ub, ln.ogp, t2[0], t2[1], t2[2], t2[3]);
     }
 
     // ---- fold protocol (LRT only: acc2 = gv sigma^2): the accumulator continues from 2 x . acc2
@@ -407,8 +412,8 @@ struct EpiDx {
             t2[j] = t1[j] * Elt<T>::from(pre.r[j]);
         }
         const int64_t ub = (int64_t)un * ld_gp + um;
-        store4<T>(g_prev + ub + ln.ogp, t1[0], t1[1], t1[2], t1[3], 4, true);
-        if (gv_prev) store4<T>(gv_prev + ub + ln.ogp, t2[0], t2[1], t2[2], t2[3], 4, true);
+        store4_out<T>(g_prev + ub, ln.ogp, t1[0], t1[1], t1[2], t1[3]);
+        if (gv_prev) store4_out<T>(gv_prev + ub, ln.ogp, t2[0], t2[1], t2[2], t2[3]);
     }
 };
 
@@ -575,8 +580,8 @@ struct EpiDw {
             gm[j] = fmaf(k_mu, (float)pre.mu[j], lm);
             gl[j] = fmaf(k_lv, fmaf(var, inv_vh, -1.0f), ll);
         }
-        if (part != 2) *reinterpret_cast<f32x4*>(grad_mu + ub + ln.o) = gm;
-        if (part != 1) *reinterpret_cast<f32x4*>(grad_lv + ub + ln.o) = gl;
+        if (part != 2) vbnn_store_out(grad_mu + ub, ln.o, gm);
+        if (part != 1) vbnn_store_out(grad_lv + ub, ln.o, gl);
     }
 
     // ---- fold protocol: the two outputs depend on one accumulator each, so d/dlvars is FINISHED between the passes
@@ -640,6 +645,6 @@ struct EpiDw {
         f32x4 gm;
 #pragma unroll
         for (int j = 0; j < 4; ++j) gm[j] = fmaf(k_mu, (float)pre.mu[j], scale * a[j] * invS);
-        *reinterpret_cast<f32x4*>(grad_mu + ((int64_t)un * I + um) + ln.o) = gm;
+        vbnn_store_out(grad_mu + ((int64_t)un * I + um), ln.o, gm);
     }
 };
