@@ -77,6 +77,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform on the scalar side
+    // Static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4: the
+    // younger wave of a SIMD loses every issue arbitration at equal priority). Measured on the wide step, two rounds of
+    // three builds on one box: 0.824 / 0.827 ms against 0.828 / 0.830 without and 0.827 / 0.832 with the OTHER half raised.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int wr = wave >> 2, wc = wave & 3;
     Epi epi = epi_in;
 
