@@ -47,7 +47,8 @@ typedef struct vbnn_ctx vbnn_ctx;
 int vbnn_abi_version(void);
 const char* vbnn_last_error(void);
 
-/* test / A-B hook. VBNN_DEBUG_GEMM_KERNEL: 0 = pick by shape (default), 1 = always the general MFMA
+/* test / A-B hook, PROCESS-wide (kernel selection is a property of the build under test, not of a context: set it
+ * before the contexts start launching, from one thread). VBNN_DEBUG_GEMM_KERNEL: 0 = pick by shape (default), 1 = always the general MFMA
  * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it, 3 = its two-pass 256 x 256 variant
  * whenever the shape and outputs allow it (whole tiles, the fused configuration). */
 #define VBNN_DEBUG_GEMM_KERNEL 0
