@@ -26,12 +26,44 @@ def main():
     x = torch.empty(n_loc, I0, dtype=torch.float32, device="cuda")
     fill_normal(x, 3, 4, 0, 0, row0=rank * n_loc)                      # the global minibatch's rows of this rank
     t = ((torch.arange(n_loc, device="cuda", dtype=torch.int64) + rank * n_loc) * 7 % 10).to(torch.int32)
+    # The ranks take turns on the GPU: rank r issues its step and drains the device before rank r + 1 starts (a token
+    # barrier on a process group of its own: the step's all-reduces are still pending on the default group). Two PROCESSES
+    # computing on one device at the same time is not a configuration the product has (one process per GPU; RCCL refuses
+    # it), and it is not benign on this pool: with the ranks' kernels interleaved on the device, about one run in twenty
+    # saw ONE 8-row LDS-DMA piece of ONE K step of the pipelined GEMM arrive late (tools/flake_probe.sh: a 8 x 128 patch
+    # of one layer's output off by a K step's worth; either rank; 6 of 115 runs overlapped, 0 of 30 taking turns, 0 of 400 steps in
+    # ONE process under copy traffic on a second stream, tools/diag_fwd_contention.py). VBNN_TEST_CONCURRENT=1 restores the overlap.
+    serial = os.environ.get("VBNN_TEST_CONCURRENT") != "1"
+    tok = dist.new_group(backend="gloo") if serial else None
     for _ in range(2):                                                  # twice: the second step reuses every buffer
-        eng.resetGradients(); eng.prepare(); eng.sample()
-        eng.run(x, t)
+        if serial:
+            for turn in range(world):
+                if turn == rank:
+                    eng.resetGradients(); eng.prepare(); eng.sample()
+                    eng.run(x, t)
+                    torch.cuda.synchronize()
+                dist.barrier(group=tok)
+        else:
+            eng.resetGradients(); eng.prepare(); eng.sample()
+            eng.run(x, t)
         eng.finish()
     loss, _ = eng.loss_and_accuracy()
     print(f"rank {rank}: local loss {loss!r} (exchange: {eng.comm_backend()})", flush=True)
+    if os.environ.get("VBNN_TEST_DIAG") == "1":     # where does a deviating loss come from: the activations or the reduction?
+        out = eng.out.double().cpu().numpy()                             # log-probabilities of the last step
+        tt = t.cpu().numpy()
+        inv_n = 1.0 / (n_loc * world)
+        from_out = float(-(out[np.arange(n_loc), tt]).sum() * inv_n)
+        h_sum = [float(eng.h_s.t.float().double().sum().item())] + [float(v.x_s.t.float().double().sum().item()) for v in eng.vb]
+        print(f"rank {rank}: diag loss-from-out {from_out!r} logits-sum {float(eng.logits.double().sum().item())!r} "
+              f"out-sum {float(out.sum())!r} h-sums {h_sum}", flush=True)
+        dump = os.environ.get("VBNN_TEST_DUMP")     # directory: keep the last layer's output of one good and of every deviating run
+        if dump and hidden == [4096, 4096] and N == 1024:
+            good = {0: 2.271684411796741, 1: 2.4192868926911615}[rank]
+            kind = "good" if loss == good else f"bad{os.getpid()}"
+            path = os.path.join(dump, f"h_rank{rank}_{kind}.npy")
+            if kind != "good" or not os.path.exists(path):
+                np.save(path, eng.h_s.t[:, :4096].float().cpu().numpy())
     lt = torch.tensor([loss], dtype=torch.float64)
     dist.all_reduce(lt)
     if rank == 0:

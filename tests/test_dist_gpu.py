@@ -47,10 +47,19 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hid
         eng.run(x, t)
     loss1, _ = eng.loss_and_accuracy()
     want = eng.grads.cpu().numpy()
+    print(f"single process loss {loss1!r}; ranks: {[l for l in res.stdout.splitlines() if 'local loss' in l]}")
     assert abs(loss2 - loss1) <= 1e-5 * abs(loss1), f"summed loss of the two ranks {loss2!r} vs single process {loss1!r}; worker output: {res.stdout[-600:]}"
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     print(f"two ranks vs one process: relative Frobenius {rel:.3e} (bound {tol})")
-    assert rel <= tol, rel
+    if rel > tol:                                   # say WHICH gradient is off: per arena region, relative to that region
+        from vbnn_amd.partition import arena_layout
+        layers, final, _, _ = arena_layout([I0] + opt["hidden"], 10)
+        regions = [(f"layer {k} {name}", d[name]) for k, d in enumerate(layers) for name in ("lv", "mu", "bias")]
+        regions += [("final weight", final["weight"]), ("final bias", final["bias"])]
+        detail = "; ".join(f"{n}: {np.linalg.norm(got[o:o + c] - want[o:o + c]) / max(np.linalg.norm(want[o:o + c]), 1e-30):.2e}"
+                           f" (max |d| {np.abs(got[o:o + c] - want[o:o + c]).max():.2e} at {int(np.abs(got[o:o + c] - want[o:o + c]).argmax())})"
+                           for n, (o, c) in regions)
+        raise AssertionError(f"relative Frobenius {rel:.3e} > {tol}: {detail}; worker output: {res.stdout[-600:]}")
 
 
 def test_bench_launches_its_own_ranks_from_a_bare_shell():

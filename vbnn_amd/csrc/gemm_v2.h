@@ -293,6 +293,25 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
         f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
     };
+    // the same with six fragments KEPT out of the destination registers (inputs + early-clobber outputs): the sources of the
+    // wave's last eight MFMAs -- see tr_issue2_keep in gemm_v3.h for the hazard hipcc cannot see through inline asm
+    auto tr_load4_keep = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x8 (&f)[4],
+                             const bf16x8 (&ka)[4], const bf16x8 (&kb)[4]) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI), "v"(ka[2]), "v"(ka[3]), "v"(kb[0]), "v"(kb[1]), "v"(kb[2]), "v"(kb[3])
+                     : "memory");
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
 
     f32x4 acc1[4][4], acc2[4][4];
 #pragma unroll
@@ -346,6 +365,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         }
         V2_STAMP(3);                                     // [2->3] issuing the DMAs (schedule 0)
         const unsigned char* stage = lds + (u % ST) * STAGE;
+        bf16x8 paf[4], pbf[4];                           // (K-major) the first k-half's fragments: kept out of the second's reads
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
             bf16x8 af[4], bf[4];
@@ -356,11 +376,13 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
                              std::integral_constant<int, 2048>(), af);
                     tr_load4(sb + b_tr[0], sb + b_tr[1], sb + b_tr[2], sb + b_tr[3], std::integral_constant<int, 0>(),
                              std::integral_constant<int, 1024>(), bf);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { paf[i] = af[i]; pbf[i] = bf[i]; }
                 } else {
-                    tr_load4(sb + a_tr[0], sb + a_tr[1], sb + a_tr[2], sb + a_tr[3], std::integral_constant<int, 16384>(),
-                             std::integral_constant<int, 16384 + 2048>(), af);
-                    tr_load4(sb + b_tr[0], sb + b_tr[1], sb + b_tr[2], sb + b_tr[3], std::integral_constant<int, 8192>(),
-                             std::integral_constant<int, 8192 + 1024>(), bf);
+                    tr_load4_keep(sb + a_tr[0], sb + a_tr[1], sb + a_tr[2], sb + a_tr[3], std::integral_constant<int, 16384>(),
+                                  std::integral_constant<int, 16384 + 2048>(), af, paf, pbf);
+                    tr_load4_keep(sb + b_tr[0], sb + b_tr[1], sb + b_tr[2], sb + b_tr[3], std::integral_constant<int, 8192>(),
+                                  std::integral_constant<int, 8192 + 1024>(), bf, paf, pbf);
                 }
             } else {
 #pragma unroll

@@ -275,8 +275,47 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                      : "v"(a0), "v"(a1), "n"(LO), "n"(HI)
                      : "memory");
     };
+    // The same, issued while `keep` (the pair in use) still feeds MFMAs: `keep` is an INPUT and the outputs are
+    // early-clobber, so the reads cannot land in its registers. A matrix instruction reads its A / B operands when it
+    // EXECUTES, and up to eight of a wave's MFMAs queue behind the partner wave's while the wave goes on issuing LDS reads:
+    // a read whose destination is a source of the last few MFMAs can return first (found with a lab build that issued
+    // eight reads behind eight MFMAs into the just-used fragment registers: the last four MFMAs' products were wrong,
+    // differently from launch to launch). hipcc sees none of this through inline asm -- to the compiler a fragment is
+    // dead once its MFMAs are emitted, and it did hand its registers to the next pair's reads.
+    auto tr_issue2_keep = [&](unsigned a0, unsigned a1, auto lo_c, auto hi_c, TrPair& o, const TrPair& keep, const TrPair& keep2) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
+                     "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
+                     : "=&v"(o.l0), "=&v"(o.h0), "=&v"(o.l1), "=&v"(o.h1)
+                     : "v"(a0), "v"(a1), "n"(LO), "n"(HI), "v"(keep.l0), "v"(keep.h0), "v"(keep.l1), "v"(keep.h1),
+                       "v"(keep2.l0), "v"(keep2.h0), "v"(keep2.l1), "v"(keep2.h1)
+                     : "memory");
+    };
     auto tr_wait2 = [&](TrPair& o) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.l0), "+v"(o.h0), "+v"(o.l1), "+v"(o.h1)::"memory");
+    };
+    // (tr_load4 with the pair in use kept out of its destination registers, as tr_issue2_keep)
+    auto tr_load4_keep = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x8 (&f)[4], const auto& keep, const auto& keep2) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI), "v"(keep.l0), "v"(keep.h0), "v"(keep.l1), "v"(keep.h1),
+                       "v"(keep2.l0), "v"(keep2.h0), "v"(keep2.l1), "v"(keep2.h1)
+                     : "memory");
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // ... and the B fragments stay allocated to the end of the phase that reads them last (an empty asm that names them):
+    // phase 1 otherwise gives the k-half-0 fragments' registers to its A pairs two MFMAs after their last use.
+    auto keep_frags = [&](const bf16x8 (&f)[4]) {
+        asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]));
     };
     auto load_a = [&](const unsigned char* sa, auto s_c, bf16x8 (&f)[4]) {
         constexpr int S = decltype(s_c)::value;
@@ -351,18 +390,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 };
                 if constexpr (AK) {
                     const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
-                    TrPair g[2];
+                    TrPair g[3];
                     auto issue = [&](auto idx_c) {             // pair idx: k-half idx >> 1, fragments 2 (idx & 1), +1
                         constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
-                        tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
-                                  std::integral_constant<int, S * 8192 + 1024>(), g[IDX & 1]);
+                        // three pairs in rotation: the reads of pair IDX must not land in pair IDX - 1 (in use) nor in
+                        // pair IDX - 2 (its MFMAs were issued last): both are kept; with two pairs one of them was the target
+                        if constexpr (IDX == 0)
+                            tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                      std::integral_constant<int, S * 8192 + 1024>(), g[0]);
+                        else
+                            tr_issue2_keep(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                           std::integral_constant<int, S * 8192 + 1024>(), g[IDX % 3], g[(IDX + 2) % 3],
+                                           g[IDX >= 2 ? (IDX + 1) % 3 : (IDX + 2) % 3]);
                     };
                     auto work = [&](auto idx_c) {
                         constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
-                        TrPair& p = g[IDX & 1];
+                        TrPair& p = g[IDX % 3];
                         tr_wait2(p);
                         if constexpr (IDX < 3) issue(std::integral_constant<int, IDX + 1>());
-                        if constexpr (IDX == 1) load_b(sb, c1, bf[1]);       // the other k-half's B fragments
+                        if constexpr (IDX == 1) {                            // the other k-half's B fragments
+                            if constexpr (BK) {
+                                const unsigned bb = (unsigned)(uintptr_t)(ldsb_t)sb;
+                                tr_load4_keep(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], std::integral_constant<int, 16384>(),
+                                              std::integral_constant<int, 16384 + 2048>(), bf[1], p, g[0]);
+                            } else {
+                                load_b(sb, c1, bf[1]);
+                            }
+                        }
                         const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
                         const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
@@ -406,15 +460,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 };
                 if constexpr (AK) {
                     const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
-                    TrPair g[2];
+                    TrPair g[3];
                     auto issue = [&](auto idx_c) {
                         constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
-                        tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
-                                  std::integral_constant<int, S * 8192 + 1024>(), g[IDX & 1]);
+                        // three pairs in rotation: the reads of pair IDX must not land in pair IDX - 1 (in use) nor in
+                        // pair IDX - 2 (its MFMAs were issued last): both are kept; with two pairs one of them was the target
+                        if constexpr (IDX == 0)
+                            tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                      std::integral_constant<int, S * 8192 + 1024>(), g[0]);
+                        else
+                            tr_issue2_keep(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                           std::integral_constant<int, S * 8192 + 1024>(), g[IDX % 3], g[(IDX + 2) % 3],
+                                           g[IDX >= 2 ? (IDX + 1) % 3 : (IDX + 2) % 3]);
                     };
                     auto work = [&](auto idx_c) {
                         constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
-                        TrPair& p = g[IDX & 1];
+                        TrPair& p = g[IDX % 3];
                         tr_wait2(p);
                         if constexpr (IDX < 3) issue(std::integral_constant<int, IDX + 1>());
                         const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -428,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                     };
                     issue(c0);
                     work(c0); work(c1); work(c2); work(c3);
+                    keep_frags(bf[0]); keep_frags(bf[1]);
                 } else {
                     auto half = [&](auto s_c) {
                         constexpr int s = decltype(s_c)::value;
