@@ -13,7 +13,7 @@ def regs(tok):
 recent, viol, kernel = [], 0, "?"
 for i, l in enumerate(lines):
     t = l.strip()
-    if t.endswith(":") and t.startswith("_Z"): kernel, recent = t[:60], []
+    if l.startswith("_Z") and ":" in l: kernel, recent = l.split(":")[0][:70], []
     if t.startswith("s_barrier"): recent = []
     if t.startswith("v_mfma"):
         ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
