@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--prepare-each-step", action="store_true", help="round 1's protocol: the parameter sweep inside every step")
     ap.add_argument("--with-update", action="store_true", help="also time step + optimiser update (reported beside the metric)")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
+    ap.add_argument("--exchange-dtype", default="f32", choices=["f32", "bf16"], help="data-parallel exchange payload: fp32 (default, the "
+                    "metric) or the optional bf16 copy (half the bytes, a DIFFERENT gradient: reported as an option, config.exchange_dtype)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -234,7 +236,7 @@ def main():
     N = cfg["batch"]
     opt = dict(var_init=1e-3, B=1e6, S=args.S, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
                hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap,
-               criterion=cfg.get("criterion", "nll"),
+               criterion=cfg.get("criterion", "nll"), exchange_dtype=args.exchange_dtype,
                state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
     for kv in filter(None, args.debug_set.split(",")):
@@ -341,7 +343,7 @@ def main():
     if use_dist:
         ident = [None] * world
         dist.all_gather_object(ident, (rank, local_rank, device_identity(torch, local_rank), os.getpid()))
-        comm = {"backend": eng.comm_backend(), "ranks_seen": [list(i) for i in ident],
+        comm = {"backend": eng.comm_backend(), "payload": eng.exchange_dtype, "ranks_seen": [list(i) for i in ident],
                 "distinct_devices": len({i[2] for i in ident}), "allreduce": eng.time_buckets(5)}
 
     if rank == 0:

@@ -343,6 +343,13 @@ int vbnn_comm_destroy(vbnn_comm* comm);
 int vbnn_comm_info(vbnn_comm* comm, int* rank, int* world, int* ranks_in_comm /* as RCCL counts them */);
 int vbnn_allreduce_grads(vbnn_comm* comm, float* buf, int64_t n);
 int vbnn_comm_finish(vbnn_comm* comm);
+/* OPTIONAL half-size exchange (160.1 MB fp32 / 80.1 MB bf16 per step of the wide configuration): the
+ * same call on a bf16 copy of the bucket, with vbnn_cast_grads to make it and to widen the sum back. The default exchange
+ * is fp32; this one rounds every rank's contribution to bf16 (RNE) and lets RCCL sum in bf16 -- a different gradient
+ * (relative 2^-9 per element and hop), for hosts that want the exchange hidden more than the last bits.
+ * vbnn_cast_grads(to_bf16 = 1): dst[i] = bf16(src[i]), src fp32; (0): dst[i] = float(src[i]), src bf16; on the context's stream. */
+int vbnn_allreduce_grads_bf16(vbnn_comm* comm, void* buf_bf16, int64_t n);
+int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int64_t n);
 /* all_dev[r] = rank r's *mine_dev (device memory, 8 bytes per rank), gathered over the same communicator and stream:
  * lets the host verify that `world` distinct processes / devices take part in the exchange. */
 int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);

@@ -139,6 +139,8 @@ int vbnn_comm_destroy(vbnn_comm* comm);
 int vbnn_comm_info(vbnn_comm* comm, int* rank, int* world, int* ranks_in_comm );
 int vbnn_allreduce_grads(vbnn_comm* comm, float* buf, int64_t n);
 int vbnn_comm_finish(vbnn_comm* comm);
+int vbnn_allreduce_grads_bf16(vbnn_comm* comm, void* buf_bf16, int64_t n);
+int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int64_t n);
 int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
 int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);
 int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx, int64_t n);

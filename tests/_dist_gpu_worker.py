@@ -20,7 +20,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=1, mode="lrt", dtype=dtype, seed=3, input_size=I0, hidden=hidden,
-               n_classes=10, fuse_kl=True)
+               n_classes=10, fuse_kl=True, exchange_dtype=sys.argv[6] if len(sys.argv) > 6 else "f32")
     eng = FusedMLP(opt, world_size=world, rank=rank)
     n_loc = N // world
     x = torch.empty(n_loc, I0, dtype=torch.float32, device="cuda")

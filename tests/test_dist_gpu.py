@@ -22,16 +22,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("dtype,hidden,I0,N,tol", [("f32", "50,34", 70, 64, 2e-5), ("bf16", "512,256", 256, 512, 2e-3),
-                                                    ("bf16", "4096,4096", 784, 1024, 2e-3)])
-def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hidden, I0, N, tol):
+@pytest.mark.parametrize("dtype,hidden,I0,N,tol,xdt", [("f32", "50,34", 70, 64, 2e-5, "f32"), ("bf16", "512,256", 256, 512, 2e-3, "f32"),
+                                                        ("bf16", "4096,4096", 784, 1024, 2e-3, "f32"),
+                                                        ("bf16", "512,256", 256, 512, 6e-3, "bf16")])
+def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hidden, I0, N, tol, xdt):
     import torch
     from vbnn_amd.engine import FusedMLP
     from vbnn_amd.nn import fill_normal
     out = str(tmp_path / "r")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), out, dtype, hidden, str(I0), str(N)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), out, dtype, hidden, str(I0), str(N), xdt]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     got = np.load(out + ".grads.npy")

@@ -1027,6 +1027,35 @@ def test_rccl_exchange_through_the_c_abi_one_rank(nnmod):
     ex.close()
 
 
+@pytest.mark.parametrize("hidden,I0,N", [([50, 34], 70, 64), ([512, 256], 256, 512)])
+def test_bf16_exchange_option_with_one_rank(nnmod, hidden, I0, N):
+    """opt.exchange_dtype = "bf16" (the optional half-size exchange) through RCCL with a world of one: every bucket is
+    rounded to bf16 (RNE), all-reduced in place on the staging arena, and widened back behind the exchange -- so the arena
+    must hold EXACTLY bf16(gradients of the same step without the option); the default engine's gradients are untouched
+    by the option's existence. Odd bucket offsets (the 50-34 net) take the cast kernel's scalar path."""
+    from vbnn_amd.engine import FusedMLP
+    from vbnn_amd.nn import fill_normal
+    opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=1, mode="lrt", dtype="bf16", seed=3, input_size=I0, hidden=hidden,
+               n_classes=10, fuse_kl=True)
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    fill_normal(x, 3, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    grads = {}
+    for name, extra in (("plain", {}), ("f32", dict(force=True)), ("bf16", dict(force=True, exchange_dtype="bf16"))):
+        eng = FusedMLP(dict(opt, **{k: v for k, v in extra.items() if k != "force"}), force_reduce=extra.get("force", False))
+        for _ in range(2):
+            eng.resetGradients(); eng.prepare(); eng.sample()
+            eng.run(x, t)
+            eng.finish()
+        torch.cuda.synchronize()
+        if extra.get("force"):
+            assert eng.comm_backend() == "vbnn_comm/rccl", eng.comm_backend()
+        grads[name] = eng.grads.clone()
+    assert torch.equal(grads["plain"], grads["f32"])
+    assert torch.equal(grads["bf16"], grads["plain"].to(torch.bfloat16).float())
+    assert not torch.equal(grads["bf16"], grads["plain"])
+
+
 # ------------------------------------------------------------------------------------------- MSE head (BASELINE configs[4])
 @pytest.mark.parametrize("N,D", [(1, 1), (37, 70), (64, 256)])
 def test_mse_criterion_matches_oracle(nnmod, oracle, N, D):

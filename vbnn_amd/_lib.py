@@ -110,6 +110,8 @@ _SIGS = {
     "vbnn_comm_info": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
     "vbnn_allreduce_grads": ([_vp, _vp, _i64], _i),
     "vbnn_comm_finish": ([_vp], _i),
+    "vbnn_allreduce_grads_bf16": ([_vp, _vp, _i64], _i),
+    "vbnn_cast_grads": ([_vp, _i, _vp, _vp, _i64], _i),
     "vbnn_comm_allgather_u64": ([_vp, _vp, _vp], _i),
     "vbnn_relu_forward": ([_vp, _vp, _vp, _i64], _i),
     "vbnn_relu_backward": ([_vp, _vp, _vp, _vp, _i64], _i),

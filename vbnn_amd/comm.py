@@ -56,8 +56,9 @@ class RcclExchange:
         self.backend = "vbnn_comm/rccl"
 
     def allreduce(self, bucket):
-        assert bucket.dtype == torch.float32 and bucket.is_contiguous()
-        L.check(L.lib().vbnn_allreduce_grads(self.h, C.c_void_p(bucket.data_ptr()), bucket.numel()))
+        assert bucket.dtype in (torch.float32, torch.bfloat16) and bucket.is_contiguous()
+        fn = L.lib().vbnn_allreduce_grads if bucket.dtype == torch.float32 else L.lib().vbnn_allreduce_grads_bf16
+        L.check(fn(self.h, C.c_void_p(bucket.data_ptr()), bucket.numel()))
 
     def finish(self):
         L.check(L.lib().vbnn_comm_finish(self.h))

@@ -158,6 +158,17 @@ extern "C" int vbnn_allreduce_grads(vbnn_comm* c, float* buf, int64_t n) {
     VBNN_API_END
 }
 
+extern "C" int vbnn_allreduce_grads_bf16(vbnn_comm* c, void* buf, int64_t n) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(c && buf && n > 0, "argument");
+    VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
+    VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    VBNN_CHECK_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclBfloat16, ncclSum, c->comm, c->stream));
+    c->pending += 1;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
 extern "C" int vbnn_comm_finish(vbnn_comm* c) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(c, "null comm");

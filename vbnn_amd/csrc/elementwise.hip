@@ -1066,3 +1066,37 @@ extern "C" int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64
     VBNN_API_END
 }
 
+// ---- the optional bf16 exchange's casts (include/vbnn_hip.h, vbnn_cast_grads): 8 elements per thread, 16-byte accesses
+template <bool TO_BF16>
+__global__ __launch_bounds__(256) void k_cast_grads(const void* __restrict__ src, void* __restrict__ dst, int64_t n, int vec) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    if (vec && i0 + 8 <= n) {
+        if constexpr (TO_BF16) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(static_cast<const float*>(src) + i0)[0];
+            const f32x4 b = reinterpret_cast<const f32x4*>(static_cast<const float*>(src) + i0)[1];
+            reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(dst) + i0)[0] =
+                bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+        } else {
+            const bf16x8 v = reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(src) + i0)[0];
+            reinterpret_cast<f32x4*>(static_cast<float*>(dst) + i0)[0] = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            reinterpret_cast<f32x4*>(static_cast<float*>(dst) + i0)[1] = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        }
+    } else {
+        for (int64_t i = i0; i < n && i < i0 + 8; ++i) {
+            if constexpr (TO_BF16) static_cast<bf16_t*>(dst)[i] = (bf16_t)static_cast<const float*>(src)[i];
+            else static_cast<float*>(dst)[i] = (float)static_cast<const bf16_t*>(src)[i];
+        }
+    }
+}
+
+extern "C" int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int64_t n) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && src && dst && n > 0, "argument");
+    const int vec = (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0;      // (odd bucket offsets of test-sized nets: scalar path)
+    const unsigned nb = (unsigned)((n + 2047) / 2048);
+    if (to_bf16) hipLaunchKernelGGL(k_cast_grads<true>, dim3(nb), dim3(256), 0, ctx->stream, src, dst, n, vec);
+    else hipLaunchKernelGGL(k_cast_grads<false>, dim3(nb), dim3(256), 0, ctx->stream, src, dst, n, vec);
+    return vbnn_check_launch("k_cast_grads");
+    VBNN_API_END
+}

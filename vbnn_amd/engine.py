@@ -37,6 +37,9 @@ class FusedMLP:
         self.world, self.rank, self.pg = world_size, rank, process_group
         self.reduce = world_size > 1 or force_reduce
         self._exchange = None                 # made on first use (vbnn_amd/comm.py): RCCL through the C ABI
+        self.exchange_dtype = str(opt.get("exchange_dtype", "f32"))      # "bf16": the optional half-size exchange (_reduce)
+        assert self.exchange_dtype in ("f32", "bf16")
+        self._stage, self._staged = None, []
         self.fuse_kl = bool(opt.get("fuse_kl", True))
         # "nll": LogSoftMax + ClassNLLCriterion (mlp.lua:30-32); "mse": nn.MSECriterion on the final Linear's outputs
         # (BASELINE.json configs[4], a regression target of n_classes dimensions -- not in the reference)
@@ -501,9 +504,23 @@ class FusedMLP:
     # ---- data-parallel exchange: sum all-reduce of one layer's gradient bucket over RCCL/xGMI, issued
     # right after that layer's accGradParameters so it overlaps the rest of backward. The criterion
     # already divides by the GLOBAL batch and the KL gradient carries 1/world, so the sum is the result.
+    # opt.exchange_dtype = "bf16" (default "f32"): the bucket is rounded to bf16 into a half-size staging arena, THAT is
+    # all-reduced (80 instead of 160 MB per step of the wide configuration), and finish() widens the sums
+    # back into the fp32 arena. A different gradient (every rank's contribution rounded, RCCL sums in bf16): an option for
+    # hosts whose step is exchange-bound, never the default, and the bench line says which one ran.
     def _reduce(self, bucket):
-        if self.reduce:
+        if not self.reduce:
+            return
+        if self.exchange_dtype != "bf16":
             self.exchange().allreduce(bucket)
+            return
+        if self._stage is None:
+            self._stage = torch.zeros(self.grads.numel(), dtype=torch.bfloat16, device=self.device)
+        off = bucket.storage_offset() - self.grads.storage_offset()
+        stage = self._stage[off:off + bucket.numel()]
+        L.check(L.lib().vbnn_cast_grads(self.ctx.h, 1, _p(bucket), _p(stage), bucket.numel()))
+        self.exchange().allreduce(stage)
+        self._staged.append((bucket, stage))
 
     def exchange(self):
         if self._exchange is None:
@@ -518,6 +535,9 @@ class FusedMLP:
         """Order the compute stream behind the outstanding all-reduces (end of the step)."""
         if self._exchange is not None:
             self._exchange.finish()
+        for bucket, stage in self._staged:            # (bf16 exchange) the sums, widened back behind the exchange
+            L.check(L.lib().vbnn_cast_grads(self.ctx.h, 0, _p(stage), _p(bucket), bucket.numel()))
+        self._staged = []
 
     def _early(self, v, lrt=True):
         return v.msg_early is not None and lrt and self.fuse_kl and getattr(v, "early_ok", True)
@@ -539,7 +559,7 @@ class FusedMLP:
         import time
         out = []
         for b in self.buckets():
-            scratch = torch.zeros_like(b)
+            scratch = torch.zeros_like(b) if self.exchange_dtype == "f32" else torch.zeros(b.numel(), dtype=torch.bfloat16, device=b.device)
             for _ in range(2):
                 self.exchange().allreduce(scratch); self.finish()
             torch.cuda.synchronize(self.device)
@@ -549,7 +569,7 @@ class FusedMLP:
             self.finish()
             torch.cuda.synchronize(self.device)
             ms = (time.perf_counter() - t0) / reps * 1e3
-            nbytes = b.numel() * 4
+            nbytes = b.numel() * scratch.element_size()
             alg = nbytes / (ms * 1e-3) / 1e9
             out.append({"bytes": nbytes, "ms": round(ms, 4), "alg_GBps": round(alg, 1),
                         "bus_GBps": round(alg * 2 * (self.world - 1) / max(self.world, 1), 1)})
