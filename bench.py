@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--prepare-each-step", action="store_true", help="round 1's protocol: the parameter sweep inside every step")
     ap.add_argument("--with-update", action="store_true", help="also time step + optimiser update (reported beside the metric)")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
+    ap.add_argument("--backward-order", default="auto", choices=["auto", "dx-first", "layerwise"], help="A/B: every updateGradInput first "
+                    "then the accGradParameters (auto: when the layers differ in size and there is no exchange), or layer by layer")
     ap.add_argument("--exchange-dtype", default="f32", choices=["f32", "bf16"], help="data-parallel exchange payload: fp32 (default, the "
                     "metric) or the optional bf16 copy (half the bytes, a DIFFERENT gradient: reported as an option, config.exchange_dtype)")
     args = ap.parse_args()
@@ -236,7 +238,7 @@ def main():
     N = cfg["batch"]
     opt = dict(var_init=1e-3, B=1e6, S=args.S, mode=args.mode, dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"],
                hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap,
-               criterion=cfg.get("criterion", "nll"), exchange_dtype=args.exchange_dtype,
+               criterion=cfg.get("criterion", "nll"), exchange_dtype=args.exchange_dtype, dx_first={"auto": None, "dx-first": True, "layerwise": False}[args.backward_order],
                state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
     for kv in filter(None, args.debug_set.split(",")):
@@ -370,7 +372,9 @@ def main():
                                 "shadows) belongs to the excluded update, as VBLinear.lua:130 has it: prepare() ran once"),
                        "timing": f"median of {len(wall)} blocks of {args.steps} steps, wall clock between barrier+synchronize, MAX over ranks",
                        "repeats_wall_ms": [round(v, 4) for v in wall], "repeats_event_ms": [round(v, 4) for v in evms],
-                       "probed_block_ms": round(probed_ms, 4)},
+                       "probed_block_ms": round(probed_ms, 4),
+                       "backward_order": ("every updateGradInput, then the accGradParameters from the first layer up" if eng.dx_first
+                                          and not eng.reduce else "layer by layer, accGradParameters (+ its all-reduce) first")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": measured_traffic(kname, args.config), "kernel": kname,
                          "kernel_ms": round(kms, 4), "flop_per_launch": kflops,

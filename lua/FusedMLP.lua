@@ -75,6 +75,13 @@ function FusedMLP.new(opt)
         check(C.vbnn_comm_create(vb.ctx, self.rank, self.world, opt.comm_id, box))
         self.comm = ffi.gc(box[0], C.vbnn_comm_destroy)
     end
+    -- single GPU, layers of different sizes: every updateGradInput first, then the accGradParameters from the first layer
+    -- up, so that the heavy launches alternate with lighter ones (engine.py: dx_first; the chip is power-bound in them)
+    local wmin, wmax = math.huge, 0
+    for k = 1, #sizes - 1 do
+        wmin, wmax = math.min(wmin, sizes[k] * sizes[k + 1]), math.max(wmax, sizes[k] * sizes[k + 1])
+    end
+    self.dx_first = (not self.comm) and (2 * wmin <= wmax)
     self:prepare()
     return self
 end
@@ -160,8 +167,8 @@ function FusedMLP:run(inputs, ld, targets, N)
     check(C.vbnn_head_backward(vb.ctx, self.dtype, self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.g_logits), N, H,
                                self.n_classes, accumulate, self.gradWeight3, self.gradBias3, vl.gradBias, 1, vl.r, vl.O, 1,
                                vl.g_s.p, vl.gv_s.p, vl.g_s.ld, nil, nil, 0))
-    -- backward, last VB layer first: accGradParameters (+ its bucket's all-reduce), then updateGradInput
-    for li = #self.vb, 1, -1 do
+    -- backward. The argument blocks of layer li (no library call in these two):
+    local function dw_block(li)
         local v = self.vb[li]
         local d = ffi.new('vbnn_dw_args')
         d.N, d.I, d.O, d.scale, d.accumulate = N, v.I, v.O, 1, accumulate
@@ -171,34 +178,56 @@ function FusedMLP:run(inputs, ld, targets, N)
         d.gradBias = v.bias_from_dw and v.gradBias or nil
         d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_s.p, v.x2_s.p, v.g_s.p, v.gv_s.p, v.x_s.ld, v.g_s.ld
         d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
-        local msg_off = v.bucket_off
-        local early = self.comm and v.O * v.I >= 2 ^ 22 and v.early_ok
-        if early then
-            -- two launches (vbnn_dw_args.part): the sigma^2 GEMM and d/dlvars first, whose exchange then starts while the
-            -- mu GEMM still runs (d/dlvars is the first block of the layer's bucket)
-            d.part = 2
-            check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, d))
-            check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + v.bucket_off, v.O * v.I))
-            d.part = 1
-            msg_off = v.bucket_off + v.O * v.I
+        return d
+    end
+    local function dx_block(li)
+        local v, p = self.vb[li], self.vb[li - 1]
+        local xa = ffi.new('vbnn_dx_args')
+        xa.g, xa.gv, xa.ld_g, xa.N, xa.I, xa.O = v.g_s.p, v.gv_s.p, v.g_s.ld, N, v.I, v.O
+        xa.x, xa.ld_x, xa.relu_mask = v.x_s.p, v.x_s.ld, 1
+        xa.r_prev, xa.ld_r_prev, xa.r_prev_packed = p.r, p.O, 1
+        xa.g_prev, xa.gv_prev, xa.ld_gp = p.g_s.p, p.gv_s.p, p.g_s.ld
+        xa.w, xa.w2, xa.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
+        return xa
+    end
+    if self.dx_first then
+        for li = #self.vb, 2, -1 do
+            check(C.vbnn_grad_input(vb.ctx, self.dtype, dx_block(li)))
         end
-        check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, d))
-        if li < #self.vb and not v.bias_from_dw then
-            check(C.vbnn_acc_grad_bias(vb.ctx, self.dtype, v.g_s.p, v.g_s.ld, N, v.O, 1, accumulate, v.gradBias))
+        for li = 1, #self.vb do
+            local v = self.vb[li]
+            check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, dw_block(li)))
+            if li < #self.vb and not v.bias_from_dw then
+                check(C.vbnn_acc_grad_bias(vb.ctx, self.dtype, v.g_s.p, v.g_s.ld, N, v.O, 1, accumulate, v.gradBias))
+            end
         end
-        if self.comm then                                         -- the final Linear's gradients ride in the last layer's message
-            local n = ((li == #self.vb) and self.n_grads or (v.bucket_off + v.bucket_n)) - msg_off
-            check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + msg_off, n))
-        end
-        if li > 1 then
-            local p = self.vb[li - 1]
-            local xa = ffi.new('vbnn_dx_args')
-            xa.g, xa.gv, xa.ld_g, xa.N, xa.I, xa.O = v.g_s.p, v.gv_s.p, v.g_s.ld, N, v.I, v.O
-            xa.x, xa.ld_x, xa.relu_mask = v.x_s.p, v.x_s.ld, 1
-            xa.r_prev, xa.ld_r_prev, xa.r_prev_packed = p.r, p.O, 1
-            xa.g_prev, xa.gv_prev, xa.ld_gp = p.g_s.p, p.gv_s.p, p.g_s.ld
-            xa.w, xa.w2, xa.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
-            check(C.vbnn_grad_input(vb.ctx, self.dtype, xa))
+    else
+        -- last VB layer first: accGradParameters (+ its bucket's all-reduce), then updateGradInput
+        for li = #self.vb, 1, -1 do
+            local v = self.vb[li]
+            local dd = dw_block(li)
+            local msg_off = v.bucket_off
+            local early = self.comm and v.O * v.I >= 2 ^ 22 and v.early_ok
+            if early then
+                -- two launches (vbnn_dw_args.part): the sigma^2 GEMM and d/dlvars first, whose exchange then starts while the
+                -- mu GEMM still runs (d/dlvars is the first block of the layer's bucket)
+                dd.part = 2
+                check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, dd))
+                check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + v.bucket_off, v.O * v.I))
+                dd.part = 1
+                msg_off = v.bucket_off + v.O * v.I
+            end
+            check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, dd))
+            if li < #self.vb and not v.bias_from_dw then
+                check(C.vbnn_acc_grad_bias(vb.ctx, self.dtype, v.g_s.p, v.g_s.ld, N, v.O, 1, accumulate, v.gradBias))
+            end
+            if self.comm then                                     -- the final Linear's gradients ride in the last layer's message
+                local n = ((li == #self.vb) and self.n_grads or (v.bucket_off + v.bucket_n)) - msg_off
+                check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + msg_off, n))
+            end
+            if li > 1 then
+                check(C.vbnn_grad_input(vb.ctx, self.dtype, dx_block(li)))
+            end
         end
     end
     self.first = false

@@ -40,6 +40,7 @@ class FusedMLP:
         self.exchange_dtype = str(opt.get("exchange_dtype", "f32"))      # "bf16": the optional half-size exchange (_reduce)
         assert self.exchange_dtype in ("f32", "bf16")
         self._stage, self._staged = None, []
+        self._dx_first_opt = opt.get("dx_first", None)      # None: decided from the layer sizes once they are known (below)
         self.fuse_kl = bool(opt.get("fuse_kl", True))
         # "nll": LogSoftMax + ClassNLLCriterion (mlp.lua:30-32); "mse": nn.MSECriterion on the final Linear's outputs
         # (BASELINE.json configs[4], a regression target of n_classes dimensions -- not in the reference)
@@ -58,6 +59,8 @@ class FusedMLP:
         sizes = [opt["input_size"]] + hidden
         self.n_classes = opt["n_classes"]
         self.sizes = sizes
+        weights = [sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1)]
+        self.dx_first = bool(self._dx_first_opt) if self._dx_first_opt is not None else (2 * min(weights) <= max(weights))
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         # ---- gradient arena: [gradWeight | gradSum | gradBias] per VB layer, then the final Linear (partition.arena_layout)
@@ -436,7 +439,24 @@ class FusedMLP:
         # all-reduce) of layer li and updateGradInput of layer li are independent of each other (both consume
         # g_li): with `overlap` they run on two HIP streams, so the HBM-bound epilogue of one GEMM sits beside the
         # MFMA main loop of the other instead of every CU hitting its epilogue at the same moment.
-        if not self.overlap:
+        if self.dx_first and not self.reduce and not self.overlap:
+            # every updateGradInput first, then the accGradParameters from the first layer up: in the wide net the two 4096^3
+            # launches are then separated by the lighter 784-wide gradient. The chip is power-bound in these launches
+            # (DESIGN.md): alternating heavy and light ones lets it hold a higher clock -- measured -25 / -7 / +3 us on a
+            # slow / middle / fast box of the pool; gradients are the same launches on the same operands, bit for bit.
+            # Not with an exchange (the widest layer's buckets must leave first) and not for stacks of equal layers (no
+            # lighter launch to put between: +0.5 % on the deep stack).
+            for li in range(nl - 1, 0, -1):
+                with self._probed("updateGradInput", li):
+                    L.check(lib.vbnn_grad_input(ctx, code, C.byref(self._dx_args(li, N))))
+            for li in range(nl):
+                v = self.vb[li]
+                d = self._dw_args(li, N, accumulate)
+                with self._probed("accGradParameters", li):
+                    L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+                if not (fused_head and li == nl - 1) and not v.bias_from_dw:
+                    L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
+        elif not self.overlap:
             for li in range(nl - 1, -1, -1):
                 v = self.vb[li]
                 d = self._dw_args(li, N, accumulate)
