@@ -26,26 +26,15 @@ def main():
     x = torch.empty(n_loc, I0, dtype=torch.float32, device="cuda")
     fill_normal(x, 3, 4, 0, 0, row0=rank * n_loc)                      # the global minibatch's rows of this rank
     t = ((torch.arange(n_loc, device="cuda", dtype=torch.int64) + rank * n_loc) * 7 % 10).to(torch.int32)
-    # The ranks take turns on the GPU: rank r issues its step and drains the device before rank r + 1 starts (a token
-    # barrier on a process group of its own: the step's all-reduces are still pending on the default group). Two PROCESSES
-    # computing on one device at the same time is not a configuration the product has (one process per GPU; RCCL refuses
-    # it), and it is not benign on this pool: with the ranks' kernels interleaved on the device, about one run in twenty
-    # saw ONE 8-row LDS-DMA piece of ONE K step of the pipelined GEMM arrive late (tools/flake_probe.sh: a 8 x 128 patch
-    # of one layer's output off by a K step's worth; either rank; 6 of 115 runs overlapped, 0 of 30 taking turns, 0 of 400 steps in
-    # ONE process under copy traffic on a second stream, tools/diag_fwd_contention.py). VBNN_TEST_CONCURRENT=1 restores the overlap.
-    serial = os.environ.get("VBNN_TEST_CONCURRENT") != "1"
-    tok = dist.new_group(backend="gloo") if serial else None
+    # The ranks OVERLAP on the GPU (two processes' kernels interleaved on one device). In r02 about one such run in twenty
+    # computed one 8-row A piece of one K step of a pipelined GEMM wrong, and the ranks were made to take turns. The cause
+    # was in the kernel (gemm_v2.h, v2_wait_barrier): in the DUAL SCHED-0 instantiations -- the ones this 512-row shard
+    # takes -- hipcc had sunk the wait for a step's last two LDS reads below the next barrier, so they were in flight
+    # while the refill of their stage was issued. Fixed there and held by tests/test_kernel_hazards.py on the generated
+    # code; the ranks run concurrently again, and tests/test_parity_gpu.py has the in-process form (two engines, two streams).
     for _ in range(2):                                                  # twice: the second step reuses every buffer
-        if serial:
-            for turn in range(world):
-                if turn == rank:
-                    eng.resetGradients(); eng.prepare(); eng.sample()
-                    eng.run(x, t)
-                    torch.cuda.synchronize()
-                dist.barrier(group=tok)
-        else:
-            eng.resetGradients(); eng.prepare(); eng.sample()
-            eng.run(x, t)
+        eng.resetGradients(); eng.prepare(); eng.sample()
+        eng.run(x, t)
         eng.finish()
     loss, _ = eng.loss_and_accuracy()
     print(f"rank {rank}: local loss {loss!r} (exchange: {eng.comm_backend()})", flush=True)

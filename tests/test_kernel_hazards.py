@@ -45,3 +45,68 @@ def test_the_checker_flags_the_pattern_it_guards_against(tmp_path):
         assert res.returncode == want, (name, res.stdout)
         if want:
             assert "_Z4kernv" in res.stdout and "2 read(s)" in res.stdout
+
+
+def _device_disassembly(tmp_path):
+    """llvm-objdump -d of the gfx950 code object inside the SHIPPED library (what the GPU box loads)."""
+    import shutil
+    from vbnn_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build() first: libvbnn_hip.so is missing"
+    so = str(tmp_path / "libvbnn_hip.so")
+    shutil.copy(_lib.LIB_PATH, so)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    res = subprocess.run([objdump, "--offloading", so], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    cos = sorted(f for f in os.listdir(str(tmp_path)) if "amdgcn" in f and "gfx950" in f)      # one per translation unit
+    assert len(cos) >= 4, os.listdir(str(tmp_path))
+    dis = str(tmp_path / "device.dis")
+    with open(dis, "w") as f:
+        for co in cos:
+            res = subprocess.run([objdump, "-d", str(tmp_path / co)], stdout=f, stderr=subprocess.PIPE, text=True, timeout=600)
+            assert res.returncode == 0, res.stderr[-2000:]
+    return dis
+
+
+def test_no_lds_read_is_outstanding_at_a_barrier_of_the_shipped_kernels(tmp_path):
+    """The pipelined loops refill an LDS stage one phase after its last read, which is legal only when the readers'
+    ds_reads have RETURNED before the barrier that releases the refill (gemm_v2.h, v2_wait_barrier). r02's rare wrong
+    forward of the two-rank rehearsal was hipcc sinking eight MFMAs -- and the lgkmcnt wait in front of them -- below the
+    next s_barrier in the DUAL SCHED-0 instantiations of gemm_nt_v2. This holds the property on every kernel of the
+    library as built: at no s_barrier may an LDS read be outstanding."""
+    dis = _device_disassembly(tmp_path)
+    text = open(dis).read()
+    assert text.count("s_barrier") > 300 and "gemm_nt_v2" in text and "gemm_nt_v3" in text      # the kernels are in there
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_barrier_lgkm.py"), dis], capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stdout[-4000:]
+
+
+def test_the_barrier_checker_flags_r02s_code_shape(tmp_path):
+    """The checker on the instruction shape hipcc generated in r02 (reads issued, barrier, refill DMA, then the wait) in
+    both input formats, through a loop's back edge, and silent once the wait precedes the barrier."""
+    chk = os.path.join(ROOT, "tools", "check_barrier_lgkm.py")
+    bad = """_Z4kernv:
+	s_waitcnt lgkmcnt(0)
+.LBB0_1:
+	s_waitcnt vmcnt(8)
+	s_barrier
+	buffer_load_dwordx4 v1, s[4:7], s64 offen lds
+	ds_read_b128 v[148:151], v176 offset:4096
+	ds_read_b128 v[156:159], v176 offset:6144
+	s_waitcnt lgkmcnt(1)
+	v_mfma_f32_16x16x32_bf16 v[0:3], v[148:151], v[152:155], v[0:3]
+	s_cbranch_scc0 .LBB0_1
+	s_endpgm
+"""
+    good = bad.replace("\ts_waitcnt vmcnt(8)\n", "\ts_waitcnt vmcnt(8) lgkmcnt(0)\n")
+    dis_bad = """0000000000001000 <_Z4kernv>:
+	s_waitcnt vmcnt(8)                                         // 000000001000: BF8C0F78
+	s_barrier                                                  // 000000001004: BF8A0000
+	ds_read_b128 v[148:151], v176 offset:4096                  // 000000001008: D9FE1000 940000B0
+	s_cbranch_scc0 65532                                       // 000000001010: BF84FFFC <_Z4kernv+0x0>
+	s_endpgm                                                   // 000000001014: BF810000
+"""
+    for name, text, want in (("bad.s", bad, 1), ("good.s", good, 0), ("bad.dis", dis_bad, 1)):
+        f = tmp_path / name
+        f.write_text(text)
+        res = subprocess.run([sys.executable, chk, str(f)], capture_output=True, text=True)
+        assert res.returncode == want, (name, res.stdout)

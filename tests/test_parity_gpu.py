@@ -834,6 +834,54 @@ def test_engine_two_stream_backward_is_identical(oracle, nnmod):
     assert np.array_equal(arenas[0].view(np.uint32), arenas[1].view(np.uint32))
 
 
+def test_two_engines_on_two_streams_compute_what_each_computes_alone(nnmod):
+    """The product's real concurrency, in one process: two FusedMLP engines on two HIP streams computing at the same time
+    (their kernels share the CUs, the LDS and the texture path), one of them with the one-rank RCCL exchange running on the
+    communicator's own high-priority stream beside its backward. Shape = the shard of the two-rank rehearsal (512 rows of
+    784-4096-4096-10), whose GEMMs take the DUAL SCHED-0 instantiations of gemm_nt_v2 in which r02's late LDS-DMA piece
+    lived (gemm_v2.h, v2_wait_barrier). Activations and gradient arenas must be BITWISE what each engine computes with the
+    device to itself."""
+    from vbnn_amd.engine import FusedMLP
+    I0, N = 784, 512
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    engs = []
+    for r, s in enumerate(streams):
+        opt = opt_for("lrt", "bf16", input_size=I0, hidden=[4096, 4096], fuse_kl=True)
+        e = FusedMLP(opt, stream=s, force_reduce=(r == 0))
+        x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+        nnmod.fill_normal(x, SEED, 4, 0, 0, row0=r * N)
+        t = ((torch.arange(N, device="cuda", dtype=torch.int64) + r * N) * 7 % 10).to(torch.int32)
+        engs.append((e, x, t, s))
+    torch.cuda.synchronize()
+
+    def step(e, x, t, s):
+        with torch.cuda.stream(s):
+            e.draw = 0                                          # the same noise every time
+            e.resetGradients(); e.sample(); e.run(x, t); e.finish()
+
+    ref = []
+    for e, x, t, s in engs:                                     # each engine alone on the device
+        with torch.cuda.stream(s):
+            e.prepare()
+        step(e, x, t, s)
+        torch.cuda.synchronize()
+        step(e, x, t, s)                                        # (second step: every buffer reused)
+        torch.cuda.synchronize()
+        ref.append((e.h_s.t.clone(), e.vb[1].x_s.t.clone(), e.grads.clone()))
+    assert engs[0][0].comm_backend() == "vbnn_comm/rccl"
+    for rep in range(8):                                        # both at once: nothing between the two enqueues
+        for k in range(3):
+            for e, x, t, s in engs:
+                step(e, x, t, s)
+        torch.cuda.synchronize()
+        for (e, _, _, _), (h, x1, g) in zip(engs, ref):
+            assert torch.equal(e.vb[1].x_s.t, x1), f"round {rep}: layer-1 output differs under concurrency"
+            assert torch.equal(e.h_s.t, h), f"round {rep}: layer-2 output differs under concurrency"
+            assert torch.equal(e.grads, g), f"round {rep}: gradient arena differs under concurrency"
+    # the two engines did compute different things (different rows), i.e. the comparison is not vacuous
+    assert not torch.equal(ref[0][0], ref[1][0])
+
+
 # ------------------------------------------------------------------------------------------- update (SURVEY 8f next #1)
 OPT_STATES = dict(state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
 

@@ -19,7 +19,8 @@
 //               and again on the ds_read_b128 address (rule 21: both sides or neither). With it the
 //               16 rows x 1 chunk a lane group reads fall on 16 distinct 16-byte bank slots
 //               (SQ_LDS_BANK_CONFLICT = 0 measured).
-//   per tile    s_waitcnt vmcnt(G)  -> this wave's G DMAs of tile u have landed (tile u+1's may fly)
+//   per tile    s_waitcnt vmcnt(G) lgkmcnt(0) -> this wave's G DMAs of tile u have landed (tile u+1's may fly) and its
+//                                     LDS reads of tile u-1 have RETURNED (v2_wait_barrier: one asm with the barrier)
 //               s_barrier           -> everybody's have; everybody is done reading tile u-1
 //               16 ds_read_b128 + 32 MFMA on tile u, with the G DMAs of tile u+2 (into the buffer tile
 //               u-1 occupied) issued one after every four MFMAs (SCHED 2). Bursting them right after the
@@ -74,10 +75,35 @@ static int g_v2_psplit = -1;      // pair split of the 256 x 128 tiling: -1 by s
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int N> __device__ __forceinline__ void v2_wait_vmcnt();
-template <> __device__ __forceinline__ void v2_wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void v2_wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-template <> __device__ __forceinline__ void v2_wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <int N> __device__ __forceinline__ void v2_wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// THE phase boundary of the pipelined loops (gemm_v2.h, gemm_v3.h): ONE asm statement that
+//   (1) waits until all but this wave's N youngest LDS-DMA pieces have landed        -- RAW, with the barrier
+//   (2) RETIRES every LDS read this wave has issued (lgkmcnt(0))                     -- WAR, with the barrier
+//   (3) s_barrier
+// (2) is what makes it legal to refill a stage ONE phase after its last read (cdna_hip_programming.md, "WAR: restage a
+// buffer >= 2 phases after its last ds_read, or 1 phase after when an lgkmcnt before the reading phase's first barrier
+// retired those reads"). It used to be left to the compiler: a fragment's ds_read is waited for in front of the MFMA
+// that consumes it, and the MFMAs of a step precede the next barrier in the source. But an MFMA is not a memory
+// operation: in the DUAL SCHED-0 instantiations (no sched_barrier pins; the loop body is two steps) hipcc 7.2 sank the
+// last eight MFMAs of a step -- and with them the wait for the last two A-fragment reads -- BELOW the next step's
+// s_barrier: `ds_read_b128 x2; s_waitcnt vmcnt(8); s_barrier; buffer_load ... lds; ...; s_waitcnt lgkmcnt(1); v_mfma`.
+// Those reads were in flight across the barrier while the other waves, released by it, issued the refill of the very
+// stage they read (tile u + 3 -> stage u % 3). Harmless while an LDS read returns long before a DMA piece can land; with a
+// second process's kernels contending for the CU's LDS and texture path it is a race, and it is the r02 "late piece":
+// one 8-row A piece of one K step wrong, 1 run in 20 of the two-rank rehearsal, whose 512-row shard takes exactly these
+// instantiations (128 x 128 tiles, SCHED 0). Found from the ISA (tools/check_barrier_lgkm.py lists the LDS reads
+// outstanding at every s_barrier of every kernel; it runs as a CPU test). The barrier is part of the statement so that
+// no LDS read of the NEXT phase can be scheduled between the wait and the barrier either (s_barrier is IntrNoMem to
+// LLVM: a plain load may cross it; an asm with a memory clobber it may not).
+template <int N> __device__ __forceinline__ void v2_wait_barrier() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// a barrier with no LDS-DMA condition: retire this wave's LDS reads, then meet
+__device__ __forceinline__ void v2_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // KM (pair-split launches only): both operands K-MAJOR -- element (row, k) at X[k * ld + row], i.e. x and g as the
 // forward / gradInput GEMMs hold them (see gemm_v3.h: tile image [64 k][rows], chunk swizzle 2 h(k), fragments by
@@ -347,15 +373,20 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         constexpr bool ALWAYS = decltype(always_c)::value;
         auto la_c = std::conditional_t<ST == 3, decltype(pair_c), decltype(next_c)>();
         V2_STAMP(0);
+#if defined(V2_DIAG) || defined(V2_LAB_SKIP_B)      // lab builds: the wait and the barrier apart, a stamp between them
 #ifdef V2_LAB_SKIP_B
-        if (u + 1 < U) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (u + 1 < U) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 #else
-        if (ST == 3 && (ALWAYS || u + 1 < U)) v2_wait_vmcnt<G>();     // tile u + 1's DMAs may stay in flight
+        if (ST == 3 && (ALWAYS || u + 1 < U)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
 #endif
-        else                       v2_wait_vmcnt<0>();
+        else                       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         V2_STAMP(1);                                     // [0->1] waiting for this wave's DMAs
         __builtin_amdgcn_s_barrier();
         V2_STAMP(2);                                     // [1->2] barrier
+#else
+        if (ST == 3 && (ALWAYS || u + 1 < U)) v2_wait_barrier<G>();   // tile u + 1's DMAs may stay in flight
+        else                                  v2_wait_barrier<0>();
+#endif
         const bool more = ALWAYS ? true : (u + LA < U);
         if (SCHED == 0 && more) {
             issue_one_at(la_c, std::integral_constant<int, 0>()); issue_one_at(la_c, std::integral_constant<int, 1>());

@@ -21,7 +21,7 @@
 //   LDS         160 KiB = A parts [2 K steps][2 phases] x 16 KiB + B tiles [3 K steps] x 32 KiB.
 //               A part P holds the 2 x 64 rows the two wave rows use in phase P, so it is free for refill after that
 //               phase: A is double-buffered at PHASE granularity, B triple-buffered at K-step granularity.
-//   per phase   s_waitcnt vmcnt(8 | 10) -> s_barrier -> 8 (16 in phase 0) ds_read_b128 + 32 MFMA, with 4 DMAs issued
+//   per phase   s_waitcnt vmcnt(8 | 10) lgkmcnt(0) -> s_barrier (one asm, v2_wait_barrier) -> 8 (16 in phase 0) ds_read_b128 + 32 MFMA, with 4 DMAs issued
 //               between the MFMAs:  phase 0 of step t: A part 1 of t+1 (x2), B of t+2 (x2)
 //                                   phase 1 of step t: A part 0 of t+2 (x2), B of t+2 (x2)
 //               every DMA is in flight for at least two phases (64 MFMAs per wave) before its data is needed.
@@ -44,8 +44,6 @@ __device__ unsigned long long* g_v3_stamp = nullptr;
 #define V3_ST(k) do { } while (0)
 #endif
 
-template <> __device__ __forceinline__ void v2_wait_vmcnt<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-template <> __device__ __forceinline__ void v2_wait_vmcnt<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
 
 // AK / BK: the operand is stored K-MAJOR -- element (row, k) at X[k * ld + row], i.e. the untransposed activation /
 // gradient / weight matrix -- instead of K-contiguous. Its tile then lies in LDS as [64 k][rows] and the MFMA fragments
@@ -378,8 +376,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             const unsigned char* sb = lds + 4 * V3_APART + ob;
             bf16x8 bf[2][4];
             // ------------------------------------------------ phase 0: A rows 0..63 of the wave
-            if (TAIL && t == nk - 1) v2_wait_vmcnt<2>(); else v2_wait_vmcnt<8>();
-            __builtin_amdgcn_s_barrier();
+            if (TAIL && t == nk - 1) v2_wait_barrier<2>(); else v2_wait_barrier<8>();      // (+ lgkmcnt(0): gemm_v2.h)
             {
                 const unsigned char* sa = lds + oa;
                 auto dma_slot = [&](int s, int i) {
@@ -448,8 +445,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 }
             }
             // ------------------------------------------------ phase 1: A rows 64..127 of the wave, B from registers
-            if (TAIL && t == nk - 1) v2_wait_vmcnt<0>(); else if (TAIL && t == nk - 2) v2_wait_vmcnt<8>(); else v2_wait_vmcnt<10>();
-            __builtin_amdgcn_s_barrier();
+            if (TAIL && t == nk - 1) v2_wait_barrier<0>(); else if (TAIL && t == nk - 2) v2_wait_barrier<8>(); else v2_wait_barrier<10>();
             {
                 const unsigned char* sa = lds + oa + V3_APART;
                 auto dma_slot = [&](int s, int i) {
@@ -561,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         // Pass 2's pipeline fill is issued BEFORE the fold, so its DMAs land while the fold computes. (The fold's own
         // loads and stores are younger than those DMAs on the in-order vmcnt counter: the counted waits of run_pass
         // only get stricter.)
-        __builtin_amdgcn_s_barrier();                         // every wave is done reading pass 1's last K step
+        v2_lds_barrier();                                     // every wave is done reading pass 1's last K step (reads retired)
         if constexpr (Epi::FOLD_STAGE == 1) {
             // FOLD_STAGE functors (see the fold below): the per-m addend (the bias) of the wave's 128 m is parked in the
             // wave's LDS staging area NOW, before pass 2's fill is issued -- ONE global load per lane whose wait covers

@@ -25,10 +25,13 @@ class _VB:
 
 
 class FusedMLP:
-    def __init__(self, opt, device=None, world_size=1, rank=0, process_group=None, force_reduce=False):
+    def __init__(self, opt, device=None, world_size=1, rank=0, process_group=None, force_reduce=False, stream=None):
+        """stream: a torch.cuda.Stream for this engine's launches (a library context of its own, hence its own reduction
+        scratch and tickets): two engines on two streams may compute on one device at the same time. Default: the
+        device's shared context on torch's current stream."""
         self.opt = opt
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.ctx = Context.get(self.device)
+        self.ctx = Context.get(self.device) if stream is None else Context(self.device.index or 0, stream=stream)
         self.dtype = opt.get("dtype", "bf16")
         self.code, self.tdt = _DT[self.dtype]
         self.mode = opt.get("mode", "lrt")
