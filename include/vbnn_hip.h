@@ -69,7 +69,8 @@ int vbnn_debug_set(int key, int value);
 /* 1 when a GEMM with an M x N output and contraction length K would take the K-major form of the two-pass kernel
  * under the current selection (whole 256 x 256 tiles filling the CUs, K a multiple of 64, bf16): the host asks once
  * per layer whether it needs the transposed copies at all (accGradParameters: M = I, N = O, K = minibatch rows;
- * gradInput: M = I, N = minibatch rows, K = O). */
+ * gradInput: M = I, N = minibatch rows, K = O). For accGradParameters the answer presumes the fused total-gradient form
+ * with the operand shadows (vbnn_dw_args.grad_mu / grad_lv + mu_s / var_s): that is the only K-major epilogue. */
 int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K);
 /* The same question for accGradParameters of an I -> O layer on N rows, which has a second K-major form (the pair-split
  * launch for outputs with few tiles). bias_row = 1: the bias gradient is to come from the GEMM (vbnn_dw_args.gradBias),
@@ -212,7 +213,9 @@ typedef struct vbnn_dw_args {
     /* optional (fused total gradients only, dtype BF16): the packed operand shadows mu_s, var_s = exp(lvars) (O x ld_w,
      * as vbnn_prepare / vbnn_update leave them). When given, the epilogue reads mu and sigma^2 FROM THEM -- 4 B per weight
      * instead of 8, and no exp -- i.e. d/dlvars = (gv^T x.x) . s2 + KL'(s2), d/dmeans = g^T x + KL'(mu) with s2, mu the
-     * values the forward GEMMs multiplied by (bf16-rounded); means / lvars are then not read. NULL: fp32 means / lvars. */
+     * values the forward GEMMs multiplied by (bf16-rounded); means / lvars are then not read. NULL: fp32 means / lvars.
+     * REQUIRED by the K-major launches (x / g given, xT / gT NULL): their epilogue reads the shadows only, so a caller that
+     * passes K-major operands without mu_s / var_s gets VBNN_ERR_INVALID -- keep the transposed operands for that case. */
     const void* mu_s; const void* var_s; int64_t ld_w;
     /* 0 (default): both GEMMs of the LRT pair, every output. 1: only the first GEMM (g^T x) and what depends on it
      * (gradWeight / grad_mu, gradBias); 2: only the second (gv^T x.x) and what depends on it (gradSum / grad_lv). Calling

@@ -9,9 +9,11 @@
 -- Data-parallel: one process per GPU; `opt.world` / `opt.rank` / `opt.comm_id` (the 128 bytes of
 -- vbnn_comm_unique_id, handed to every rank by the launcher) switch on the RCCL exchange of the gradient buckets.
 --
--- NOT EXECUTED in the build image (no LuaJIT / Torch7 there); tests/test_abi.py lints it structurally: every
--- C.vbnn_* it calls is declared in the header with that many parameters, and the call ORDER of `run` is the one
--- engine.py issues.
+-- NOT EXECUTED in the build image (no LuaJIT / Torch7 there). Its executable stand-in is tools/c_host.c: the same
+-- functions (new / _alloc_batch / prepare / run / update), the same library calls in the same order, in plain C over the
+-- same header, run on the GPU by tests/test_c_host.py and bitwise equal to engine.py there. tests/test_abi.py and
+-- tests/test_c_host.py lint this file structurally: every C.vbnn_* it calls is declared in the header with that many
+-- parameters, every struct field it sets exists, and the call ORDER of each function is the C host's and engine.py's.
 local vb = require('vbnn_ffi')
 local ffi, C, check = vb.ffi, vb.C, vb.check
 
@@ -55,7 +57,8 @@ function FusedMLP.new(opt)
         v.bucket_n = off - v.bucket_off
         v.stats = vb.alloc(32)
         v.mu_s, v.var_s = packed(O, I, self.esize), packed(O, I, self.esize)
-        v.muT_s, v.varT_s = packed(I, O, self.esize), packed(I, O, self.esize)
+        if li > 1 then v.muT_s, v.varT_s = packed(I, O, self.esize), packed(I, O, self.esize) end
+        v.use_muT = li > 1                                        -- until _alloc_batch has asked the library (K-major weights)
         v.t = 0
         -- VBLinear.lua:18,22-28 + the He rule of mlp.lua:47-55 for the means (stream 5 = VBNN_STREAM_HEINIT)
         check(C.vbnn_fill_normal(vb.ctx, f32(v.means), O, I, I, self.seed, 5, v.layer_id, 0, 0, math.sqrt(2 / I)))
@@ -86,35 +89,49 @@ function FusedMLP.new(opt)
     return self
 end
 
--- buffers that depend on the local batch size (engine.py:_alloc_batch)
+-- buffers that depend on the local batch size (engine.py:_alloc_batch; tools/c_host.c:fm_alloc_batch)
 function FusedMLP:_alloc_batch(N)
     if self.N == N then return end
     self.N = N
+    local km_ok = self.dtype == C.VBNN_BF16 and self.S == 1
+    local need_prepare = false
+    local ones, ones_dev = torch.FloatTensor(N):fill(1), vb.alloc(N * 4)
+    check(C.vbnn_buf_upload(vb.ctx, ones_dev, ones:data(), N * 4))
     for li, v in ipairs(self.vb) do
         local last = li == #self.vb
-        v.bias_from_dw = (v.I % 256 ~= 0) and not last          -- the ones column of x: bias gradient from the GEMM
-        local km = C.vbnn_kmajor_supported_dw(v.I, v.O, N, v.bias_from_dw and 1 or 0)
+        v.bias_from_dw = (v.I % 256 ~= 0) and not last          -- the ones column / row of x: bias gradient from the GEMM
+        local km = km_ok and C.vbnn_kmajor_supported_dw(v.I, v.O, N, v.bias_from_dw and 1 or 0) or 0
         v.dw_km = km > 0
-        v.dx_km = li > 1 and C.vbnn_kmajor_supported(v.I, N, v.O) ~= 0
-        -- the two-launch form of accGradParameters (early d/dlvars message) needs the plain K-major launch of the two-pass
-        -- kernel; the few-tile K-major launches compute both GEMMs in one grid (engine.py: early_ok)
-        v.early_ok = (not v.bias_from_dw) and C.vbnn_kmajor_supported(v.I, v.O, N) ~= 0
-        local xcols = v.I + ((v.dw_km and v.bias_from_dw) and 1 or 0)
+        -- the two-launch form of accGradParameters (early d/dlvars message) needs either the transposed operands or the
+        -- plain K-major launch of the two-pass kernel; the few-tile K-major launches compute both GEMMs in one grid
+        v.early_ok = (not v.dw_km) or ((not v.bias_from_dw) and C.vbnn_kmajor_supported(v.I, v.O, N) ~= 0)
+        v.dx_km = km_ok and li > 1 and C.vbnn_kmajor_supported(v.I, N, v.O) ~= 0
+        local use_muT = li > 1 and not v.dx_km
+        if use_muT and not v.use_muT then need_prepare = true end
+        v.use_muT = use_muT
+        local extra = v.bias_from_dw and 1 or 0
+        local xcols = v.I + (v.dw_km and extra or 0)
         if km == 2 then xcols = math.floor((xcols + 255) / 256) * 256 end
         v.x_s, v.x2_s = packed(N, xcols, self.esize), packed(N, xcols, self.esize)
-        v.g_s, v.gv_s = packed(N, v.O, self.esize), packed(N, v.O, self.esize)
-        v.r = vb.alloc(N * v.O * self.esize)
-        assert(v.dw_km and (li == 1 or v.dx_km), 'FusedMLP.lua covers the K-major configuration (no transposed copies); ' ..
-               'shapes the library answers 0 for need the xT / gT / muT operands engine.py allocates')
-        if v.bias_from_dw then                                    -- column I of x is all ones, written once
-            local ones, ones_dev = torch.FloatTensor(N):fill(1), vb.alloc(N * 4)
-            check(C.vbnn_buf_upload(vb.ctx, ones_dev, ones:data(), N * 4))
+        v.has_t = not v.dw_km                                     -- shapes without a K-major form get the transposed copies
+        if v.dw_km and v.bias_from_dw then                        -- column I of x is all ones, written once
             check(C.vbnn_pack(vb.ctx, self.dtype, C.VBNN_PACK_COPY, f32(ones_dev), nil, 1, N, 1,
                               ffi.cast('char*', v.x_s.p) + v.I * self.esize, v.x_s.ld, nil, 0))
         end
+        if v.has_t then
+            v.xT_s, v.x2T_s = packed(v.I + extra, N, self.esize), packed(v.I + extra, N, self.esize)
+            v.gT_s, v.gvT_s = packed(v.O, N, self.esize), packed(v.O, N, self.esize)
+            if v.bias_from_dw then                                -- row I of x^T is all ones
+                check(C.vbnn_pack(vb.ctx, self.dtype, C.VBNN_PACK_COPY, f32(ones_dev), nil, N, 1, N,
+                                  ffi.cast('char*', v.xT_s.p) + v.I * v.xT_s.ld * self.esize, v.xT_s.ld, nil, 0))
+            end
+        end
+        v.g_s, v.gv_s = packed(N, v.O, self.esize), packed(N, v.O, self.esize)
+        v.r = vb.alloc(N * v.O * self.esize)
     end
     self.h_s = packed(N, self.sizes[#self.sizes], self.esize)
     self.logits, self.out, self.g_logits = vb.alloc(N * self.n_classes * 4), vb.alloc(N * self.n_classes * 4), vb.alloc(N * self.n_classes * 4)
+    if need_prepare then self:prepare() end
 end
 
 function FusedMLP:resetGradients() self.first = true end          -- mlp.lua:62-67: the first draw overwrites
@@ -127,7 +144,8 @@ function FusedMLP:prepare()
         local e = d[k - 1]
         e.means, e.lvars, e.O, e.I = f32(v.means), f32(v.lvars), v.O, v.I
         e.mu_s, e.var_s, e.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
-        e.muT_s, e.varT_s, e.ld_wT = nil, nil, 0
+        e.muT_s, e.varT_s = v.use_muT and v.muT_s.p or nil, v.use_muT and v.varT_s.p or nil
+        e.ld_wT = v.muT_s and v.muT_s.ld or 0
         e.stats = ffi.cast('double*', v.stats)
     end
     local w3 = ffi.new('vbnn_pack_desc[1]')
@@ -145,7 +163,8 @@ function FusedMLP:run(inputs, ld, targets, N)
     local inv_n = 1 / (N * self.world)
     local row0 = self.rank * N
     local v0 = self.vb[1]
-    check(C.vbnn_pack_input(vb.ctx, self.dtype, f32(inputs), ld, N, v0.I, v0.x_s.p, v0.x2_s.p, v0.x_s.ld, nil, nil, 0))
+    check(C.vbnn_pack_input(vb.ctx, self.dtype, f32(inputs), ld, N, v0.I, v0.x_s.p, v0.x2_s.p, v0.x_s.ld, v0.has_t and v0.xT_s.p or nil,
+                            v0.has_t and v0.x2T_s.p or nil, v0.has_t and v0.xT_s.ld or 0))
     -- forward: dual GEMM + noise / ReLU / operand packing in the epilogue
     for li, v in ipairs(self.vb) do
         local nxt = self.vb[li + 1]
@@ -157,6 +176,7 @@ function FusedMLP:run(inputs, ld, targets, N)
         fa.h = nxt and nxt.x_s.p or self.h_s.p
         fa.h2 = nxt and nxt.x2_s.p or nil
         fa.ld_h = nxt and nxt.x_s.ld or self.h_s.ld
+        if nxt and nxt.has_t then fa.hT, fa.h2T, fa.ld_hT = nxt.xT_s.p, nxt.x2T_s.p, nxt.xT_s.ld end
         check(C.vbnn_forward(vb.ctx, self.dtype, fa))
     end
     -- final Linear + LogSoftMax + ClassNLL (mlp.lua:29-32), forward and backward
@@ -166,27 +186,32 @@ function FusedMLP:run(inputs, ld, targets, N)
                               f32(self.g_logits), accumulate, ffi.cast('double*', self.acc), ffi.cast('int32_t*', self.corr)))
     check(C.vbnn_head_backward(vb.ctx, self.dtype, self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.g_logits), N, H,
                                self.n_classes, accumulate, self.gradWeight3, self.gradBias3, vl.gradBias, 1, vl.r, vl.O, 1,
-                               vl.g_s.p, vl.gv_s.p, vl.g_s.ld, nil, nil, 0))
+                               vl.g_s.p, vl.gv_s.p, vl.g_s.ld, vl.has_t and vl.gT_s.p or nil, vl.has_t and vl.gvT_s.p or nil,
+                               vl.has_t and vl.gT_s.ld or 0))
     -- backward. The argument blocks of layer li (no library call in these two):
     local function dw_block(li)
         local v = self.vb[li]
         local d = ffi.new('vbnn_dw_args')
+        if v.has_t then d.xT, d.x2T, d.gT, d.gvT, d.ld_n = v.xT_s.p, v.x2T_s.p, v.gT_s.p, v.gvT_s.p, v.gT_s.ld end
         d.N, d.I, d.O, d.scale, d.accumulate = N, v.I, v.O, 1, accumulate
         d.seed, d.layer, d.draw, d.lvars = self.seed, v.layer_id, self.draw, f32(v.lvars)
         d.grad_mu, d.grad_lv, d.means, d.stats = v.grad_mu, v.grad_lv, f32(v.means), ffi.cast('double*', v.stats)
         d.B, d.S, d.kl_scale = self.B, self.S, 1 / self.world
         d.gradBias = v.bias_from_dw and v.gradBias or nil
         d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_s.p, v.x2_s.p, v.g_s.p, v.gv_s.p, v.x_s.ld, v.g_s.ld
-        d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
+        if self.dtype == C.VBNN_BF16 then d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld end   -- KL terms from the shadows
         return d
     end
     local function dx_block(li)
         local v, p = self.vb[li], self.vb[li - 1]
         local xa = ffi.new('vbnn_dx_args')
+        if v.use_muT then xa.wT, xa.w2T = v.muT_s.p, v.varT_s.p end
+        xa.ld_wT = v.muT_s.ld
         xa.g, xa.gv, xa.ld_g, xa.N, xa.I, xa.O = v.g_s.p, v.gv_s.p, v.g_s.ld, N, v.I, v.O
         xa.x, xa.ld_x, xa.relu_mask = v.x_s.p, v.x_s.ld, 1
         xa.r_prev, xa.ld_r_prev, xa.r_prev_packed = p.r, p.O, 1
         xa.g_prev, xa.gv_prev, xa.ld_gp = p.g_s.p, p.gv_s.p, p.g_s.ld
+        if p.has_t then xa.gT_prev, xa.gvT_prev, xa.ld_gpT = p.gT_s.p, p.gvT_s.p, p.gT_s.ld end
         xa.w, xa.w2, xa.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
         return xa
     end
@@ -251,7 +276,9 @@ function FusedMLP:update(opt, log14)
         v.t = v.t + 1
         local e = d[k - 1]
         e.means, e.lvars, e.O, e.I = f32(v.means), f32(v.lvars), v.O, v.I
-        e.mu_s, e.var_s, e.ld_w, e.muT_s, e.varT_s, e.ld_wT = v.mu_s.p, v.var_s.p, v.mu_s.ld, nil, nil, 0
+        e.mu_s, e.var_s, e.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
+        e.muT_s, e.varT_s = v.use_muT and v.muT_s.p or nil, v.use_muT and v.varT_s.p or nil
+        e.ld_wT = v.muT_s and v.muT_s.ld or 0
         e.stats, e.grad_mu, e.grad_lv = ffi.cast('double*', v.stats), v.grad_mu, v.grad_lv
         e.m_mu, e.v_mu, e.m_lv, e.v_lv = f32(v.m_mu), f32(v.v_mu), f32(v.m_lv), f32(v.v_lv)
         for key, st in pairs({ mu = opt.meanState, lv = opt.varState }) do

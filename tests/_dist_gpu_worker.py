@@ -19,7 +19,8 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=1, mode="lrt", dtype=dtype, seed=3, input_size=I0, hidden=hidden,
+    S = int(sys.argv[7]) if len(sys.argv) > 7 else 1                  # sequential Monte-Carlo draws per minibatch (main.lua:32-37)
+    opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=S, mode="lrt", dtype=dtype, seed=3, input_size=I0, hidden=hidden,
                n_classes=10, fuse_kl=True, exchange_dtype=sys.argv[6] if len(sys.argv) > 6 else "f32")
     eng = FusedMLP(opt, world_size=world, rank=rank)
     n_loc = N // world
@@ -33,8 +34,10 @@ def main():
     # while the refill of their stage was issued. Fixed there and held by tests/test_kernel_hazards.py on the generated
     # code; the ranks run concurrently again, and tests/test_parity_gpu.py has the in-process form (two engines, two streams).
     for _ in range(2):                                                  # twice: the second step reuses every buffer
-        eng.resetGradients(); eng.prepare(); eng.sample()
-        eng.run(x, t)
+        eng.resetGradients(); eng.prepare()
+        for _ in range(S):                                              # the draws accumulate; the buckets leave with the last one
+            eng.sample()
+            eng.run(x, t)
         eng.finish()
     loss, _ = eng.loss_and_accuracy()
     print(f"rank {rank}: local loss {loss!r} (exchange: {eng.comm_backend()})", flush=True)

@@ -22,30 +22,34 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("dtype,hidden,I0,N,tol,xdt", [("f32", "50,34", 70, 64, 2e-5, "f32"), ("bf16", "512,256", 256, 512, 2e-3, "f32"),
-                                                        ("bf16", "4096,4096", 784, 1024, 2e-3, "f32"),
-                                                        ("bf16", "512,256", 256, 512, 6e-3, "bf16")])
-def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hidden, I0, N, tol, xdt):
+@pytest.mark.parametrize("dtype,hidden,I0,N,tol,xdt,S", [("f32", "50,34", 70, 64, 2e-5, "f32", 1), ("bf16", "512,256", 256, 512, 2e-3, "f32", 1),
+                                                          ("bf16", "4096,4096", 784, 1024, 2e-3, "f32", 1),
+                                                          ("bf16", "512,256", 256, 512, 6e-3, "bf16", 1),
+                                                          # S sequential draws: the buckets are exchanged ONCE, with the last draw
+                                                          ("f32", "50,34", 70, 64, 2e-5, "f32", 3), ("bf16", "512,256", 256, 512, 2e-3, "f32", 2)])
+def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hidden, I0, N, tol, xdt, S):
     import torch
     from vbnn_amd.engine import FusedMLP
     from vbnn_amd.nn import fill_normal
     out = str(tmp_path / "r")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), out, dtype, hidden, str(I0), str(N), xdt]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), out, dtype, hidden, str(I0), str(N), xdt, str(S)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     got = np.load(out + ".grads.npy")
     loss2 = float(np.load(out + ".loss.npy")[0])
-    opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=1, mode="lrt", dtype=dtype, seed=3, input_size=I0,
+    opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=S, mode="lrt", dtype=dtype, seed=3, input_size=I0,
                hidden=[int(h) for h in hidden.split(",")], n_classes=10, fuse_kl=True)
     eng = FusedMLP(opt)
     x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
     fill_normal(x, 3, 4, 0, 0)
     t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
     for _ in range(2):
-        eng.resetGradients(); eng.prepare(); eng.sample()
-        eng.run(x, t)
+        eng.resetGradients(); eng.prepare()
+        for _ in range(S):
+            eng.sample()
+            eng.run(x, t)
     loss1, _ = eng.loss_and_accuracy()
     want = eng.grads.cpu().numpy()
     print(f"single process loss {loss1!r}; ranks: {[l for l in res.stdout.splitlines() if 'local loss' in l]}")

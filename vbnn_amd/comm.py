@@ -81,16 +81,47 @@ class RcclExchange:
 
 def make_exchange(ctx, rank, world, process_group=None):
     """RCCL through the C ABI unless VBNN_EXCHANGE=torch (or the torch backend is not nccl: a gloo rehearsal has no
-    device per rank for RCCL); a failure to bind librccl falls back to torch.distributed and says so."""
+    device per rank for RCCL); a failure to bind librccl falls back to torch.distributed and says so.
+    The decision is COLLECTIVE: every rank probes the binding (vbnn_comm_unique_id loads librccl and asks it for an id; only
+    rank 0's is used), the ranks agree on MIN(ok) over the out-of-band process group, and either all of them build the RCCL
+    communicator or all of them fall back -- a rank that cannot bind never leaves the others waiting in a broadcast or
+    inside ncclCommInitRank. The same agreement follows vbnn_comm_create."""
     import torch.distributed as dist
     want = os.environ.get("VBNN_EXCHANGE", "")
     if want == "torch":
         return TorchExchange(process_group, "VBNN_EXCHANGE=torch")
-    if dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) != "nccl" and want != "rccl":
+    have_pg = dist.is_available() and dist.is_initialized()
+    if have_pg and dist.get_backend(process_group) != "nccl" and want != "rccl":
         return TorchExchange(process_group)
+    if world == 1 or not have_pg:
+        try:
+            return RcclExchange(ctx, rank, world, process_group)
+        except (L.VbnnError, OSError, AssertionError) as e:
+            if not have_pg:
+                raise
+            return TorchExchange(process_group, f"vbnn_comm unavailable: {e}")
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                            device=ctx.device if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+        return bool(flag.item())
+
+    why = ""
     try:
-        return RcclExchange(ctx, rank, world, process_group)
+        L.check(L.lib().vbnn_comm_unique_id((C.c_ubyte * 128)()))          # probe: is librccl bound on THIS rank?
+        ok = True
+    except (L.VbnnError, OSError) as e:
+        ok, why = False, str(e)
+    if not agree(ok):
+        return TorchExchange(process_group, f"vbnn_comm unavailable on some rank{': ' + why if why else ''}")
+    ex = None
+    try:
+        ex = RcclExchange(ctx, rank, world, process_group)
     except (L.VbnnError, OSError, AssertionError) as e:
-        if not (dist.is_available() and dist.is_initialized()):
-            raise
-        return TorchExchange(process_group, f"vbnn_comm unavailable: {e}")
+        why = str(e)
+    if not agree(ex is not None):
+        if ex is not None:
+            ex.close()
+        return TorchExchange(process_group, f"vbnn_comm_create failed on some rank{': ' + why if why else ''}")
+    return ex

@@ -127,6 +127,9 @@ class FusedMLP:
         self.draw = 0
         self._map = False
         self._first = True
+        self._draws_run = 0
+        self._exchange_now = True
+        self._exchange_done = False
         self._N = None
         self._rpd = 0            # > 0 inside run_draws: rows per Monte-Carlo draw of the stacked minibatch
         self._draws = None
@@ -157,8 +160,10 @@ class FusedMLP:
         for li, v in enumerate(self.vb):
             last_fused = (v is self.vb[-1]) and self.n_classes <= 16 and self.criterion == "nll"
             v.bias_from_dw = (v.I % 256 != 0) and not last_fused
+            # (the K-major launches take the epilogue's fast protocol, which reads mu / sigma^2 from the operand shadows
+            # only: vbnn_dw_args.mu_s / var_s are REQUIRED for them, include/vbnn_hip.h)
             km = lib.vbnn_kmajor_supported_dw(v.I, v.O, N, 1 if v.bias_from_dw else 0) if (
-                km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1) else 0
+                km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1 and self.kl_from_shadows) else 0
             v.dw_km = km > 0
             v.x_pad256 = km == 2         # the split launch of gemm_v3 reads x / x.x in whole 256-column tiles
             # the two-launch form of accGradParameters (early d/dlvars message) needs either the transposed operands or the
@@ -214,6 +219,8 @@ class FusedMLP:
     # and the first criterion pass overwrites the loss / hit accumulators.
     def resetGradients(self):
         self._first = True
+        self._draws_run = 0          # sequential draws since the reset: the exchange leaves with the LAST one (run)
+        self._exchange_done = False
 
     # ---- once per minibatch, after the parameters changed: VBLinear:compute_prior (VBLinear.lua:77-88)
     # fused with the packing of the GEMM shadows.
@@ -395,8 +402,22 @@ class FusedMLP:
                         w=v.mu_s.ptr, w2=v.var_s.ptr if lrt else None, ld_w=v.mu_s.ld)
 
     # ---- mlp.lua:76-84, fused
-    def run(self, inputs, targets, row0=None, backward=True):
+    def run(self, inputs, targets, row0=None, backward=True, last_draw=None):
+        """last_draw (data-parallel only): whether this run's gradients are the minibatch's final ones, i.e. whether the
+        buckets' all-reduces are issued. Default: the opt.S-th sequential run since resetGradients() (always, inside
+        run_draws). The draws of a minibatch ACCUMULATE in the arena (main.lua:32-37): exchanging after every draw would
+        all-reduce sums that already contain other ranks' contributions, and the exchange stream's in-place write would
+        race with the next draw's accumulate epilogue -- so earlier draws only accumulate."""
         lib, ctx, code = L.lib(), self.ctx.h, self.code
+        if backward:
+            self._draws_run += 1
+            if last_draw is None:
+                last_draw = bool(self._rpd) or self._draws_run >= int(self.S)
+            if self.reduce and not self._rpd and self._draws_run > int(self.S) and self._exchange_done:
+                raise RuntimeError(f"run() called {self._draws_run} times since resetGradients() with opt.S = {int(self.S)}: the "
+                                   "gradient buckets were already exchanged after draw S")
+            self._exchange_now = bool(last_draw)
+            self._exchange_done = self._exchange_now
         x = inputs.reshape(inputs.shape[0], -1)                         # nn.Reshape (mlp.lua:12)
         N = x.shape[0]
         assert x.shape[1] == self.sizes[0] and x.dtype == torch.float32 and x.is_cuda
@@ -532,7 +553,7 @@ class FusedMLP:
     # back into the fp32 arena. A different gradient (every rank's contribution rounded, RCCL sums in bf16): an option for
     # hosts whose step is exchange-bound, never the default, and the bench line says which one ran.
     def _reduce(self, bucket):
-        if not self.reduce:
+        if not self.reduce or not self._exchange_now:
             return
         if self.exchange_dtype != "bf16":
             self.exchange().allreduce(bucket)
