@@ -1312,8 +1312,9 @@ def test_error_convention(nnmod):
 
 
 # --------------------------------------------------------------------- the benchmark configurations, whole step
-@pytest.mark.parametrize("hidden,I0", [([4096, 4096], 784), ([4096] * 8, 4096)], ids=["wide", "deep"])
-def test_full_size_step_properties(oracle, nnmod, hidden, I0):
+@pytest.mark.parametrize("hidden,I0,crit", [([4096, 4096], 784, "nll"), ([4096] * 8, 4096, "nll"), ([4096] * 8, 4096, "mse")],
+                         ids=["wide", "deep", "deep-mse"])
+def test_full_size_step_properties(oracle, nnmod, hidden, I0, crit):
     """BASELINE.json's measured configurations (batch 4096, bf16, LRT, S = 1) are beyond what the oracle finishes in
     seconds, so the WHOLE fused step is held to size-independent properties instead:
       1. two fresh engines produce bit-identical gradient arenas (no atomics, no arrival-order sums);
@@ -1321,15 +1322,24 @@ def test_full_size_step_properties(oracle, nnmod, hidden, I0):
          copies (debug key 6 = 0) are different kernels over different buffers: their gradients must agree to bf16
          operand rounding of the bias column sums, far below any layout or indexing error;
       3. two half-batch ranks of a world of 2 sum to the single-process gradients and loss (wide only: memory);
-      4. softmax-gradient identities: the final Linear's bias gradient sums to zero over classes; every gradient finite."""
+      4. softmax-gradient identities: the final Linear's bias gradient sums to zero over classes; every gradient finite.
+    "deep-mse" is BASELINE configs[4] exactly as bench.py --config deep runs it: 8 x 4096 + Linear 4096 -> 4096 + nn.MSECriterion
+    on the synthetic regression target. Its form of 4: the criterion's two outputs bind each other (loss = sum g^2 / (4 inv_nd)
+    with g = 2 inv_nd (y - t)) and the final Linear's bias gradient is the column sum of g."""
     import torch
     from vbnn_amd import _lib as L
     from vbnn_amd.engine import FusedMLP
     N = 4096
-    opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True)
+    mse = crit == "mse"
+    opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True, criterion=crit, n_classes=4096 if mse else 10)
     x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
     nnmod.fill_normal(x, SEED, 4, 0, 0)
     t = ((torch.arange(N, device="cuda", dtype=torch.int64) * 2654435761) % 10).to(torch.int32)
+    if mse:
+        probe = FusedMLP(opt)
+        t = probe.synthetic_targets(x)                              # y* = x R / sqrt(I): bench.py's regression target
+        del probe
+    checks = {}
 
     def one(world=1, rank=0, xs=x, ts=t, **over):
         eng = FusedMLP(dict(opt, **over), world_size=world, rank=rank)
@@ -1339,14 +1349,25 @@ def test_full_size_step_properties(oracle, nnmod, hidden, I0):
         loss, correct = eng.loss_and_accuracy()
         g = eng.grads.clone()
         gb3 = eng.gradBias3.clone()
+        if mse and not checks:
+            gl = eng.g_logits.double()
+            checks["loss_from_g"] = float((gl * gl).sum().item()) * (xs.shape[0] * world * 4096) / 4.0
+            checks["gb3_from_g"] = gl.sum(dim=0)
         del eng
         return g, loss, gb3
 
     g_a, loss_a, gb3 = one()
     g_b, loss_b, _ = one()
     assert torch.equal(g_a, g_b) and loss_a == loss_b                                   # 1
-    assert bool(torch.isfinite(g_a).all()) and np.isfinite(loss_a) and loss_a > 1.0   # untrained: worse than chance's log 10
-    assert abs(float(gb3.sum())) <= 1e-5 * float(gb3.abs().sum() + 1e-12)               # 4
+    assert bool(torch.isfinite(g_a).all()) and np.isfinite(loss_a)
+    if mse:
+        assert loss_a > 0.1                                                             # untrained regression: O(1) squared error
+        assert abs(checks["loss_from_g"] - loss_a) <= 1e-5 * loss_a, (checks["loss_from_g"], loss_a)   # 4 (criterion identities)
+        err = float((gb3.double() - checks["gb3_from_g"]).abs().max())
+        assert err <= 1e-5 * float(checks["gb3_from_g"].abs().max()) + 1e-9, err
+    else:
+        assert loss_a > 1.0                                                             # untrained: worse than chance's log 10
+        assert abs(float(gb3.sum())) <= 1e-5 * float(gb3.abs().sum() + 1e-12)           # 4
     L.check(L.lib().vbnn_debug_set(6, 0))
     try:
         g_t, loss_t, _ = one()
