@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
     ap.add_argument("--backward-order", default="auto", choices=["auto", "dx-first", "layerwise"], help="A/B: every updateGradInput first "
                     "then the accGradParameters (auto: when the layers differ in size and there is no exchange), or layer by layer")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], help="the step as ONE hipGraph launch (vbnn_capture_*, device-resident "
+                    "draw counter); auto = off (measured slower than stream launches on this ROCm)")
     ap.add_argument("--exchange-dtype", default="f32", choices=["f32", "bf16"], help="data-parallel exchange payload: fp32 (default, the "
                     "metric) or the optional bf16 copy (half the bytes, a DIFFERENT gradient: reported as an option, config.exchange_dtype)")
     args = ap.parse_args()
@@ -258,7 +260,15 @@ def main():
                hidden=cfg["hidden"], n_classes=cfg["n_classes"], fuse_kl=True, overlap=args.overlap,
                criterion=cfg.get("criterion", "nll"), exchange_dtype=args.exchange_dtype, dx_first={"auto": None, "dx-first": True, "layerwise": False}[args.backward_order],
                state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
-    eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
+    # (auto = off everywhere: on this ROCm a captured step is bitwise the launched one but ~1.4 us per kernel node SLOWER than
+    # the same kernels launched back to back on a stream -- 95 against 82 us for the small configuration)
+    use_graph = args.mode == "lrt" and not use_dist and not args.overlap and args.graph == "on"
+    stream = None
+    if use_graph:                                         # a stream of the engine's own: the NULL stream cannot be captured
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)                     # (everything of this process from here on: fills, events, the step)
+        opt["device_draw"] = True
+    eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist, stream=stream)
     for kv in filter(None, args.debug_set.split(",")):
         k, v = kv.split("=")
         L.check(L.lib().vbnn_debug_set(int(k), int(v)))
@@ -278,6 +288,9 @@ def main():
                 eng.sample()
                 eng.run(x, t)
         eng.finish()
+
+    issue = step                                          # the step launch by launch (warm-up, capture, the probed block)
+    graph = None
 
     def train_step():
         step()
@@ -314,6 +327,14 @@ def main():
     eng.prepare()                                        # once: afterwards the update kernel maintains shadows + statistics
     for _ in range(args.warmup):
         step()
+    if use_graph:
+        torch.cuda.synchronize()
+        graph = eng.capture_step(issue)                   # the same calls, recorded once; every replay draws its own noise
+
+        def step():                                       # noqa: F811 -- from here on a step is ONE graph launch
+            graph.launch()
+        for _ in range(3):
+            step()
     wall, evms = timed_blocks(step, max(1, args.repeats))
     loss, correct = eng.loss_and_accuracy()
     ms = sorted(wall)[len(wall) // 2]
@@ -326,9 +347,24 @@ def main():
     barrier()
     tp0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        issue()                                           # launch by launch: events cannot be placed inside a graph replay
     barrier()
     probed_ms = (time.perf_counter() - tp0) / args.steps * 1e3
+    # what a dependent launch costs on this box, measured here: 400 one-thread kernels (vbnn_sample with an increment of 0)
+    floor_us = None
+    if rank == 0 and eng.device_draw:
+        import ctypes as C
+        dd = C.c_void_p(eng._draw_dev.data_ptr())
+        for _ in range(20):
+            L.check(L.lib().vbnn_sample(eng.ctx.h, dd, 0))
+        fe0, fe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        fe0.record()
+        for _ in range(400):
+            L.check(L.lib().vbnn_sample(eng.ctx.h, dd, 0))
+        fe1.record()
+        torch.cuda.synchronize()
+        floor_us = fe0.elapsed_time(fe1) * 1e3 / 400
     probe, eng.probe = eng.probe, None
 
     pcie = None
@@ -392,7 +428,10 @@ def main():
                        "repeats_wall_ms": [round(v, 4) for v in wall], "repeats_event_ms": [round(v, 4) for v in evms],
                        "probed_block_ms": round(probed_ms, 4),
                        "backward_order": ("every updateGradInput, then the accGradParameters from the first layer up" if eng.dx_first
-                                          and not eng.reduce else "layer by layer, accGradParameters (+ its all-reduce) first")},
+                                          and not eng.reduce else "layer by layer, accGradParameters (+ its all-reduce) first"),
+                       "launch": (f"ONE hipGraph launch per step: {graph.kernel_nodes} kernel nodes captured once (vbnn_capture_*), the draw "
+                                  "counter in device memory (vbnn_sample is a node), bitwise the launch-by-launch step" if graph else
+                                  "one stream launch per kernel")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": measured_traffic(kname, args.config),
                          "traffic_source": "profiles/r*_traffic.json: separate rocprofv3 --pmc passes of the same launch "
@@ -401,6 +440,12 @@ def main():
                          "timed_region_kernels_ms": {k: round(v_, 4) for k, v_ in live.items()},
                          "isolated_kernels_ms": kall},
         }
+        if floor_us is not None and graph is not None:
+            out["roofline"]["launch_floor"] = {"us_per_dependent_launch": round(floor_us, 3), "kernel_nodes": graph.kernel_nodes,
+                                               "ms_per_step": round(floor_us * graph.kernel_nodes * 1e-3, 4),
+                                               "note": "a one-thread kernel launched 400 times back to back on the step's stream, in this run: what "
+                                                       "the step's kernel boundaries alone cost; the step's MFMA time at the fp32 peak is "
+                                                       f"{fps * N / (peak * 1e12) * 1e3:.4f} ms"}
         if train:
             out["config"]["train"] = train
         if pcie:

@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
 #endif
 
-#define VBNN_ABI_VERSION 2
+#define VBNN_ABI_VERSION 3
 #define VBNN_KPAD 64            /* packed leading dimensions are multiples of this */
 
 enum { VBNN_OK = 0, VBNN_ERR_INVALID = 1, VBNN_ERR_HIP = 2, VBNN_ERR_NOMEM = 3, VBNN_ERR_UNSUPPORTED = 4 };
@@ -134,7 +134,8 @@ typedef struct vbnn_fwd_args {
     const void* w;      /* mu shadow (LRT) or sampled-weight shadow (WN / MAP)            */
     const void* w2;     /* sigma^2 shadow, LRT only (NULL: single GEMM)                    */
     const void* x;      /* input                                                           */
-    const void* x2;     /* input squared, LRT only                                         */
+    const void* x2;     /* input squared, LRT only. dtype F32: may be NULL -- the kernel forms x.x in  */
+                        /* registers while staging x (bit for bit what the packer would store)  */
     int64_t ld_w, ld_x;
     int64_t N, I, O;
     const float* bias;  /* O, may be NULL                                                  */
@@ -151,10 +152,19 @@ typedef struct vbnn_fwd_args {
      * minibatch row n % rows_per_draw of draw `draw + n / rows_per_draw`, and its noise is addressed accordingly -- bit
      * for bit the z of that draw's own launch. The backward GEMMs then sum over all draws in one pass (K = N). 0: off. */
     int64_t rows_per_draw;
+    /* optional DEVICE-RESIDENT draw counter (NULL: off): the noise is addressed by draw + *draw_dev, read when the kernel
+     * runs -- so that a step whose launches were captured into a graph (vbnn_capture_*) draws fresh noise at every replay:
+     * the host's `sample()` is then vbnn_sample (a device-side increment, itself a node of the graph) and `draw` stays a
+     * constant base. General kernel only: with it set the pipelined bf16 kernels are not selected (the launch-bound
+     * configurations are the ones worth capturing; the others take the counter as the launch argument above). */
+    const uint32_t* draw_dev;
 } vbnn_fwd_args;
 
 /* updateOutput. WN/MAP: y = x w^T + b  (inherited nn.Linear:updateOutput, VBLinear.lua:7).
- * LRT: m = x mu^T + b, v = (x.x)(sigma^2)^T, y = m + sqrt(v) . z   (north_star). */
+ * LRT: m = x mu^T + b, v = (x.x)(sigma^2)^T, y = m + sqrt(v) . z   (north_star).
+ * dtype F32 (the general kernel): `x` may be the RAW minibatch -- any 16-byte-aligned row-major matrix with ld_x >= I,
+ * ld_x % 4 == 0, columns [I, ld_x) finite; the K walk is masked at the row end, no zero padding is needed -- so an fp32
+ * host needs no vbnn_pack_input at all. */
 int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a);
 
 typedef struct vbnn_dx_args {
@@ -174,7 +184,8 @@ typedef struct vbnn_dx_args {
     void* g_prev; void* gv_prev; int64_t ld_gp;      /* N x ld_gp   */
     void* gT_prev; void* gvT_prev; int64_t ld_gpT;   /* I x ld_gpT  */
     /* optional K-MAJOR weights: mu, sigma^2 as the forward holds them (O x ld_w). When vbnn_kmajor_supported(I, N, O)
-     * says so the GEMM reads these and wT / w2T may be NULL: the parameter sweep writes no transposed shadows. */
+     * says so the GEMM reads these and wT / w2T may be NULL: the parameter sweep writes no transposed shadows.
+     * dtype F32: always (any shape) -- with wT == NULL the general kernel reads w / w2 K-major. */
     const void* w; const void* w2; int64_t ld_w;
 } vbnn_dx_args;
 
@@ -208,7 +219,10 @@ typedef struct vbnn_dw_args {
     float* gradBias;
     /* optional K-MAJOR operands: the untransposed x, x.x (N x ld_x) and g, gv (N x ld_g) exactly as the forward and
      * gradInput GEMMs hold them. When vbnn_kmajor_supported(I, O, N) says so the GEMM reads these (transpose reads in
-     * LDS) and xT / x2T / gT / gvT may be NULL: no epilogue has to write transposed copies. Otherwise xT.. are used. */
+     * LDS) and xT / x2T / gT / gvT may be NULL: no epilogue has to write transposed copies. Otherwise xT.. are used.
+     * dtype F32: always (any shape, part = 0) -- with xT == NULL the general kernel reads x and g (gv) K-major; x2 may
+     * then be NULL (x.x is formed in registers), x may be the raw minibatch (ld_x % 4 == 0), and gradBias needs no row or
+     * column of ones anywhere: the kernel synthesises it. */
     const void* x; const void* x2; const void* g; const void* gv; int64_t ld_x; int64_t ld_g;
     /* optional (fused total gradients only, dtype BF16): the packed operand shadows mu_s, var_s = exp(lvars) (O x ld_w,
      * as vbnn_prepare / vbnn_update leave them). When given, the epilogue reads mu and sigma^2 FROM THEM -- 4 B per weight
@@ -223,6 +237,7 @@ typedef struct vbnn_dw_args {
      * as two launches -- so that a data-parallel host can start the exchange of the finished d/dlvars while the d/dmeans
      * GEMM still runs (vbnn_allreduce_grads between the two calls). LRT pairs only. */
     int part;
+    const uint32_t* draw_dev;   /* as vbnn_fwd_args.draw_dev (the weight-noise form regenerates e from the counter) */
 } vbnn_dw_args;
 
 /* accGradParameters (VBLinear.lua:112-118), one GEMM instead of the reference's two. */
@@ -277,9 +292,11 @@ int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const fl
 
 /* The minibatch (N x I f32, row pitch ld_src) as GEMM operands in one pass: x_s, x2_s = (rounded x)^2 (N x ld_x)
  * and their transposes (I x ld_xT); x2_s / xT_s / x2T_s optional. Replaces the host->device copies of
- * main.lua:22-25 plus two vbnn_pack calls. */
+ * main.lua:22-25 plus two vbnn_pack calls. rows_per_draw > 0 (vbnn_fwd_args.rows_per_draw): the N operand rows are several
+ * Monte-Carlo draws of ONE minibatch of rows_per_draw rows -- operand row n is src row n % rows_per_draw, so the host never
+ * materialises the S-fold input. 0: off. */
 int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64_t ld_src, int64_t N, int64_t I, void* x_s,
-                    void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT);
+                    void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT, int64_t rows_per_draw);
 
 /* ---- the update that follows the hot path -------------------------------- */
 
@@ -357,6 +374,25 @@ int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int6
  * lets the host verify that `world` distinct processes / devices take part in the exchange. */
 int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
 
+/* ---- a whole step as ONE graph launch (launch-bound configurations: BASELINE configs[1], the reference's own batch-1
+ * S = 30 operating point, config.lua:11,32) ----------------------------------------------------------------------------
+ * mlp:sample() (mlp.lua:69-74) on the device: *draw_dev += by, ordered on the context's stream like any launch. With
+ * vbnn_fwd_args.draw_dev pointing at the same word, a captured step is replayable: every replay advances the counter
+ * and draws the noise of ITS draw, exactly what the same calls issued one by one compute (tested bitwise). */
+int vbnn_sample(vbnn_ctx* ctx, uint32_t* draw_dev, uint32_t by);
+/* vbnn_capture_begin: from here on the context's launches are RECORDED, not run (hipStreamBeginCapture on its stream --
+ * which must not be the NULL stream). Issue one step's calls as usual (every buffer already allocated, every kernel
+ * launched at least once before: allocation and first-launch configuration cannot be captured), then vbnn_capture_end
+ * returns the executable graph. vbnn_graph_launch replays it on that stream (asynchronous, like a launch); the arguments
+ * -- pointers, sizes, the accumulate flags -- are the recorded ones, the data behind the pointers is read at replay time.
+ * vbnn_graph_info: kernel nodes / all nodes of the graph. */
+typedef struct vbnn_graph vbnn_graph;
+int vbnn_capture_begin(vbnn_ctx* ctx);
+int vbnn_capture_end(vbnn_ctx* ctx, vbnn_graph** out);
+int vbnn_graph_launch(vbnn_graph* g);
+int vbnn_graph_info(vbnn_graph* g, int* kernel_nodes, int* nodes);
+int vbnn_graph_destroy(vbnn_graph* g);
+
 /* ---- glue modules on the measured path (mlp.lua:12-32) --------------------------------------- */
 int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);
 int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx, int64_t n);
@@ -385,11 +421,12 @@ int vbnn_mse_backward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* 
  * g_logits = d(loss)/d(logits) (N x C f32); `logits`, `out` optional. The loss (sum of -out[n][target] * inv_n) and
  * the hit count are summed in a fixed order inside the launch (bitwise reproducible) and stored to loss_sum_dev[0]
  * / correct_dev[0] when accumulate = 0, added to them when accumulate = 1 (the S draws of a minibatch,
- * mlp.lua:76-84): no memset of the two accumulators is needed. */
+ * mlp.lua:76-84): no memset of the two accumulators is needed. rows_per_draw > 0: stacked draws, row n's target is
+ * target[n % rows_per_draw] (`target` holds one minibatch's rows_per_draw entries). */
 int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
                       float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
-                      int32_t* correct_dev);
+                      int32_t* correct_dev, int64_t rows_per_draw);
 /* Backward of the same head in one pass over h: gradWeight (C x H) / gradBias (C) of the final Linear (accumulate
  * as in vbnn_acc_grad_parameters; NULL to skip), its gradInput pushed through the ReLU straight into the last VB
  * layer's packed gradient operands (same meaning as the hand-off fields of vbnn_dx_args), and optionally

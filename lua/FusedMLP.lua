@@ -94,27 +94,32 @@ function FusedMLP:_alloc_batch(N)
     if self.N == N then return end
     self.N = N
     local km_ok = self.dtype == C.VBNN_BF16 and self.S == 1
+    -- fp32 (the general kernel): the minibatch raw, x.x formed in registers, x / g / mu / sigma^2 K-major, the bias gradient
+    -- from a synthetic row of ones (engine.py: f32_direct). Not with an exchange (its two-launch accGradParameters wants x.x)
+    self.direct = self.dtype == C.VBNN_F32 and not self.comm
     local need_prepare = false
     local ones, ones_dev = torch.FloatTensor(N):fill(1), vb.alloc(N * 4)
     check(C.vbnn_buf_upload(vb.ctx, ones_dev, ones:data(), N * 4))
     for li, v in ipairs(self.vb) do
         local last = li == #self.vb
         v.bias_from_dw = (v.I % 256 ~= 0) and not last          -- the ones column / row of x: bias gradient from the GEMM
-        local km = km_ok and C.vbnn_kmajor_supported_dw(v.I, v.O, N, v.bias_from_dw and 1 or 0) or 0
-        v.dw_km = km > 0
+        local km = (km_ok and not self.direct) and C.vbnn_kmajor_supported_dw(v.I, v.O, N, v.bias_from_dw and 1 or 0) or 0
+        v.dw_km = km > 0 or self.direct
         -- the two-launch form of accGradParameters (early d/dlvars message) needs either the transposed operands or the
         -- plain K-major launch of the two-pass kernel; the few-tile K-major launches compute both GEMMs in one grid
-        v.early_ok = (not v.dw_km) or ((not v.bias_from_dw) and C.vbnn_kmajor_supported(v.I, v.O, N) ~= 0)
-        v.dx_km = km_ok and li > 1 and C.vbnn_kmajor_supported(v.I, N, v.O) ~= 0
+        v.early_ok = (not self.direct) and ((not v.dw_km) or ((not v.bias_from_dw) and C.vbnn_kmajor_supported(v.I, v.O, N) ~= 0))
+        v.dx_km = li > 1 and (self.direct or (km_ok and C.vbnn_kmajor_supported(v.I, N, v.O) ~= 0))
         local use_muT = li > 1 and not v.dx_km
         if use_muT and not v.use_muT then need_prepare = true end
         v.use_muT = use_muT
         local extra = v.bias_from_dw and 1 or 0
         local xcols = v.I + (v.dw_km and extra or 0)
         if km == 2 then xcols = math.floor((xcols + 255) / 256) * 256 end
-        v.x_s, v.x2_s = packed(N, xcols, self.esize), packed(N, xcols, self.esize)
+        if self.direct then xcols = v.I end                       -- (the row of ones is synthesised by the kernel)
+        v.x_s = packed(N, xcols, self.esize)
+        v.x2_s = (not self.direct) and packed(N, xcols, self.esize) or nil
         v.has_t = not v.dw_km                                     -- shapes without a K-major form get the transposed copies
-        if v.dw_km and v.bias_from_dw then                        -- column I of x is all ones, written once
+        if v.dw_km and v.bias_from_dw and not self.direct then    -- column I of x is all ones, written once
             check(C.vbnn_pack(vb.ctx, self.dtype, C.VBNN_PACK_COPY, f32(ones_dev), nil, 1, N, 1,
                               ffi.cast('char*', v.x_s.p) + v.I * self.esize, v.x_s.ld, nil, 0))
         end
@@ -163,18 +168,23 @@ function FusedMLP:run(inputs, ld, targets, N)
     local inv_n = 1 / (N * self.world)
     local row0 = self.rank * N
     local v0 = self.vb[1]
-    check(C.vbnn_pack_input(vb.ctx, self.dtype, f32(inputs), ld, N, v0.I, v0.x_s.p, v0.x2_s.p, v0.x_s.ld, v0.has_t and v0.xT_s.p or nil,
-                            v0.has_t and v0.x2T_s.p or nil, v0.has_t and v0.xT_s.ld or 0))
+    for _, v in ipairs(self.vb) do v.x_in, v.ld_in = v.x_s.p, v.x_s.ld end
+    if self.direct and ld % 4 == 0 and tonumber(ffi.cast('uintptr_t', inputs)) % 16 == 0 then
+        v0.x_in, v0.ld_in = inputs, ld                            -- the GEMMs read the minibatch where it lies: no packing launch
+    else
+        check(C.vbnn_pack_input(vb.ctx, self.dtype, f32(inputs), ld, N, v0.I, v0.x_s.p, v0.x2_s and v0.x2_s.p or nil, v0.x_s.ld,
+                                v0.has_t and v0.xT_s.p or nil, v0.has_t and v0.x2T_s.p or nil, v0.has_t and v0.xT_s.ld or 0, 0))
+    end
     -- forward: dual GEMM + noise / ReLU / operand packing in the epilogue
     for li, v in ipairs(self.vb) do
         local nxt = self.vb[li + 1]
         local fa = ffi.new('vbnn_fwd_args')
-        fa.w, fa.w2, fa.x, fa.x2, fa.ld_w, fa.ld_x = v.mu_s.p, v.var_s.p, v.x_s.p, v.x2_s.p, v.mu_s.ld, v.x_s.ld
+        fa.w, fa.w2, fa.x, fa.x2, fa.ld_w, fa.ld_x = v.mu_s.p, v.var_s.p, v.x_in, v.x2_s and v.x2_s.p or nil, v.mu_s.ld, v.ld_in
         fa.N, fa.I, fa.O, fa.bias = N, v.I, v.O, f32(v.bias)
         fa.seed, fa.layer, fa.draw, fa.row0 = self.seed, v.layer_id, self.draw, row0
         fa.r, fa.ld_r, fa.r_packed, fa.relu = v.r, v.O, 1, 1
         fa.h = nxt and nxt.x_s.p or self.h_s.p
-        fa.h2 = nxt and nxt.x2_s.p or nil
+        fa.h2 = (nxt and nxt.x2_s) and nxt.x2_s.p or nil
         fa.ld_h = nxt and nxt.x_s.ld or self.h_s.ld
         if nxt and nxt.has_t then fa.hT, fa.h2T, fa.ld_hT = nxt.xT_s.p, nxt.x2T_s.p, nxt.xT_s.ld end
         check(C.vbnn_forward(vb.ctx, self.dtype, fa))
@@ -183,7 +193,7 @@ function FusedMLP:run(inputs, ld, targets, N)
     local vl, H = self.vb[#self.vb], self.sizes[#self.sizes]
     check(C.vbnn_head_forward(vb.ctx, self.dtype, self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.bias3),
                               ffi.cast('const int32_t*', targets), N, H, self.n_classes, inv_n, f32(self.logits), f32(self.out),
-                              f32(self.g_logits), accumulate, ffi.cast('double*', self.acc), ffi.cast('int32_t*', self.corr)))
+                              f32(self.g_logits), accumulate, ffi.cast('double*', self.acc), ffi.cast('int32_t*', self.corr), 0))
     check(C.vbnn_head_backward(vb.ctx, self.dtype, self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.g_logits), N, H,
                                self.n_classes, accumulate, self.gradWeight3, self.gradBias3, vl.gradBias, 1, vl.r, vl.O, 1,
                                vl.g_s.p, vl.gv_s.p, vl.g_s.ld, vl.has_t and vl.gT_s.p or nil, vl.has_t and vl.gvT_s.p or nil,
@@ -198,7 +208,7 @@ function FusedMLP:run(inputs, ld, targets, N)
         d.grad_mu, d.grad_lv, d.means, d.stats = v.grad_mu, v.grad_lv, f32(v.means), ffi.cast('double*', v.stats)
         d.B, d.S, d.kl_scale = self.B, self.S, 1 / self.world
         d.gradBias = v.bias_from_dw and v.gradBias or nil
-        d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_s.p, v.x2_s.p, v.g_s.p, v.gv_s.p, v.x_s.ld, v.g_s.ld
+        d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_in, v.x2_s and v.x2_s.p or nil, v.g_s.p, v.gv_s.p, v.ld_in, v.g_s.ld
         if self.dtype == C.VBNN_BF16 then d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld end   -- KL terms from the shadows
         return d
     end

@@ -52,6 +52,7 @@ typedef struct vbnn_fwd_args {
     void* h;  void* h2;  int64_t ld_h;
     void* hT; void* h2T; int64_t ld_hT;
     int64_t rows_per_draw;
+    const uint32_t* draw_dev;
 } vbnn_fwd_args;
 int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a);
 typedef struct vbnn_dx_args {
@@ -89,6 +90,7 @@ typedef struct vbnn_dw_args {
     const void* x; const void* x2; const void* g; const void* gv; int64_t ld_x; int64_t ld_g;
     const void* mu_s; const void* var_s; int64_t ld_w;
     int part;
+    const uint32_t* draw_dev;
 } vbnn_dw_args;
 int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
 int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O,
@@ -114,7 +116,7 @@ int vbnn_compute_vargrads(vbnn_ctx* ctx, const float* lvars, const float* vars, 
 int vbnn_calc_lc(vbnn_ctx* ctx, const float* means, const float* lvars, const float* vars, const float* mu_sqe,
                  const double* stats, float B, float* lc_elem, double* lc_sum_dev, int64_t W);
 int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64_t ld_src, int64_t N, int64_t I, void* x_s,
-                    void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT);
+                    void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT, int64_t rows_per_draw);
 int vbnn_adam_step(vbnn_ctx* ctx, float* x, const float* grad, const float* grad2, float* m, float* v, int64_t n,
                    float lr, float beta1, float beta2, float eps, float lambda, int64_t t, double* norms_dev);
 int vbnn_sgd_step(vbnn_ctx* ctx, float* x, const float* grad, int64_t n, float lr);
@@ -142,6 +144,13 @@ int vbnn_comm_finish(vbnn_comm* comm);
 int vbnn_allreduce_grads_bf16(vbnn_comm* comm, void* buf_bf16, int64_t n);
 int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int64_t n);
 int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
+int vbnn_sample(vbnn_ctx* ctx, uint32_t* draw_dev, uint32_t by);
+typedef struct vbnn_graph vbnn_graph;
+int vbnn_capture_begin(vbnn_ctx* ctx);
+int vbnn_capture_end(vbnn_ctx* ctx, vbnn_graph** out);
+int vbnn_graph_launch(vbnn_graph* g);
+int vbnn_graph_info(vbnn_graph* g, int* kernel_nodes, int* nodes);
+int vbnn_graph_destroy(vbnn_graph* g);
 int vbnn_relu_forward(vbnn_ctx* ctx, const float* x, float* y, int64_t n);
 int vbnn_relu_backward(vbnn_ctx* ctx, const float* x, const float* g, float* gx, int64_t n);
 int vbnn_logsoftmax_nll(vbnn_ctx* ctx, const float* logits, int64_t ld, const int32_t* target,
@@ -154,7 +163,7 @@ int vbnn_mse_backward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* 
 int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
                       float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
-                      int32_t* correct_dev);
+                      int32_t* correct_dev, int64_t rows_per_draw);
 int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                        const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
                        float* gradBias, float* gradBias_prev, int relu_mask, const void* r_prev, int64_t ld_r_prev,

@@ -882,6 +882,66 @@ def test_two_engines_on_two_streams_compute_what_each_computes_alone(nnmod):
     assert not torch.equal(ref[0][0], ref[1][0])
 
 
+@pytest.mark.parametrize("N,S,stack", [(256, 1, False), (1, 30, True), (100, 3, False)], ids=["batch256", "batch1-S30-stacked", "batch100-S3"])
+def test_captured_step_is_bitwise_the_launched_step(nnmod, N, S, stack):
+    """BASELINE configs[1] (784-400-400-10, fp32) as ONE graph launch: the draw counter lives in device memory
+    (vbnn_fwd_args.draw_dev, vbnn_sample), the step's launches are captured once (vbnn_capture_*) and replayed. Every replay
+    must be bit for bit the same step issued launch by launch -- its own noise included (the counter advances inside the
+    graph) -- for the batch-256 step, for the reference's own operating point (batch 1, S = 30, config.lua:11,32, draws
+    stacked as rows) and for S sequential draws accumulating (main.lua:32-37)."""
+    from vbnn_amd.engine import FusedMLP
+    I0 = 784
+    opt = opt_for("lrt", "f32", input_size=I0, hidden=[400, 400], S=S, fuse_kl=True, device_draw=True)
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    torch.cuda.synchronize()
+
+    def make():
+        s = torch.cuda.Stream()
+        e = FusedMLP(opt, stream=s)
+
+        def issue():
+            e.resetGradients()
+            if stack:
+                e.run_draws(x, t, S)
+            else:
+                for _ in range(S):
+                    e.sample(); e.run(x, t)
+            e.finish()
+        with torch.cuda.stream(s):
+            e.prepare()
+        return e, s, issue
+
+    ea, sa, issue_a = make()
+    want = []
+    for step in range(4):                                       # launch by launch
+        with torch.cuda.stream(sa):
+            issue_a()
+        loss, _ = ea.loss_and_accuracy()
+        want.append((ea.grads.clone(), loss, ea.vb[0].r.clone()))
+    assert not torch.equal(want[1][2], want[2][2])              # each step drew its own noise
+
+    eb, sb, issue_b = make()
+    with torch.cuda.stream(sb):
+        issue_b()                                               # step 1 un-captured: allocations, first-launch configuration
+    loss, _ = eb.loss_and_accuracy()
+    assert torch.equal(eb.grads, want[0][0]) and loss == want[0][1]
+    g = eb.capture_step(issue_b)
+    # fp32: no packing launch, no finish launch -- sample, 2 forwards, 2 head kernels, gradInput, 2 accGradParameters (+ one
+    # more sample for the stacked draws)
+    want_nodes = 10 if stack else 8 * S          # stacked draws: + the packer (row n % rows_per_draw) and the closing sample(S - 1)
+    assert g.kernel_nodes == g.nodes == want_nodes, (g.kernel_nodes, g.nodes, want_nodes)
+    print(f"captured step: {g.kernel_nodes} kernel nodes")
+    for step in range(1, 4):                                    # steps 2..4 as graph replays
+        g.launch()
+        loss, _ = eb.loss_and_accuracy()
+        assert torch.equal(eb.vb[0].r, want[step][2]), f"replay {step}: the noise differs"
+        assert torch.equal(eb.grads, want[step][0]) and loss == want[step][1], f"replay {step}: gradients / loss differ"
+    assert eb.draw == ea.draw
+    g.close()
+
+
 # ------------------------------------------------------------------------------------------- update (SURVEY 8f next #1)
 OPT_STATES = dict(state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
 

@@ -70,11 +70,13 @@ typedef struct {
     packed_t x_s, x2_s, xT_s, x2T_s, g_s, gv_s, gT_s, gvT_s;
     void* r;
     int bias_from_dw, dw_km, dx_km, use_muT, early_ok, has_t;
+    const void* x_in; int64_t ld_in;                       /* this run's input operand of the layer (x_s, or the raw minibatch) */
     int64_t t;
 } layer_t;
 
 typedef struct {
     int dtype, esize, n_layers, n_classes, world, rank, dx_first;
+    int direct;               /* fp32: operands as their producers left them (no packing launch, no squares, no transposes) */
     uint64_t seed;
     float B, S;
     double var_init;
@@ -167,6 +169,9 @@ static void fm_alloc_batch(fused_mlp* m, int64_t N) {
     if (m->N) { fprintf(stderr, "c_host: one batch size per process\n"); exit(2); }
     m->N = N;
     const int km_ok = m->dtype == VBNN_BF16 && (int)m->S == 1;
+    /* fp32 (the general kernel): the minibatch raw, x.x formed in registers, x / g / mu / sigma^2 K-major, the bias gradient
+       from a synthetic row of ones (engine.py: f32_direct). Not with an exchange (its two-launch accGradParameters wants x.x) */
+    m->direct = m->dtype == VBNN_F32 && !m->comm;
     int need_prepare = 0;
     float* ones_host = (float*)malloc((size_t)N * 4);
     for (int64_t k = 0; k < N; ++k) ones_host[k] = 1.0f;
@@ -177,6 +182,13 @@ static void fm_alloc_batch(fused_mlp* m, int64_t N) {
         layer_t* v = &m->vb[li];
         const int last = li == m->n_layers - 1;
         v->bias_from_dw = (v->I % 256 != 0) && !last;             /* the ones column / row of x: bias gradient from the GEMM */
+        if (m->direct) {
+            v->dw_km = 1; v->early_ok = 0; v->dx_km = li > 0; v->use_muT = 0; v->has_t = 0;
+            v->x_s = packed(N, v->I, m->esize);                   /* (layer 1: only when the raw minibatch cannot be read in place) */
+            v->g_s = packed(N, v->O, m->esize); v->gv_s = packed(N, v->O, m->esize);
+            v->r = dev_alloc((size_t)N * v->O * m->esize);
+            continue;
+        }
         const int km = km_ok ? vbnn_kmajor_supported_dw(v->I, v->O, N, v->bias_from_dw) : 0;
         v->dw_km = km > 0;
         v->early_ok = !v->dw_km || (!v->bias_from_dw && vbnn_kmajor_supported(v->I, v->O, N));
@@ -240,7 +252,7 @@ static void dw_block(fused_mlp* m, int li, int64_t N, int accumulate, vbnn_dw_ar
     d->grad_mu = v->grad_mu; d->grad_lv = v->grad_lv; d->means = v->means; d->stats = v->stats;
     d->B = m->B; d->S = m->S; d->kl_scale = 1.0f / (float)m->world;
     d->gradBias = v->bias_from_dw ? v->gradBias : NULL;
-    d->x = v->x_s.p; d->x2 = v->x2_s.p; d->g = v->g_s.p; d->gv = v->gv_s.p; d->ld_x = v->x_s.ld; d->ld_g = v->g_s.ld;
+    d->x = v->x_in; d->x2 = m->direct ? NULL : v->x2_s.p; d->g = v->g_s.p; d->gv = v->gv_s.p; d->ld_x = v->ld_in; d->ld_g = v->g_s.ld;
     if (m->dtype == VBNN_BF16) { d->mu_s = v->mu_s.p; d->var_s = v->var_s.p; d->ld_w = v->mu_s.ld; }   /* KL terms from the shadows */
 }
 
@@ -265,20 +277,25 @@ static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t*
     const int64_t row0 = (int64_t)m->rank * N;
     const int nl = m->n_layers;
     layer_t* v0 = &m->vb[0];
-    CHECK(vbnn_pack_input(g_ctx, m->dtype, inputs, ld, N, v0->I, v0->x_s.p, v0->x2_s.p, v0->x_s.ld, v0->has_t ? v0->xT_s.p : NULL,
-                          v0->has_t ? v0->x2T_s.p : NULL, v0->has_t ? v0->xT_s.ld : 0));
+    for (int li = 0; li < nl; ++li) { m->vb[li].x_in = m->vb[li].x_s.p; m->vb[li].ld_in = m->vb[li].x_s.ld; }
+    if (m->direct && ld % 4 == 0 && ((uintptr_t)inputs & 15u) == 0) {
+        v0->x_in = inputs; v0->ld_in = ld;                        /* the GEMMs read the minibatch where it lies: no packing launch */
+    } else {
+        CHECK(vbnn_pack_input(g_ctx, m->dtype, inputs, ld, N, v0->I, v0->x_s.p, m->direct ? NULL : v0->x2_s.p, v0->x_s.ld,
+                              v0->has_t ? v0->xT_s.p : NULL, v0->has_t ? v0->x2T_s.p : NULL, v0->has_t ? v0->xT_s.ld : 0, 0));
+    }
     /* forward: dual GEMM + noise / ReLU / operand packing in the epilogue */
     for (int li = 0; li < nl; ++li) {
         layer_t* v = &m->vb[li];
         layer_t* nxt = li + 1 < nl ? &m->vb[li + 1] : NULL;
         vbnn_fwd_args fa;
         memset(&fa, 0, sizeof fa);
-        fa.w = v->mu_s.p; fa.w2 = v->var_s.p; fa.x = v->x_s.p; fa.x2 = v->x2_s.p; fa.ld_w = v->mu_s.ld; fa.ld_x = v->x_s.ld;
+        fa.w = v->mu_s.p; fa.w2 = v->var_s.p; fa.x = v->x_in; fa.x2 = m->direct ? NULL : v->x2_s.p; fa.ld_w = v->mu_s.ld; fa.ld_x = v->ld_in;
         fa.N = N; fa.I = v->I; fa.O = v->O; fa.bias = v->bias;
         fa.seed = m->seed; fa.layer = v->layer_id; fa.draw = m->draw; fa.row0 = row0;
         fa.r = v->r; fa.ld_r = v->O; fa.r_packed = 1; fa.relu = 1;
         fa.h = nxt ? nxt->x_s.p : m->h_s.p;
-        fa.h2 = nxt ? nxt->x2_s.p : NULL;
+        fa.h2 = (nxt && !m->direct) ? nxt->x2_s.p : NULL;
         fa.ld_h = nxt ? nxt->x_s.ld : m->h_s.ld;
         if (nxt && nxt->has_t) { fa.hT = nxt->xT_s.p; fa.h2T = nxt->x2T_s.p; fa.ld_hT = nxt->xT_s.ld; }
         CHECK(vbnn_forward(g_ctx, m->dtype, &fa));
@@ -287,7 +304,7 @@ static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t*
     layer_t* vl = &m->vb[nl - 1];
     const int64_t H = m->sizes[nl];
     CHECK(vbnn_head_forward(g_ctx, m->dtype, m->h_s.p, m->h_s.ld, m->w3_s.p, m->w3_s.ld, m->bias3, targets, N, H, m->n_classes, inv_n,
-                            m->logits, m->out, m->g_logits, accumulate, m->acc, m->corr));
+                            m->logits, m->out, m->g_logits, accumulate, m->acc, m->corr, 0));
     CHECK(vbnn_head_backward(g_ctx, m->dtype, m->h_s.p, m->h_s.ld, m->w3_s.p, m->w3_s.ld, m->g_logits, N, H, m->n_classes, accumulate,
                              m->gradWeight3, m->gradBias3, vl->gradBias, 1, vl->r, vl->O, 1, vl->g_s.p, vl->gv_s.p, vl->g_s.ld,
                              vl->has_t ? vl->gT_s.p : NULL, vl->has_t ? vl->gvT_s.p : NULL, vl->has_t ? vl->gT_s.ld : 0));

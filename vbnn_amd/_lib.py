@@ -30,7 +30,8 @@ class FwdArgs(C.Structure):
                 ("N", _i64), ("I", _i64), ("O", _i64), ("bias", _vp),
                 ("seed", _u64), ("layer", _u32), ("draw", _u32), ("row0", _i64),
                 ("y", _vp), ("ld_y", _i64), ("r", _vp), ("ld_r", _i64), ("r_packed", _i), ("relu", _i),
-                ("h", _vp), ("h2", _vp), ("ld_h", _i64), ("hT", _vp), ("h2T", _vp), ("ld_hT", _i64), ("rows_per_draw", _i64)]
+                ("h", _vp), ("h2", _vp), ("ld_h", _i64), ("hT", _vp), ("h2T", _vp), ("ld_hT", _i64), ("rows_per_draw", _i64),
+                ("draw_dev", _vp)]
 
 
 class DxArgs(C.Structure):
@@ -70,7 +71,7 @@ class DwArgs(C.Structure):
                 ("lvars", _vp), ("grad_mu", _vp), ("grad_lv", _vp), ("means", _vp), ("stats", _vp),
                 ("B", _f), ("S", _f), ("kl_scale", _f), ("gradBias", _vp),
                 ("x", _vp), ("x2", _vp), ("g", _vp), ("gv", _vp), ("ld_x", _i64), ("ld_g", _i64),
-                ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64), ("part", _i)]
+                ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64), ("part", _i), ("draw_dev", _vp)]
 
 
 _SIGS = {
@@ -100,7 +101,7 @@ _SIGS = {
     "vbnn_compute_mugrads": ([_vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),
     "vbnn_compute_vargrads": ([_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),
     "vbnn_calc_lc": ([_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i64], _i),
-    "vbnn_pack_input": ([_vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64], _i),
+    "vbnn_pack_input": ([_vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64], _i),
     "vbnn_adam_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _vp], _i),
     "vbnn_sgd_step": ([_vp, _vp, _vp, _i64, _f], _i),
     "vbnn_update": ([_vp, _i, _i, _vp, _vp], _i),
@@ -113,11 +114,17 @@ _SIGS = {
     "vbnn_allreduce_grads_bf16": ([_vp, _vp, _i64], _i),
     "vbnn_cast_grads": ([_vp, _i, _vp, _vp, _i64], _i),
     "vbnn_comm_allgather_u64": ([_vp, _vp, _vp], _i),
+    "vbnn_sample": ([_vp, _vp, _u32], _i),
+    "vbnn_capture_begin": ([_vp], _i),
+    "vbnn_capture_end": ([_vp, C.POINTER(_vp)], _i),
+    "vbnn_graph_launch": ([_vp], _i),
+    "vbnn_graph_info": ([_vp, C.POINTER(_i), C.POINTER(_i)], _i),
+    "vbnn_graph_destroy": ([_vp], _i),
     "vbnn_relu_forward": ([_vp, _vp, _vp, _i64], _i),
     "vbnn_relu_backward": ([_vp, _vp, _vp, _vp, _i64], _i),
     "vbnn_logsoftmax_nll": ([_vp, _vp, _i64, _vp, _i64, _i64, _f, _vp, _vp, _vp, _vp], _i),
     "vbnn_prepare": ([_vp, _i, _i, _vp, _vp], _i),
-    "vbnn_head_forward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _f, _vp, _vp, _vp, _i, _vp, _vp], _i),
+    "vbnn_head_forward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _f, _vp, _vp, _vp, _i, _vp, _vp, _i64], _i),
     "vbnn_head_backward": ([_vp, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp,
                            _vp, _i64, _vp, _vp, _i64], _i),
     "vbnn_mse_forward": ([_vp, _vp, _i64, _vp, _i64, _i64, _i64, _f, _vp, _i64, _i, _vp], _i),

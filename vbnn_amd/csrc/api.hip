@@ -1,6 +1,7 @@
 // api.hip -- context, device buffers and error reporting of the C ABI (include/vbnn_hip.h).
 #include "common.h"
 #include <stdarg.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -138,6 +139,90 @@ extern "C" int vbnn_buf_download(vbnn_ctx* ctx, void* dst_host, const void* src_
     VBNN_REQUIRE(ctx && dst_host && src_dev, "argument");
     VBNN_CHECK_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     VBNN_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+// ---- a step as one graph launch (include/vbnn_hip.h) -----------------------------------------------------------------
+__global__ void k_sample_advance(uint32_t* draw_dev, uint32_t by) { *draw_dev += by; }
+
+extern "C" int vbnn_sample(vbnn_ctx* ctx, uint32_t* draw_dev, uint32_t by) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && draw_dev, "argument");
+    hipLaunchKernelGGL(k_sample_advance, dim3(1), dim3(1), 0, ctx->stream, draw_dev, by);
+    return vbnn_check_launch("k_sample_advance");
+    VBNN_API_END
+}
+
+struct vbnn_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    hipStream_t stream;
+    int device;
+    int kernel_nodes, nodes;
+};
+
+extern "C" int vbnn_capture_begin(vbnn_ctx* ctx) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx, "null ctx");
+    VBNN_REQUIRE(ctx->stream != nullptr, "the NULL stream cannot be captured: give the context a stream of its own");
+    // relaxed: other threads of the host (an allocator, a data loader) may go on calling HIP while this stream records
+    VBNN_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_capture_end(vbnn_ctx* ctx, vbnn_graph** out) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && out, "argument");
+    hipGraph_t g = nullptr;
+    VBNN_CHECK_HIP(hipStreamEndCapture(ctx->stream, &g));
+    if (!g) { vbnn_set_error("the capture was invalidated (an operation that cannot be recorded was issued on the stream)"); return VBNN_ERR_HIP; }
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); vbnn_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+    vbnn_graph* r = new vbnn_graph();
+    r->graph = g; r->exec = ex; r->stream = ctx->stream; r->device = ctx->device; r->kernel_nodes = 0; r->nodes = 0;
+    size_t n = 0;
+    if (hipGraphGetNodes(g, nullptr, &n) == hipSuccess && n > 0) {
+        std::vector<hipGraphNode_t> nodes(n);
+        if (hipGraphGetNodes(g, nodes.data(), &n) == hipSuccess) {
+            r->nodes = (int)n;
+            for (size_t i = 0; i < n; ++i) {
+                hipGraphNodeType t;
+                if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) r->kernel_nodes += 1;
+            }
+        }
+    }
+    *out = r;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_graph_launch(vbnn_graph* g) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(g && g->exec, "null graph");
+    VBNN_CHECK_HIP(hipGraphLaunch(g->exec, g->stream));
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_graph_info(vbnn_graph* g, int* kernel_nodes, int* nodes) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(g, "null graph");
+    if (kernel_nodes) *kernel_nodes = g->kernel_nodes;
+    if (nodes) *nodes = g->nodes;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_graph_destroy(vbnn_graph* g) {
+    VBNN_API_BEGIN
+    if (!g) return VBNN_OK;
+    (void)hipStreamSynchronize(g->stream);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
     return VBNN_OK;
     VBNN_API_END
 }

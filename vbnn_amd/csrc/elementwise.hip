@@ -1001,7 +1001,7 @@ extern "C" int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_up
 // transposes. Same tiling as k_prep_layer: 4 elements per thread, LDS transpose.
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ src, int64_t ld_src, int64_t N, int64_t I, T* x_s,
-                                                    T* x2_s, int64_t ld_x, T* xT_s, T* x2T_s, int64_t ld_xT) {
+                                                    T* x2_s, int64_t ld_x, T* xT_s, T* x2T_s, int64_t ld_xT, int64_t rpd) {
     __shared__ float ta[64][65];
     __shared__ float tb[64][65];
     const int64_t tiles_c = (I + 63) / 64, tiles_r = (N + 63) / 64;
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ sr
             float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
             const int valid = (r < N) ? (int)min((int64_t)4, I - c) : 0;
             if (valid > 0) {
-                load4<float>(src + r * ld_src + c, a, valid, vec_in);
+                load4<float>(src + (rpd > 0 ? r % rpd : r) * ld_src + c, a, valid, vec_in);     // stacked draws: row n is minibatch row n % rpd
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float ar = Elt<T>::from(Elt<T>::to(a[e])); b[e] = ar * ar; }
                 store4<T>(x_s + r * ld_x + c, a[0], a[1], a[2], a[3], valid, true);
@@ -1047,9 +1047,10 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ sr
 }
 
 extern "C" int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64_t ld_src, int64_t N, int64_t I, void* x_s,
-                               void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT) {
+                               void* x2_s, int64_t ld_x, void* xT_s, void* x2T_s, int64_t ld_xT, int64_t rows_per_draw) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && src && x_s, "null argument");
+    VBNN_REQUIRE(rows_per_draw >= 0, "rows_per_draw");
     VBNN_REQUIRE(N > 0 && I > 0 && ld_src >= I && ld_x >= I && ld_x % 4 == 0, "shape");
     VBNN_REQUIRE(!x2T_s || xT_s, "x2T_s needs xT_s");
     VBNN_REQUIRE(!xT_s || ld_xT >= N, "ld_xT");
@@ -1057,10 +1058,10 @@ extern "C" int vbnn_pack_input(vbnn_ctx* ctx, int dtype, const float* src, int64
     const int nb = (int)(ntiles < 4096 ? ntiles : 4096);
     if (dtype == VBNN_F32)
         hipLaunchKernelGGL(k_pack_input<float>, dim3(nb), dim3(256), 0, ctx->stream, src, ld_src, N, I, (float*)x_s, (float*)x2_s,
-                           ld_x, (float*)xT_s, (float*)x2T_s, ld_xT);
+                           ld_x, (float*)xT_s, (float*)x2T_s, ld_xT, rows_per_draw);
     else if (dtype == VBNN_BF16)
         hipLaunchKernelGGL(k_pack_input<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, src, ld_src, N, I, (bf16_t*)x_s,
-                           (bf16_t*)x2_s, ld_x, (bf16_t*)xT_s, (bf16_t*)x2T_s, ld_xT);
+                           (bf16_t*)x2_s, ld_x, (bf16_t*)xT_s, (bf16_t*)x2T_s, ld_xT, rows_per_draw);
     else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
     return vbnn_check_launch("k_pack_input");
     VBNN_API_END

@@ -57,6 +57,7 @@ struct EpiFwd {
     const float* bias;
     int noise;
     uint64_t seed; uint32_t layer, draw; int64_t row0;
+    const uint32_t* draw_dev = nullptr;              // optional device-resident draw counter (vbnn_fwd_args.draw_dev): added to `draw`
     int rpd;                                         // > 0: stacked draws, vbnn_fwd_args.rows_per_draw
     float* y; int64_t ld_y; int y_vec;
     float* r; T* r_t; int64_t ld_r; int r_vec;       // r as f32 (module path) or as T (fused path), never both
@@ -67,6 +68,9 @@ struct EpiFwd {
 
     static constexpr bool SPLITTABLE = false;     // every output needs both GEMMs of the pair
     static constexpr bool EDGE_FAST = false;      // ragged wave tiles take the guarded form
+    // kernels that support the device-resident counter call this once at entry (a wave-uniform scalar load)
+    __device__ __forceinline__ void bind_draw() { if (draw_dev) draw += *draw_dev; }
+    __host__ __device__ __forceinline__ bool has_draw_dev() const { return draw_dev != nullptr; }
     __device__ __forceinline__ void edge_row(int, float) const {}
     __device__ __forceinline__ void set_part(int) {}
     __host__ __device__ __forceinline__ T* t1_ptr() const { return hT; }
@@ -303,6 +307,8 @@ struct EpiDx {
 
     static constexpr bool SPLITTABLE = false;
     static constexpr bool EDGE_FAST = false;
+    __device__ __forceinline__ void bind_draw() {}                 // (no noise in gradInput: r comes from the forward)
+    __host__ __device__ __forceinline__ bool has_draw_dev() const { return false; }
     __device__ __forceinline__ void edge_row(int, float) const {}
     __device__ __forceinline__ void set_part(int) {}
     __host__ __device__ __forceinline__ T* t1_ptr() const { return gT_prev; }
@@ -425,6 +431,7 @@ struct EpiDw {
     float scale; int accumulate;
     float* gradWeight; float* gradSum; int vec;
     uint64_t seed; uint32_t layer, draw;
+    const uint32_t* draw_dev = nullptr;   // optional device-resident draw counter (vbnn_dw_args.draw_dev; weight-noise e only)
     const float* lvars;
     float* grad_mu; float* grad_lv;
     const float* means; const double* stats; float B, S, kl_scale;
@@ -438,6 +445,8 @@ struct EpiDw {
     int part = 0;
     static constexpr bool SPLITTABLE = true;
     __device__ __forceinline__ void set_part(int p) { part = p; }
+    __device__ __forceinline__ void bind_draw() { if (draw_dev) draw += *draw_dev; }
+    __host__ __device__ __forceinline__ bool has_draw_dev() const { return draw_dev != nullptr; }
     // A wave tile that straddles the last row I of the output (I % 4 == 0, so every lane's quad is wholly inside or
     // wholly outside) may still take the FAST protocol with the outside lanes switched off: its batched loads then
     // cost one latency per batch instead of one per position, on the wave that otherwise finishes the launch last.

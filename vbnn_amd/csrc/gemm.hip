@@ -62,7 +62,8 @@ static bool try_kmajor(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda
     if constexpr (sizeof(T) != 2) {
         return false;
     } else {
-        if (!A || !B || (DUAL && (!A2 || !B2)) || !kmajor_selected(M, N, K) || !gemm_v3_possible(M, N, K, lda, ldb, AK, BK, epi))
+        if (!A || !B || (DUAL && (!A2 || !B2)) || epi.has_draw_dev() || !kmajor_selected(M, N, K) ||
+            !gemm_v3_possible(M, N, K, lda, ldb, AK, BK, epi))
             return false;
         *status = launch_gemm_v3<T, DUAL, AK, BK, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb, (int)M,
                                                        (int)N, (int)K, epi);
@@ -72,12 +73,23 @@ static bool try_kmajor(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda
 
 template <typename T, bool DUAL, class Epi>
 static int launch_gemm(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda, const void* B, const void* B2,
-                       int64_t ldb, int64_t M, int64_t N, int64_t K, const Epi& epi) {
+                       int64_t ldb, int64_t M, int64_t N, int64_t K, const Epi& epi, const V1Form& form = V1Form()) {
+    if (form.ta || form.tb || form.sq) {
+        // fp32 operand forms of the general kernel (gemm_v1.h): K-major sides, the squared partner formed in registers
+        if (!A || !B || (DUAL && ((form.sq != 2 && !A2) || (form.sq != 1 && !B2)))) {
+            vbnn_set_error("operand missing for the fp32 K-major / squared form");
+            return VBNN_ERR_INVALID;
+        }
+        return launch_gemm_v1<T, DUAL, Epi>(ctx->stream, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
+                                            (int)M, (int)N, (int)K, epi, form);
+    }
     if (!A || !B || (DUAL && (!A2 || !B2))) {
         vbnn_set_error("the K-contiguous operands are required for this shape (vbnn_kmajor_supported says no)");
         return VBNN_ERR_INVALID;
     }
-    const bool v2_ok = gemm_v2_possible<T>(lda, ldb) && M * lda < (1ll << 30) && N * ldb < (1ll << 30);
+    // the device-resident draw counter is read by the general kernel only (the launch-bound configurations that get
+    // captured into a graph run on it; the pipelined kernels take the counter as a launch argument)
+    const bool v2_ok = gemm_v2_possible<T>(lda, ldb) && M * lda < (1ll << 30) && N * ldb < (1ll << 30) && !epi.has_draw_dev();
     if (v2_ok && sizeof(T) == 2 &&
         ((g_force_kernel == 3 && gemm_v3_possible(M, N, K, lda, ldb, false, false, epi)) ||
          (g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_eligible(M, N, K, lda, ldb, false, false, epi))))
@@ -95,7 +107,7 @@ static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
     EpiFwd<T> e;
     e.bias = a->bias;
     e.noise = a->w2 != nullptr ? (g_fake_noise ? 2 : 1) : 0;
-    e.seed = a->seed; e.layer = a->layer; e.draw = a->draw; e.row0 = a->row0;
+    e.seed = a->seed; e.layer = a->layer; e.draw = a->draw; e.row0 = a->row0; e.draw_dev = a->draw_dev;
     e.rpd = (int)a->rows_per_draw;
     e.y = a->y; e.ld_y = a->ld_y; e.y_vec = a->y && aligned16(a->y) && (a->ld_y % 4 == 0);
     e.r = a->r_packed ? nullptr : (float*)a->r;
@@ -105,7 +117,11 @@ static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
     e.h = (T*)a->h; e.h2 = (T*)a->h2; e.ld_h = a->ld_h;
     e.hT = (T*)a->hT; e.h2T = (T*)a->h2T; e.ld_hT = a->ld_hT;
     e.O = (int)a->O; e.N = (int)a->N;
-    if (a->w2) return launch_gemm<T, true>(ctx, a->w, a->w2, a->ld_w, a->x, a->x2, a->ld_x, a->O, a->N, a->I, e);
+    if (a->w2) {
+        V1Form f;
+        if (!a->x2) f.sq = 1;                                    // fp32: x.x is formed while staging x (vbnn_fwd_args.x2 == NULL)
+        return launch_gemm<T, true>(ctx, a->w, a->w2, a->ld_w, a->x, a->x2, a->ld_x, a->O, a->N, a->I, e, f);
+    }
     return launch_gemm<T, false>(ctx, a->w, nullptr, a->ld_w, a->x, nullptr, a->ld_x, a->O, a->N, a->I, e);
 }
 
@@ -127,6 +143,14 @@ static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
     if (dual ? try_kmajor<T, true, true, false>(ctx, a->w, a->w2, a->ld_w, a->g, a->gv, a->ld_g, a->I, a->N, a->O, e, &st)
              : try_kmajor<T, false, true, false>(ctx, a->w, nullptr, a->ld_w, a->g, nullptr, a->ld_g, a->I, a->N, a->O, e, &st))
         return st;
+    if constexpr (sizeof(T) == 4) {
+        if (!a->wT && a->w) {                                    // fp32: the weights K-major as the forward holds them (gemm_v1.h, TA)
+            V1Form f;
+            f.ta = true;
+            if (dual) return launch_gemm<T, true>(ctx, a->w, a->w2, a->ld_w, a->g, a->gv, a->ld_g, a->I, a->N, a->O, e, f);
+            return launch_gemm<T, false>(ctx, a->w, nullptr, a->ld_w, a->g, nullptr, a->ld_g, a->I, a->N, a->O, e, f);
+        }
+    }
     if (dual) return launch_gemm<T, true>(ctx, a->wT, a->w2T, a->ld_wT, a->g, a->gv, a->ld_g, a->I, a->N, a->O, e);
     return launch_gemm<T, false>(ctx, a->wT, nullptr, a->ld_wT, a->g, nullptr, a->ld_g, a->I, a->N, a->O, e);
 }
@@ -134,13 +158,13 @@ static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
 template <typename T>
 static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
     EpiDw e;
-    e.lrt = (a->x2T != nullptr) || (a->x2 != nullptr);
+    e.lrt = (a->x2T != nullptr) || (a->x2 != nullptr) || (a->gvT != nullptr) || (a->gv != nullptr);
     e.scale = a->scale; e.accumulate = a->accumulate;
     e.gradWeight = a->gradWeight; e.gradSum = a->gradSum;
     e.vec = (a->I % 4 == 0) && (!a->lvars || aligned16(a->lvars)) && (!a->means || aligned16(a->means)) &&
             (!a->gradWeight || aligned16(a->gradWeight)) && (!a->gradSum || aligned16(a->gradSum)) &&
             (!a->grad_mu || aligned16(a->grad_mu)) && (!a->grad_lv || aligned16(a->grad_lv));
-    e.seed = a->seed; e.layer = a->layer; e.draw = a->draw;
+    e.seed = a->seed; e.layer = a->layer; e.draw = a->draw; e.draw_dev = a->draw_dev;
     e.lvars = a->lvars;
     e.grad_mu = a->grad_mu; e.grad_lv = a->grad_lv;
     e.means = a->means; e.stats = a->stats; e.B = a->B; e.S = a->S; e.kl_scale = a->kl_scale;
@@ -166,6 +190,18 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
         return launch_gemm<T, false>(ctx, xt, nullptr, a->ld_n, gt, nullptr, a->ld_n, Mp, a->O, a->N, e);
     }
     const bool dual = e.lrt != 0;
+    if constexpr (sizeof(T) == 4) {
+        if (!a->xT && a->x && a->g) {
+            // fp32: x and g (gv) K-major as the forward / gradInput GEMMs hold them, x.x formed in registers when not given,
+            // the bias gradient from a synthetic row of ones (gemm_v1.h: TA, TB, SQ = 2, ones_row)
+            V1Form f;
+            f.ta = f.tb = true;
+            f.sq = (dual && !a->x2) ? 2 : 0;
+            f.ones_row = a->gradBias ? (int)a->I : -1;
+            if (dual) return launch_gemm<T, true>(ctx, a->x, a->x2, a->ld_x, a->g, a->gv, a->ld_g, M, a->O, a->N, e, f);
+            return launch_gemm<T, false>(ctx, a->x, nullptr, a->ld_x, a->g, nullptr, a->ld_g, M, a->O, a->N, e, f);
+        }
+    }
     // MIXED operands: x, x.x K-major as the forward holds them, g, gv TRANSPOSED (gT, gvT: O x ld_n, K-contiguous) as
     // their producer's epilogue can write them -- the transpose read of the 256-column B tile is the slower of the two
     // (lab: 104 vs 93 us per pass at 4096^3), a transposed g costs its producer one more pair of stores
@@ -178,14 +214,14 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
               : try_kmajor<T, false, true, true>(ctx, a->x, nullptr, a->ld_x, a->g, nullptr, a->ld_g, a->I, a->O, a->N, e, &st)))
         return st;
     if constexpr (sizeof(T) == 2) {                          // ... or, for outputs with few tiles, pair split + split-K on gemm_v3
-        if (dual && a->x && a->x2 && a->g && a->gv && a->I % 4 == 0 && kmajor_dw_v3_split_selected(M, a->O, a->N)) {
+        if (dual && !a->draw_dev && a->x && a->x2 && a->g && a->gv && a->I % 4 == 0 && kmajor_dw_v3_split_selected(M, a->O, a->N)) {
             st = launch_gemm_v3_split<T, EpiDw>(ctx, (const T*)a->x, (const T*)a->x2, a->ld_x, (const T*)a->g, (const T*)a->gv, a->ld_g,
                                                 (int)M, (int)a->O, (int)a->N, e);
             if (st != VBNN_ERR_UNSUPPORTED) return st;
         }
     }
     if constexpr (sizeof(T) == 2) {                          // ... or the pair-split form of the pipelined kernel
-        if (dual && a->x && a->x2 && a->g && a->gv && kmajor_dw_v2_selected(M, a->O, a->N)) {
+        if (dual && !a->draw_dev && a->x && a->x2 && a->g && a->gv && kmajor_dw_v2_selected(M, a->O, a->N)) {
             st = launch_gemm_v2<T, true, EpiDw>(ctx, (const T*)a->x, (const T*)a->x2, a->ld_x, (const T*)a->g, (const T*)a->gv, a->ld_g,
                                                 (int)M, (int)a->O, (int)a->N, e, true);
             if (st != VBNN_ERR_UNSUPPORTED) return st;
@@ -199,7 +235,8 @@ extern "C" int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && a, "null ctx/args");
     VBNN_REQUIRE(a->w && a->x, "w and x are required");
-    VBNN_REQUIRE((a->w2 == nullptr) == (a->x2 == nullptr), "w2 and x2 go together (LRT pair)");
+    VBNN_REQUIRE(!a->x2 || a->w2, "x2 needs w2 (LRT pair)");
+    VBNN_REQUIRE(!a->w2 || a->x2 || dtype == VBNN_F32, "w2 and x2 go together (LRT pair); only the fp32 kernel squares x itself");
     VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
     VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
     VBNN_REQUIRE(a->rows_per_draw >= 0 && a->rows_per_draw < (1ll << 31), "rows_per_draw");
@@ -242,15 +279,17 @@ extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && a, "null ctx/args");
     VBNN_REQUIRE((a->xT && a->gT) || (a->x && a->g) || (a->x && a->gT), "xT and gT (or the K-major x and g, or x with gT) are required");
-    VBNN_REQUIRE((a->x2T != nullptr || a->x2 != nullptr) == (a->gvT != nullptr || a->gv != nullptr), "x.x and gv operands go together (LRT pair)");
+    const bool f32_km = dtype == VBNN_F32 && !a->xT && a->x && a->g;       // fp32 K-major form: x.x may be left to the kernel
+    VBNN_REQUIRE(f32_km || (a->x2T != nullptr || a->x2 != nullptr) == (a->gvT != nullptr || a->gv != nullptr), "x.x and gv operands go together (LRT pair)");
     VBNN_REQUIRE(!a->xT || ((a->x2T == nullptr) == (a->gvT == nullptr)), "x2T and gvT go together (LRT pair)");
-    VBNN_REQUIRE(!a->g || ((a->x2 == nullptr) == (a->gv == nullptr)), "x2 and gv go together (LRT pair)");
+    VBNN_REQUIRE(f32_km || !a->g || ((a->x2 == nullptr) == (a->gv == nullptr)), "x2 and gv go together (LRT pair)");
+    VBNN_REQUIRE(!a->x2 || a->gv || a->gvT, "x2 without gv");
     VBNN_REQUIRE(a->N > 0 && a->I > 0 && a->O > 0, "N, I, O must be positive");
     VBNN_REQUIRE(a->N < (1ll << 31) && a->I < (1ll << 31) && a->O < (1ll << 31), "dimension too large");
-    VBNN_REQUIRE(!((a->x2T || a->x2) && (a->gradSum || a->grad_lv)) || a->lvars, "LRT gradSum/grad_lv need lvars");
+    VBNN_REQUIRE(!((a->x2T || a->x2 || a->gv || a->gvT) && (a->gradSum || a->grad_lv)) || a->lvars, "LRT gradSum/grad_lv need lvars");
     VBNN_REQUIRE(!(a->grad_mu || a->grad_lv) || (a->means && a->lvars && a->stats && a->B > 0 && a->S > 0),
                  "fused total gradients need means, lvars, stats, B, S");
-    VBNN_REQUIRE(a->part >= 0 && a->part <= 2 && (a->part == 0 || a->x2T || a->x2), "part: 0, or 1 / 2 of an LRT pair");
+    VBNN_REQUIRE(a->part >= 0 && a->part <= 2 && (a->part == 0 || a->x2T || a->x2), "part: 0, or 1 / 2 of an LRT pair (with x.x given)");
     if (dtype == VBNN_F32) return acc_grad_t<float>(ctx, a);
     if (dtype == VBNN_BF16) return acc_grad_t<bf16_t>(ctx, a);
     vbnn_set_error("unsupported dtype %d", dtype);

@@ -13,6 +13,19 @@
 // global-load latency: half as many barrier / latency round trips).
 // Operands are "packed": K contiguous, leading dimension padded to VBNN_KPAD = 64 elements with
 // zeros, so the K loop needs no tail handling in either geometry.
+//
+// r03, fp32 only (the launch-bound configurations, BASELINE configs[1]): operand FORMS beyond the packed one, so that the
+// fp32 step needs no packing launch and no transposed copy of anything --
+//   TA / TB   the operand is stored K-MAJOR, element (row, k) at X[k * ld + row] (the untransposed activation, gradient or
+//             weight matrix): a thread's 16-byte chunk is then four ROWS of one k, written to the same LDS image with four
+//             ds_write_b32. K rows past the true K are zero-filled (a K-major operand has no zero padding along K).
+//   SQ        the pair's second operand on one side IS the square of the first (x.x beside x): it is formed in registers
+//             while staging (bit for bit what the packer stored) and never loaded. SQ = 1: B2 = B.B; SQ = 2: A2 = A.A.
+//   K mask    a K-contiguous operand whose leading dimension is shorter than the padded K walk (the raw minibatch, ld = I) is
+//             zero-filled past its row end instead of read.
+//   ones row  (TA) A row `ones_row` is all ones without being stored anywhere: its output row is the column sum of B --
+//             the bias gradient from the parameter-gradient GEMM (vbnn_dw_args.gradBias).
+// The K order of every accumulation chain is unchanged: results are bitwise those of the packed / transposed operands.
 #pragma once
 #include "common.h"
 
@@ -35,10 +48,10 @@ __device__ __forceinline__ f32x4 mfma_step<bf16_t>(const bf16x8& a, const bf16x8
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <typename T, bool DUAL, int WR, int KS, class Epi>
+template <typename T, bool DUAL, int WR, int KS, class Epi, bool TA = false, bool TB = false, int SQ = 0>
 __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const T* __restrict__ A2, int64_t lda,
                                                   const T* __restrict__ B, const T* __restrict__ B2, int64_t ldb,
-                                                  int M, int N, int Kp, Epi epi) {
+                                                  int M, int N, int Kp, int K, int ones_row, Epi epi) {
     constexpr int BT = 32 * WR;                       // block tile rows (M and N)
     constexpr int RB = 64 * KS;                       // bytes of K per row per step
     constexpr int PITCH = RB + 16;                    // + 16 B pad: conflict-free ds_read_b128 down a column
@@ -48,11 +61,17 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
     constexpr int CHUNKS = BT * CPR;                  // 16-byte chunks per operand tile
     constexpr int CPT = CHUNKS / 256;                 // chunks per thread per operand tile
     constexpr int NOP = DUAL ? 4 : 2;
+    constexpr int RC = BT / CE;                       // (K-major) 16-byte row chunks per k row
     static_assert(CHUNKS % 256 == 0, "tile does not divide over 256 threads");
+    static_assert(!(TA || TB || SQ) || sizeof(T) == 4, "K-major / squared operand forms: fp32 only");
+    static_assert(SQ == 0 || DUAL, "SQ derives the pair's second operand");
+    static_assert(RC * KE == CHUNKS, "a K-major tile has as many chunks as a K-contiguous one");
     typedef typename Frag<T>::type frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NOP * BT * PITCH];
+    constexpr bool DB = (WR == 1);                    // double-buffered LDS: see the K walk
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(DB ? 2 : 1) * NOP * BT * PITCH];
 
+    epi.bind_draw();                                  // device-resident draw counter, if the host gave one (vbnn_fwd_args.draw_dev)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -66,21 +85,88 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
     const T* src[4] = {A, B, A2, B2};
     // (a native vector type, not HIP's uint4 struct: an array of the latter is not promoted to registers -- it lived in scratch)
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    // operand `op` (0 A, 1 B, 2 A2, 3 B2) is loaded at all -- not derived from its partner by SQ; and its storage form
+    auto loaded = [](int op) { return !((SQ == 1 && op == 3) || (SQ == 2 && op == 2)); };
+    auto is_t = [](int op) { return (op & 1) == 0 ? TA : TB; };
     u32x4_t stage[PD][NOP][CPT];
-    const T* gptr[NOP][CPT];
-    int lds_off[CPT];
+    const T* gptr[NOP][CPT];                          // a readable 16-byte chunk of the thread's row(s): the row start / k row 0
+    int goff[NOP][CPT];                               // element offset from it to the thread's chunk at K step 0
+    int lds_off[2][CPT];                              // byte offset of the chunk in an operand tile [K-contiguous | K-major]
+    int kofs[2][CPT];                                 // element offset along K of the chunk inside a step [kc * CE | k row]
+    int one_e[CPT];                                   // (TA) which element of the chunk is the ones row, or -1
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
         const int chunk = tid + c * 256;
-        const int row = chunk / CPR, kc = chunk % CPR;
-        lds_off[c] = row * PITCH + kc * 16;
+        lds_off[0][c] = (chunk / CPR) * PITCH + (chunk % CPR) * 16;               // row chunk / CPR, 16-byte chunk chunk % CPR
+        kofs[0][c] = (chunk % CPR) * CE;
+        lds_off[1][c] = ((chunk % RC) * CE) * PITCH + (chunk / RC) * (int)sizeof(T);   // rows 4 rc .. 4 rc + 3, k row chunk / RC
+        kofs[1][c] = chunk / RC;
+        one_e[c] = -1;
 #pragma unroll
         for (int op = 0; op < NOP; ++op) {
             const bool isA = (op & 1) == 0;
-            const int grow = isA ? min(m0 + row, M - 1) : min(n0 + row, N - 1);
-            gptr[op][c] = src[op] + (int64_t)grow * (isA ? lda : ldb) + kc * CE;
+            const int64_t ld = isA ? lda : ldb;
+            const int rows = isA ? M : N, t0 = isA ? m0 : n0;
+            if (is_t(op)) {
+                // four consecutive ROWS of one k. The pitch is a multiple of 4 and so is r0: a chunk either lies inside
+                // the pitch (stored rows, then the operand's zero padding) or wholly past it -- then every row of it is
+                // outside the matrix, the epilogue masks what it feeds, and any readable finite data will do: chunk 0
+                const int r0 = t0 + (chunk % RC) * CE;
+                gptr[op][c] = src[op] + ((int64_t)r0 + CE <= ld ? r0 : 0);
+                goff[op][c] = (chunk / RC) * (int)ld;
+                if (isA && ones_row >= r0 && ones_row < r0 + CE) one_e[c] = ones_row - r0;
+            } else {
+                const int grow = min(t0 + chunk / CPR, rows - 1);
+                gptr[op][c] = src[op] + (int64_t)grow * ld;
+                goff[op][c] = (chunk % CPR) * CE;
+            }
         }
     }
+    // K limit of each side's loads. K-major: the true K (k rows past it do not exist). K-contiguous: the operand's own
+    // zero padding is read up to Kp when the leading dimension holds it (the packed operands: exactly the loads of
+    // before); a shorter row (a raw matrix such as the minibatch itself, ld = K) is zero-filled past its end.
+    const int klim_a = TA ? K : (int)min((int64_t)Kp, lda), klim_b = TB ? K : (int)min((int64_t)Kp, ldb);
+    const int64_t kstr_a = TA ? lda : 1, kstr_b = TB ? ldb : 1;
+    // A chunk's LOAD is unconditional and its result is not touched until it is written to LDS PD steps later (the loads of
+    // PD steps fly together: a load inside `if (valid)`, or a select right behind it, makes hipcc wait for each on the spot).
+    // A chunk past the K limit reads the row's first chunk instead; `fixed` zeroes it -- and plants the ones -- at the LDS write.
+    auto chunk_valid = [&](int op, int c, int kt) -> bool {
+        const bool t = is_t(op);
+        const int k = kt * KE + kofs[t ? 1 : 0][c];
+        const int klim = (op & 1) == 0 ? klim_a : klim_b;
+        return t ? (k < klim) : (k + CE <= klim);
+    };
+    auto load_chunk = [&](int op, int c, int kt) -> u32x4_t {
+        const bool isA = (op & 1) == 0;
+        const int64_t off = chunk_valid(op, c, kt) ? goff[op][c] + (int64_t)(kt * KE) * (isA ? kstr_a : kstr_b) : 0;
+        return *reinterpret_cast<const u32x4_t*>(gptr[op][c] + off);
+    };
+    auto fixed = [&](int op, int c, int kt, u32x4_t v) -> u32x4_t {
+        const bool valid = chunk_valid(op, c, kt);
+        v = valid ? v : u32x4_t{0u, 0u, 0u, 0u};
+        if (TA && (op & 1) == 0 && one_e[c] >= 0) {               // the synthetic row of ones (its square is one as well)
+            const unsigned one = valid ? 0x3f800000u : 0u;
+            v[0] = one_e[c] == 0 ? one : v[0]; v[1] = one_e[c] == 1 ? one : v[1];
+            v[2] = one_e[c] == 2 ? one : v[2]; v[3] = one_e[c] == 3 ? one : v[3];
+        }
+        return v;
+    };
+    // one chunk into its operand tile: K-contiguous = one ds_write_b128; K-major = four ds_write_b32 (rows 4 rc + e, k row kr)
+    auto put = [&](int op, int c, int buf, u32x4_t v) {
+        unsigned char* base = lds + buf * (NOP * BT * PITCH) + op * BT * PITCH;
+        if (is_t(op)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned*>(base + lds_off[1][c] + e * PITCH) = v[e];
+        } else {
+            *reinterpret_cast<u32x4_t*>(base + lds_off[0][c]) = v;
+        }
+    };
+    auto squared = [](u32x4_t v) -> u32x4_t {
+        u32x4_t r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float f = __uint_as_float(v[e]); r[e] = __float_as_uint(f * f); }
+        return r;
+    };
 
     f32x4 acc1[WR][WR], acc2[WR][WR];
 #pragma unroll
@@ -95,37 +181,38 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
         for (int op = 0; op < NOP; ++op)
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                stage[d][op][c] = *reinterpret_cast<const u32x4_t*>(gptr[op][c] + (int64_t)min(d, nk - 1) * KE);
+                if (loaded(op)) stage[d][op][c] = load_chunk(op, c, min(d, nk - 1));
 
     const int a_row = (wm * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
     const int b_row = (wn * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
 
-    // (the K walk is unrolled by PD so that every register set has a compile-time index; same k order as ever)
-    for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+    auto put_step = [&](auto d_c, int kt, int buf) {          // the staged chunks of K step kt (register set d) into LDS buffer `buf`
+        constexpr int d = decltype(d_c)::value;
 #pragma unroll
-      for (int d = 0; d < PD; ++d) {
-        const int kt = kt0 + d;
-        if (kt < nk) {                                // block-uniform (no `break`: the unrolled body must keep constant indices)
+        for (int op = 0; op < NOP; ++op)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                if (loaded(op)) put(op, c, buf, fixed(op, c, kt, stage[d][op][c]));
+                else put(op, c, buf, squared(fixed(op - 2, c, kt, stage[d][op - 2][c])));     // SQ: the pair's second operand is the first one squared
+            }
+    };
+    auto load_step = [&](auto d_c, int kt) {
+        constexpr int d = decltype(d_c)::value;
 #pragma unroll
         for (int op = 0; op < NOP; ++op)
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                *reinterpret_cast<u32x4_t*>(lds + op * BT * PITCH + lds_off[c]) = stage[d][op][c];
-        __syncthreads();
-        if (kt + PD < nk) {
-#pragma unroll
-            for (int op = 0; op < NOP; ++op)
-#pragma unroll
-                for (int c = 0; c < CPT; ++c)
-                    stage[d][op][c] = *reinterpret_cast<const u32x4_t*>(gptr[op][c] + (int64_t)(kt + PD) * KE);
-        }
+                if (loaded(op)) stage[d][op][c] = load_chunk(op, c, kt);
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* l = lds + buf * (NOP * BT * PITCH);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {             // 64 bytes of K per row per sub-step
             frag_t af[WR], bf[WR];
 #pragma unroll
             for (int i = 0; i < WR; ++i) {
-                af[i] = *reinterpret_cast<const frag_t*>(lds + 0 * BT * PITCH + a_row + i * 16 * PITCH + ks * 64);
-                bf[i] = *reinterpret_cast<const frag_t*>(lds + 1 * BT * PITCH + b_row + i * 16 * PITCH + ks * 64);
+                af[i] = *reinterpret_cast<const frag_t*>(l + 0 * BT * PITCH + a_row + i * 16 * PITCH + ks * 64);
+                bf[i] = *reinterpret_cast<const frag_t*>(l + 1 * BT * PITCH + b_row + i * 16 * PITCH + ks * 64);
             }
 #pragma unroll
             for (int i = 0; i < WR; ++i)
@@ -134,8 +221,8 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
             if (DUAL) {
 #pragma unroll
                 for (int i = 0; i < WR; ++i) {
-                    af[i] = *reinterpret_cast<const frag_t*>(lds + 2 * BT * PITCH + a_row + i * 16 * PITCH + ks * 64);
-                    bf[i] = *reinterpret_cast<const frag_t*>(lds + 3 * BT * PITCH + b_row + i * 16 * PITCH + ks * 64);
+                    af[i] = *reinterpret_cast<const frag_t*>(l + 2 * BT * PITCH + a_row + i * 16 * PITCH + ks * 64);
+                    bf[i] = *reinterpret_cast<const frag_t*>(l + 3 * BT * PITCH + b_row + i * 16 * PITCH + ks * 64);
                 }
 #pragma unroll
                 for (int i = 0; i < WR; ++i)
@@ -143,9 +230,44 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
                     for (int j = 0; j < WR; ++j) acc2[i][j] = mfma_step<T>(af[i], bf[j], acc2[i][j]);
             }
         }
+    };
+    // (the K walk is unrolled by PD so that every register set has a compile-time index; same k order as ever)
+    if constexpr (DB) {
+        // Double-buffered LDS (the 32 x 32 tile of the launch-bound sizes: one workgroup per CU, so nothing else hides a
+        // step's LDS write + barrier): step kt + 1 is written into the other buffer while step kt is computed, ONE barrier
+        // per step. The arithmetic and its order are those of the single-buffered loop.
+        static_assert(PD % 2 == 0, "buffer parity = register set parity");
+        put_step(std::integral_constant<int, 0>(), 0, 0);
+        if (PD < nk) load_step(std::integral_constant<int, 0>(), PD);
         __syncthreads();
+        for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+            vbnn_static_for<0, PD>([&](auto D) __attribute__((always_inline)) {
+                constexpr int d = decltype(D)::value, dn = (d + 1) % PD;
+                const int kt = kt0 + d;
+                if (kt < nk) {                        // block-uniform
+                    if (kt + 1 < nk) {
+                        put_step(std::integral_constant<int, dn>(), kt + 1, (d + 1) & 1);
+                        if (kt + 1 + PD < nk) load_step(std::integral_constant<int, dn>(), kt + 1 + PD);
+                    }
+                    compute(d & 1);
+                    __syncthreads();                  // buffer d & 1 is free; buffer (d + 1) & 1 is complete
+                }
+            });
         }
-      }
+    } else {
+        for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+            vbnn_static_for<0, PD>([&](auto D) __attribute__((always_inline)) {
+                constexpr int d = decltype(D)::value;
+                const int kt = kt0 + d;
+                if (kt < nk) {                        // block-uniform (the unrolled body keeps constant register-set indices)
+                    put_step(D, kt, 0);
+                    __syncthreads();
+                    if (kt + PD < nk) load_step(D, kt + PD);
+                    compute(0);
+                    __syncthreads();
+                }
+            });
+        }
     }
 
     const int em = m0 + wm * WR * 16 + (lane >> 4) * 4;
@@ -156,35 +278,72 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
         for (int j = 0; j < WR; ++j) epi(em + i * 16, en + j * 16, acc1[i][j], acc2[i][j]);
 }
 
-template <typename T, bool DUAL, class Epi>
-static int launch_gemm_v1(hipStream_t stream, const T* A, const T* A2, int64_t lda, const T* B, const T* B2,
-                          int64_t ldb, int M, int N, int K, const Epi& epi) {
+// form of a launch's operands beyond the packed default (fp32 only): see the head of this file
+struct V1Form {
+    bool ta = false, tb = false;      // A / B side stored K-major
+    int sq = 0;                       // 1: B2 = B.B, 2: A2 = A.A (never loaded)
+    int ones_row = -1;                // (ta) A row that is all ones
+};
+
+template <typename T, bool DUAL, class Epi, bool TA, bool TB, int SQ>
+static int launch_gemm_v1_form(hipStream_t stream, const T* A, const T* A2, int64_t lda, const T* B, const T* B2,
+                               int64_t ldb, int M, int N, int K, const Epi& epi, int ones_row) {
+    // a K-contiguous operand holds the padded K walk (packed: zero fill) or is exactly a raw matrix of row length >= K,
+    // whose columns [K, ld) -- if any -- must be finite (they meet the other side's zero padding)
+    auto need = [&](int Kp) -> bool {
+        const bool a_ok = TA || lda >= Kp || lda >= K, b_ok = TB || ldb >= Kp || ldb >= K;
+        if (!a_ok || !b_ok) vbnn_set_error("leading dimension too small: lda=%lld ldb=%lld K=%d", (long long)lda, (long long)ldb, K);
+        return a_ok && b_ok;
+    };
+    if ((TA && (lda % 4 != 0 || lda < M - (ones_row >= 0 ? 1 : 0))) || (TB && (ldb % 4 != 0 || ldb < N))) {
+        vbnn_set_error("K-major fp32 operands need a row pitch that is a multiple of 4 and holds the rows: lda=%lld ldb=%lld",
+                       (long long)lda, (long long)ldb);
+        return VBNN_ERR_INVALID;
+    }
+    if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15u) != 0 || (!TA && lda % (16 / (int)sizeof(T)) != 0) ||
+        (!TB && ldb % (16 / (int)sizeof(T)) != 0)) {
+        vbnn_set_error("gemm_v1 operands must be 16-byte aligned with 16-byte row pitches");
+        return VBNN_ERR_INVALID;
+    }
     const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (blocks128 >= 128) {
         const int KE = 64 / (int)sizeof(T);
         const int Kp = (K + KE - 1) / KE * KE;
-        if (lda < Kp || ldb < Kp) {
-            vbnn_set_error("packed leading dimension too small: lda=%lld ldb=%lld need >= %d", (long long)lda, (long long)ldb, Kp);
-            return VBNN_ERR_INVALID;
-        }
+        if (!need(Kp)) return VBNN_ERR_INVALID;
         dim3 grid((M + 127) / 128, (N + 127) / 128);
-        hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 4, 1, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+        hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 4, 1, Epi, TA, TB, SQ>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, K, ones_row, epi);
     } else {
         constexpr int KS = 2;                                     // 128 B of K per row per step: 32 f32 / 64 bf16
         constexpr int KE2 = 128 / (int)sizeof(T);                 // (4 x 64 x 144 B of LDS for the dual tile)
         const int Kp = (K + KE2 - 1) / KE2 * KE2;
-        if (lda < Kp || ldb < Kp) {
-            vbnn_set_error("packed leading dimension too small: lda=%lld ldb=%lld need >= %d", (long long)lda, (long long)ldb, Kp);
-            return VBNN_ERR_INVALID;
-        }
+        if (!need(Kp)) return VBNN_ERR_INVALID;
         const long blocks64 = (long)((M + 63) / 64) * ((N + 63) / 64);
         if (blocks64 >= 96) {
             dim3 grid((M + 63) / 64, (N + 63) / 64);
-            hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 2, KS, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+            hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 2, KS, Epi, TA, TB, SQ>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, K, ones_row, epi);
         } else {        // latency-bound sizes (the 256 x 400 outputs of the small MLP): 32 x 32 tiles, 4x the blocks
             dim3 grid((M + 31) / 32, (N + 31) / 32);
-            hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 1, KS, Epi>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, epi);
+            hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 1, KS, Epi, TA, TB, SQ>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, K, ones_row, epi);
         }
     }
     return vbnn_check_launch("gemm_nt_v1");
+}
+
+template <typename T, bool DUAL, class Epi>
+static int launch_gemm_v1(hipStream_t stream, const T* A, const T* A2, int64_t lda, const T* B, const T* B2,
+                          int64_t ldb, int M, int N, int K, const Epi& epi, const V1Form& f = V1Form()) {
+    if constexpr (sizeof(T) == 4) {
+        // the forms the fp32 step uses: forward (B2 = B.B), gradInput (A K-major), accGradParameters (both K-major, A2 = A.A)
+        if constexpr (DUAL) {
+            if (!f.ta && !f.tb && f.sq == 1) return launch_gemm_v1_form<T, true, Epi, false, false, 1>(stream, A, A2, lda, B, B2, ldb, M, N, K, epi, -1);
+            if (f.ta && f.tb && f.sq == 2) return launch_gemm_v1_form<T, true, Epi, true, true, 2>(stream, A, A2, lda, B, B2, ldb, M, N, K, epi, f.ones_row);
+        }
+        if (f.ta && !f.tb && f.sq == 0) return launch_gemm_v1_form<T, DUAL, Epi, true, false, 0>(stream, A, A2, lda, B, B2, ldb, M, N, K, epi, -1);
+        if (f.ta && f.tb && f.sq == 0) return launch_gemm_v1_form<T, DUAL, Epi, true, true, 0>(stream, A, A2, lda, B, B2, ldb, M, N, K, epi, f.ones_row);
+    }
+    if (f.ta || f.tb || f.sq) {
+        vbnn_set_error("operand form not instantiated (K-major %d / %d, squares %d): fp32 only", (int)f.ta, (int)f.tb, f.sq);
+        return VBNN_ERR_UNSUPPORTED;
+    }
+    return launch_gemm_v1_form<T, DUAL, Epi, false, false, 0>(stream, A, A2, lda, B, B2, ldb, M, N, K, epi, -1);
 }

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * HEAD_FW) void k_head_forward(const T* __restri
                                                       const float* __restrict__ bias, const int32_t* __restrict__ target, int64_t N,
                                                       int64_t Hp /* H padded to the K step */, int C, float inv_n, float* out,
                                                       float* g_logits, float* logits, double* loss_sum, int32_t* correct,
-                                                      int accumulate, double* part_loss, int32_t* part_corr, unsigned* counter) {
+                                                      int accumulate, double* part_loss, int32_t* part_corr, unsigned* counter, int64_t rpd) {
     constexpr int KE = 64 / (int)sizeof(T);      // K elements per MFMA step (16 bytes per lane x 4 lane groups)
     constexpr int CE = 16 / (int)sizeof(T);
     typedef typename Frag<T>::type frag_t;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * HEAD_FW) void k_head_forward(const T* __restri
         se += __shfl_xor(se, 16, 64);
         se += __shfl_xor(se, 32, 64);
         const float lse = mx + logf(se);
-        const int t = row_ok ? min(max(target[n], 0), C - 1) : 0;
+        const int t = row_ok ? min(max(target[rpd > 0 ? n % rpd : n], 0), C - 1) : 0;     // stacked draws share the minibatch's targets
         double loss_acc = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -236,7 +236,9 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
                                                        T* g_prev, T* gv_prev, int64_t ld_gp, T* gT_prev, T* gvT_prev, int64_t ld_gpT,
                                                        int rows_per_chunk, float* __restrict__ partial_w /* [R][C][H] */,
                                                        float* __restrict__ partial_b /* [R][C] */,
-                                                       float* __restrict__ partial_bp /* [R][H] */) {
+                                                       float* __restrict__ partial_bp /* [R][H] */,
+                                                       unsigned* fin_tickets /* NULL: a finish kernel follows */, int fin_accumulate,
+                                                       float* fin_gw, float* fin_gb, float* fin_gbp) {
     constexpr int CE = 16 / (int)sizeof(T);      // K elements per lane of an MFMA fragment
     constexpr int KE = 4 * CE;                   // rows contracted per mfma_step
     constexpr int TP = sizeof(T) == 2 ? 66 : 65;  // tile pitch, 33 / 65 dwords: rows 8 apart fall on different banks
@@ -417,13 +419,15 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
             for (int k = 0; k < 4; ++k) gcur[k] = gnxt[k];
         }
     }
+    // (with an in-launch finish the partials are the last arriver's payload: write-through stores, vbnn_last_arriver)
+    auto put = [&](float* p, float v) { if (fin_tickets) vbnn_store_wt(p, v); else *p = v; };
     if (partial_w) {                                         // lane (q, c16): classes 4q .. 4q+3 of hidden unit 16 w + c16
         const int64_t i = c0 + 16 * wave + c16;
         if (i < H) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * q + j < C) partial_w[((int64_t)blockIdx.y * C + 4 * q + j) * H + i] = accw[j];
-            if (partial_bp && q == 0) partial_bp[(int64_t)blockIdx.y * H + i] = accp[0];
+                if (4 * q + j < C) put(&partial_w[((int64_t)blockIdx.y * C + 4 * q + j) * H + i], accw[j]);
+            if (partial_bp && q == 0) put(&partial_bp[(int64_t)blockIdx.y * H + i], accp[0]);
         }
     }
     if (partial_b && blockIdx.x == 0) {
@@ -435,8 +439,33 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
             float tot = 0.f;
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) tot += red[rg * 16 + tid];
-            partial_b[(int64_t)blockIdx.y * C + tid] = tot;
+            put(&partial_b[(int64_t)blockIdx.y * C + tid], tot);
         }
+    }
+    // ---- in-launch finish (few workgroups: the launch-bound configurations, where a separate finish kernel is ~4.6 us of
+    // an 85 us step): the LAST of the R row-chunk workgroups of this column tile to arrive adds the R partials of the
+    // tile's outputs in chunk order -- the order and the arithmetic of k_head_backward_finish, so the same bits.
+    if (!fin_tickets) return;
+    __shared__ int fin_last;
+    if (!vbnn_last_arriver(fin_tickets + blockIdx.x, gridDim.y, &fin_last)) return;
+    const int R = (int)gridDim.y;
+    const int64_t nw = (int64_t)C * H;
+    for (int k = tid; k < C * 64 + 64; k += 256) {           // the tile's C x 64 gradWeight entries, then its 64 gradBias_prev entries
+        const bool is_w = k < C * 64;
+        const int64_t i = c0 + (is_w ? k & 63 : k - C * 64);
+        if (i >= H) continue;
+        float* dst = is_w ? (fin_gw ? fin_gw + (int64_t)(k >> 6) * H + i : nullptr) : (fin_gbp ? fin_gbp + i : nullptr);
+        if (!dst) continue;
+        const float* src = is_w ? partial_w + (int64_t)(k >> 6) * H + i : partial_bp + i;
+        const int64_t stride = is_w ? nw : H;
+        float tot = 0.f;
+        for (int r = 0; r < R; ++r) tot += vbnn_load_wt(src + (int64_t)r * stride);
+        *dst = (fin_accumulate ? *dst : 0.f) + tot;
+    }
+    if (blockIdx.x == 0 && tid < C && fin_gb) {
+        float tot = 0.f;
+        for (int r = 0; r < R; ++r) tot += vbnn_load_wt(partial_b + r * C + tid);
+        fin_gb[tid] = (fin_accumulate ? fin_gb[tid] : 0.f) + tot;
     }
 }
 
@@ -475,8 +504,9 @@ __global__ __launch_bounds__(256) void k_head_backward_finish(const float* __res
 extern "C" int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                                  const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
                                  float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
-                                 int32_t* correct_dev) {
+                                 int32_t* correct_dev, int64_t rows_per_draw) {
     VBNN_API_BEGIN
+    VBNN_REQUIRE(rows_per_draw >= 0, "rows_per_draw");
     VBNN_REQUIRE(ctx && h && w3 && target && g_logits, "null argument");
     VBNN_REQUIRE(N > 0 && H > 0 && C > 0 && C <= HEAD_CMAX, "shape (C <= 16)");
     VBNN_REQUIRE(ld_h % VBNN_KPAD == 0 && ld_w % VBNN_KPAD == 0 && ld_h >= H && ld_w >= H, "h and w3 must be packed operands");
@@ -490,17 +520,18 @@ extern "C" int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_
         const int64_t Hp = (H + 15) / 16 * 16;
         hipLaunchKernelGGL(k_head_forward<float>, dim3(nb), dim3(64 * HEAD_FW), 0, ctx->stream, (const float*)h, ld_h, (const float*)w3,
                            ld_w, bias, target, N, Hp, (int)C, inv_n, out, g_logits, logits, loss_sum_dev, correct_dev, accumulate, part_loss,
-                           part_corr, ticket);
+                           part_corr, ticket, rows_per_draw);
     } else if (dtype == VBNN_BF16) {
         const int64_t Hp = (H + 31) / 32 * 32;
         hipLaunchKernelGGL(k_head_forward<bf16_t>, dim3(nb), dim3(64 * HEAD_FW), 0, ctx->stream, (const bf16_t*)h, ld_h,
                            (const bf16_t*)w3, ld_w, bias, target, N, Hp, (int)C, inv_n, out, g_logits, logits, loss_sum_dev,
-                           correct_dev, accumulate, part_loss, part_corr, ticket);
+                           correct_dev, accumulate, part_loss, part_corr, ticket, rows_per_draw);
     } else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
     return vbnn_check_launch("k_head_forward");
     VBNN_API_END
 }
 
+static int g_head_inline_finish = 1;      // A/B: VBNN_HEAD_INLINE_FINISH=0 in the environment keeps the separate finish kernel
 template <typename T>
 static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3, int64_t ld_w, const float* g_logits, int64_t N,
                            int64_t H, int64_t C, int accumulate, float* gradWeight, float* gradBias, float* gradBias_prev,
@@ -510,6 +541,8 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
     const T* r_prev_t = r_prev_packed ? (const T*)r_prev_any : nullptr;
     const bool sums = gradWeight || gradBias || gradBias_prev;
     if (!sums && !g_prev && !gT_prev) return VBNN_OK;
+    static const bool env_read = [] { const char* e = getenv("VBNN_HEAD_INLINE_FINISH"); if (e && e[0] == '0') g_head_inline_finish = 0; return true; }();
+    (void)env_read;
     // row chunks: about 1024 blocks (several per CU, so one's loads sit beside another's LDS work), bounded by the
     // reduction scratch: per chunk C x H + C + H partial sums
     const int64_t tiles_c = (H + 63) / 64, tiles_r = (N + 63) / 64;
@@ -536,23 +569,28 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
     float* pbp = gradBias_prev ? partial_bp : nullptr;
     const bool full = vec && (H % 64 == 0) && (N % 64 == 0) && N * ld_h < (1ll << 31) && N * ld_gp < (1ll << 31) &&
                       H * ld_gpT < (1ll << 31) && (!r_prev_any || N * ld_r_prev < (1ll << 31));
+    // few workgroups (one partial wave of the chip): the row-chunk partials are finished INSIDE the launch by each column
+    // tile's last arriver (same order, same bits as the finish kernel); otherwise a finish kernel follows (a last
+    // arriver's serial tail behind thousands of streaming workgroups costs more than the launch it saves, r01)
+    const bool inline_fin = sums && tiles_c * R <= vbnn_cu_count() && tiles_c <= VBNN_CNT_TILES_MAX && g_head_inline_finish;
+    unsigned* ft = inline_fin ? ctx->counters + VBNN_CNT_TILES : nullptr;
     if (full && C <= 12 && !r_prev)
         hipLaunchKernelGGL((k_head_backward<T, true, true, 12>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
                            relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
-                           pw, pb, pbp);
+                           pw, pb, pbp, ft, accumulate, gradWeight, gradBias, gradBias_prev);
     else if (full)
         hipLaunchKernelGGL((k_head_backward<T, true, true>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
                            relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
-                           pw, pb, pbp);
+                           pw, pb, pbp, ft, accumulate, gradWeight, gradBias, gradBias_prev);
     else if (vec)
         hipLaunchKernelGGL((k_head_backward<T, true, false>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
                            relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
-                           pw, pb, pbp);
+                           pw, pb, pbp, ft, accumulate, gradWeight, gradBias, gradBias_prev);
     else
         hipLaunchKernelGGL((k_head_backward<T, false, false>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
                            relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
-                           pw, pb, pbp);
-    if (sums) {
+                           pw, pb, pbp, ft, accumulate, gradWeight, gradBias, gradBias_prev);
+    if (sums && !inline_fin) {
         const int64_t outs = C * H + (gradBias_prev ? H : 0);
         hipLaunchKernelGGL(k_head_backward_finish, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, ctx->stream, partial_w,
                            partial_b, partial_bp, (int)R, H, (int)C, accumulate, gradWeight, gradBias, gradBias_prev);

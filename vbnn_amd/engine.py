@@ -24,6 +24,37 @@ class _VB:
     pass
 
 
+class _View:
+    """A caller's 2-D fp32 tensor handed to a GEMM as it lies (ptr, row pitch): the raw minibatch of the fp32 path."""
+
+    def __init__(self, t):
+        self.t, self.ld = t, t.stride(0)
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.t.data_ptr())
+
+
+class _StepGraph:
+    """A captured step (FusedMLP.capture_step): launch() replays it on the engine's stream."""
+
+    def __init__(self, eng, handle, draws):
+        self.eng, self.h, self.draws = eng, handle, draws
+        k, n = C.c_int(), C.c_int()
+        L.check(L.lib().vbnn_graph_info(self.h, C.byref(k), C.byref(n)))
+        self.kernel_nodes, self.nodes = k.value, n.value
+
+    def launch(self):
+        L.check(L.lib().vbnn_graph_launch(self.h))
+        self.eng.draw += self.draws                      # the host's mirror of the device counter
+        self.eng._first = False
+
+    def close(self):
+        if self.h:
+            L.check(L.lib().vbnn_graph_destroy(self.h))
+            self.h = None
+
+
 class FusedMLP:
     def __init__(self, opt, device=None, world_size=1, rank=0, process_group=None, force_reduce=False, stream=None):
         """stream: a torch.cuda.Stream for this engine's launches (a library context of its own, hence its own reduction
@@ -125,6 +156,12 @@ class FusedMLP:
         self._corr = torch.zeros(1, dtype=torch.int32, device=dev)
         self._lc = torch.zeros(1, dtype=torch.float64, device=dev)
         self.draw = 0
+        # opt.device_draw: the draw counter lives in device memory (vbnn_fwd_args.draw_dev), sample() is a device-side
+        # increment (vbnn_sample) -- what makes a step CAPTURABLE (capture_step): every replay of the graph advances the
+        # counter and draws its own noise. `self.draw` stays the host's mirror of the count.
+        self.device_draw = bool(opt.get("device_draw", False))
+        assert not self.device_draw or self.mode == "lrt", "device_draw: LRT (weight noise draws in vbnn_wn_sample, a host-addressed launch)"
+        self._draw_dev = torch.zeros(1, dtype=torch.int32, device=dev) if self.device_draw else None
         self._map = False
         self._first = True
         self._draws_run = 0
@@ -132,6 +169,7 @@ class FusedMLP:
         self._exchange_done = False
         self._N = None
         self._rpd = 0            # > 0 inside run_draws: rows per Monte-Carlo draw of the stacked minibatch
+        self._x_in = None        # fp32: the raw minibatch of the current run, read in place by layer 1's GEMMs
         self._draws = None
         self.init_parameters()
 
@@ -156,10 +194,20 @@ class FusedMLP:
         # mu, sigma^2 as stored, the parameter sweep writes no transposed shadows. The library decides by shape; the
         # fused configuration that takes that kernel is bf16, LRT, total gradients from the epilogue, one draw.
         km_ok = (self.opt.get("dtype", "f32") == "bf16") and not self.opt.get("keep_transposes", False)
+        # fp32 (the general kernel, gemm_v1.h): every GEMM takes its operands as the producer left them -- the minibatch raw,
+        # x.x formed in registers, x / g / mu / sigma^2 K-major, the bias gradient from a synthetic row of ones -- so the fp32
+        # step has no packing launch, no squared and no transposed copy of anything. (Not with an exchange: the two-launch
+        # accGradParameters of a data-parallel run wants x.x as an operand.)
+        self.f32_direct = (self.dtype == "f32" and self.mode == "lrt" and not self.reduce and
+                           not self.opt.get("keep_transposes", False))
         need_prepare = False
         for li, v in enumerate(self.vb):
             last_fused = (v is self.vb[-1]) and self.n_classes <= 16 and self.criterion == "nll"
             v.bias_from_dw = (v.I % 256 != 0) and not last_fused
+            if self.f32_direct:
+                v.dw_km, v.x_pad256, v.early_ok, v.dx_km = True, False, False, li > 0
+                v.use_muT = False
+                continue
             # (the K-major launches take the epilogue's fast protocol, which reads mu / sigma^2 from the operand shadows
             # only: vbnn_dw_args.mu_s / var_s are REQUIRED for them, include/vbnn_hip.h)
             km = lib.vbnn_kmajor_supported_dw(v.I, v.O, N, 1 if v.bias_from_dw else 0) if (
@@ -181,6 +229,14 @@ class FusedMLP:
             # K-major the row of ones is COLUMN I of x (in the K padding of the forward operand, where the packed
             # weights are zero, so the forward does not see it).
             extra = 1 if v.bias_from_dw else 0
+            if self.f32_direct:
+                v.x_s = _Packed(N, v.I, tdt, dev)        # (layer 1: used only when the raw minibatch cannot be read in place)
+                v.x2_s = None
+                v.xT_s = v.x2T_s = v.gT_s = v.gvT_s = None
+                v.mixed_g = False
+                v.g_s, v.gv_s = _Packed(N, v.O, tdt, dev), _Packed(N, v.O, tdt, dev)
+                v.r = torch.zeros(N, v.O, dtype=tdt, device=dev)
+                continue
             xcols = v.I + (extra if v.dw_km else 0)
             if v.x_pad256:
                 xcols = (xcols + 255) // 256 * 256
@@ -300,9 +356,11 @@ class FusedMLP:
         return err / draws, acc / draws
 
     # ---- mlp.lua:69-74
-    def sample(self):
-        self.draw += 1
+    def sample(self, by=1):
+        self.draw += by
         self._map = False
+        if self.device_draw:
+            L.check(L.lib().vbnn_sample(self.ctx.h, _p(self._draw_dev), by))
         if self.mode == "wn":
             lib = L.lib()
             for v in self.vb:
@@ -354,12 +412,15 @@ class FusedMLP:
         v, lrt = self.vb[li], self._lrt()
         last = li == len(self.vb) - 1
         nxt = None if last else self.vb[li + 1]
-        return L.FwdArgs(w=v.mu_s.ptr, w2=v.var_s.ptr if lrt else None, x=v.x_s.ptr, x2=v.x2_s.ptr if lrt else None,
-                         ld_w=v.mu_s.ld, ld_x=v.x_s.ld, N=N, I=v.I, O=v.O, bias=_p(v.bias), seed=self.seed,
-                         layer=v.layer_id, draw=self.draw, row0=row0, y=None, ld_y=0,
+        xin = self._x_in if (li == 0 and self._x_in is not None) else v.x_s       # the raw minibatch, read in place (fp32)
+        sq = lrt and not self.f32_direct                                          # squares as operands (else formed by the kernel)
+        return L.FwdArgs(w=v.mu_s.ptr, w2=v.var_s.ptr if lrt else None, x=xin.ptr, x2=v.x2_s.ptr if sq else None,
+                         ld_w=v.mu_s.ld, ld_x=xin.ld, N=N, I=v.I, O=v.O, bias=_p(v.bias), seed=self.seed,
+                         layer=v.layer_id, draw=0 if self.device_draw else self.draw,
+                         draw_dev=_p(self._draw_dev) if self.device_draw else None, row0=row0, y=None, ld_y=0,
                          r=_p(v.r) if lrt else None, ld_r=v.O, r_packed=1, relu=1,
                          h=self.h_s.ptr if last else nxt.x_s.ptr,
-                         h2=None if (last or not lrt) else nxt.x2_s.ptr,
+                         h2=None if (last or not sq) else nxt.x2_s.ptr,
                          ld_h=self.h_s.ld if last else nxt.x_s.ld,
                          hT=(None if (self.n_classes <= 16 and self.criterion == "nll") else self.hT_s.ptr) if last else (nxt.xT_s.ptr if nxt.xT_s else None),
                          h2T=None if (last or not lrt or not nxt.x2T_s) else nxt.x2T_s.ptr,
@@ -369,12 +430,13 @@ class FusedMLP:
         v, lrt = self.vb[li], self._lrt()
         has_t = v.xT_s is not None
         has_gt = v.gT_s is not None
+        xin = self._x_in if (li == 0 and self._x_in is not None) else v.x_s
         d = L.DwArgs(xT=v.xT_s.ptr if has_t else None, x2T=v.x2T_s.ptr if (lrt and has_t) else None,
                      gT=v.gT_s.ptr if has_gt else None, gvT=v.gvT_s.ptr if (lrt and has_gt) else None,
                      ld_n=v.gT_s.ld if has_gt else 0, N=N, I=v.I, O=v.O, scale=1.0,
                      accumulate=accumulate, seed=self.seed, layer=v.layer_id, draw=self.draw, lvars=_p(v.lvars),
-                     x=v.x_s.ptr, x2=v.x2_s.ptr if lrt else None, g=v.g_s.ptr, gv=v.gv_s.ptr if lrt else None,
-                     ld_x=v.x_s.ld, ld_g=v.g_s.ld)
+                     x=xin.ptr, x2=v.x2_s.ptr if (lrt and v.x2_s is not None) else None, g=v.g_s.ptr, gv=v.gv_s.ptr if lrt else None,
+                     ld_x=xin.ld, ld_g=v.g_s.ld)
         if self.fuse_kl:
             d.gradWeight, d.gradSum = None, None
             d.grad_mu, d.grad_lv = _p(v.gradWeight), _p(v.gradSum)
@@ -419,8 +481,11 @@ class FusedMLP:
             self._exchange_now = bool(last_draw)
             self._exchange_done = self._exchange_now
         x = inputs.reshape(inputs.shape[0], -1)                         # nn.Reshape (mlp.lua:12)
-        N = x.shape[0]
+        # stacked draws (run_draws): the operands have S x rows_per_draw rows, the input and the targets one minibatch's --
+        # the packer and the head address row n % rows_per_draw (no S-fold copy of the input is ever made)
+        N = x.shape[0] * (self._draws if self._rpd else 1)
         assert x.shape[1] == self.sizes[0] and x.dtype == torch.float32 and x.is_cuda
+        assert not self._rpd or x.shape[0] == self._rpd
         self._alloc_batch(N)
         if row0 is None:
             row0 = self.rank * (self._rpd or N)
@@ -428,9 +493,14 @@ class FusedMLP:
         accumulate = 0 if self._first else 1
         inv_n = partition.scales(self._rpd or N, self.world)["inv_n"]       # per DRAW: stacked draws sum their criteria
         v0 = self.vb[0]
-        L.check(lib.vbnn_pack_input(ctx, code, _p(x), x.stride(0), N, v0.I, v0.x_s.ptr, v0.x2_s.ptr if lrt else None,
-                                    v0.x_s.ld, v0.xT_s.ptr if v0.xT_s else None,
-                                    v0.x2T_s.ptr if (lrt and v0.x2T_s) else None, v0.xT_s.ld if v0.xT_s else 0))
+        self._x_in = None
+        if self.f32_direct and not self._rpd and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+            self._x_in = _View(x)                        # the GEMMs read the minibatch where it lies: no packing launch
+        else:
+            L.check(lib.vbnn_pack_input(ctx, code, _p(x), x.stride(0), N, v0.I, v0.x_s.ptr,
+                                        v0.x2_s.ptr if (lrt and v0.x2_s is not None) else None,
+                                        v0.x_s.ld, v0.xT_s.ptr if v0.xT_s else None,
+                                        v0.x2T_s.ptr if (lrt and v0.x2T_s) else None, v0.xT_s.ld if v0.xT_s else 0, self._rpd))
         nl = len(self.vb)
         # ---------------- forward
         for li in range(nl):
@@ -444,7 +514,7 @@ class FusedMLP:
             # ---------------- fused classifier head (mlp.lua:29-32): streaming kernels, no 10-wide MFMA tiles
             L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
                                           _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
-                                          _p(self.g_logits), accumulate, _p(self._acc), _p(self._corr)))
+                                          _p(self.g_logits), accumulate, _p(self._acc), _p(self._corr), self._rpd))
             if not backward:
                 self._first = False
                 return
@@ -455,6 +525,8 @@ class FusedMLP:
                                            vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr if vl.gT_s else None,
                                            vl.gvT_s.ptr if (lrt and vl.gvT_s) else None, vl.gT_s.ld if vl.gT_s else 0))
         else:
+            if self._rpd:                                 # (the generic criteria take one target per operand row)
+                targets = targets.repeat(self._draws) if targets.dim() == 1 else targets.repeat(self._draws, 1)
             self._generic_head(N, targets, inv_n, accumulate, backward)
             if not backward:
                 self._first = False
@@ -535,15 +607,38 @@ class FusedMLP:
         assert self.mode == "lrt" and not self._map and self._first, "run_draws: LRT, right after resetGradients()"
         x = inputs.reshape(inputs.shape[0], -1)
         N = x.shape[0]
-        xs = x.repeat(S, 1)
-        ts = targets.repeat(S) if targets.dim() == 1 else targets.repeat(S, 1)
-        self.draw += 1                                   # the first draw's counter; row n uses draw + n // N
+        self.sample()                                    # the first draw's counter; row n uses draw + n // N
         self._rpd, self._draws = N, S
         try:
-            self.run(xs, ts)
+            self.run(x, targets)
         finally:
             self._rpd, self._draws = 0, None
-        self.draw += S - 1
+        if S > 1:
+            self.sample(S - 1)
+
+    # ---- one step as ONE graph launch (include/vbnn_hip.h: vbnn_capture_*). `issue` is a callable that issues the step's
+    # calls on this engine (resetGradients / sample / run or run_draws / finish) exactly as it would to run them; between
+    # begin and end they are recorded instead. Needs opt.device_draw (the noise counter must not be a launch argument), a
+    # stream of the engine's own (FusedMLP(..., stream=...): the NULL stream cannot be captured) and one un-captured call
+    # of `issue` before (allocations and first-launch configuration cannot be recorded). The inputs are read from the
+    # same device buffers at every replay: copy the next minibatch into them.
+    def capture_step(self, issue):
+        assert self.device_draw, "capture_step needs opt.device_draw = True"
+        assert self.ctx.torch_stream is not None, "capture_step needs an engine stream: FusedMLP(opt, stream=torch.cuda.Stream())"
+        assert not self.reduce, "capture_step: single-GPU steps (the exchange runs on the communicator's own stream)"
+        lib = L.lib()
+        draws0 = self.draw
+        with torch.cuda.stream(self.ctx.torch_stream):
+            L.check(lib.vbnn_capture_begin(self.ctx.h))
+            h = C.c_void_p()
+            try:
+                issue()
+            finally:
+                st = lib.vbnn_capture_end(self.ctx.h, C.byref(h))
+            L.check(st)
+        draws = self.draw - draws0
+        self.draw = draws0                               # nothing ran: the recorded vbnn_sample nodes advance the counter at replay
+        return _StepGraph(self, h, draws)
 
     # ---- data-parallel exchange: sum all-reduce of one layer's gradient bucket over RCCL/xGMI, issued
     # right after that layer's accGradParameters so it overlaps the rest of backward. The criterion
