@@ -201,6 +201,8 @@ def main():
                     "then the accGradParameters (auto: when the layers differ in size and there is no exchange), or layer by layer")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], help="the step as ONE hipGraph launch (vbnn_capture_*, device-resident "
                     "draw counter); auto = off (measured slower than stream launches on this ROCm)")
+    ap.add_argument("--cu-budget", type=int, default=0, help="data-parallel A/B: the engine's launches on a CU-masked stream of that many "
+                    "compute units (vbnn_ctx_create_cu_budget), the rest left to RCCL's channels; 0 = no mask")
     ap.add_argument("--exchange-dtype", default="f32", choices=["f32", "bf16"], help="data-parallel exchange payload: fp32 (default, the "
                     "metric) or the optional bf16 copy (half the bytes, a DIFFERENT gradient: reported as an option, config.exchange_dtype)")
     args = ap.parse_args()
@@ -263,12 +265,16 @@ def main():
     # (auto = off everywhere: on this ROCm a captured step is bitwise the launched one but ~1.4 us per kernel node SLOWER than
     # the same kernels launched back to back on a stream -- 95 against 82 us for the small configuration)
     use_graph = args.mode == "lrt" and not use_dist and not args.overlap and args.graph == "on"
+    if args.cu_budget > 0:
+        opt["cu_budget"] = args.cu_budget
     stream = None
     if use_graph:                                         # a stream of the engine's own: the NULL stream cannot be captured
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)                     # (everything of this process from here on: fills, events, the step)
         opt["device_draw"] = True
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist, stream=stream)
+    if args.cu_budget > 0:
+        torch.cuda.set_stream(eng.ctx.torch_stream)      # the masked stream is the process's stream from here on
     for kv in filter(None, args.debug_set.split(",")):
         k, v = kv.split("=")
         L.check(L.lib().vbnn_debug_set(int(k), int(v)))
@@ -401,6 +407,19 @@ def main():
         dist.all_gather_object(ident, (rank, local_rank, device_identity(torch, local_rank), os.getpid()))
         comm = {"backend": eng.comm_backend(), "payload": eng.exchange_dtype, "ranks_seen": [list(i) for i in ident],
                 "distinct_devices": len({i[2] for i in ident}), "allreduce": eng.time_buckets(5)}
+        ex = eng.exchange()
+        if hasattr(ex, "gather_u64"):
+            # the same census over the EXCHANGE's own communicator (vbnn_comm_allgather_u64: RCCL's all-gather on the stream
+            # the gradient buckets travel on), so the line proves that N ranks on N devices took part in THAT communicator --
+            # not just in torch.distributed's process group. One word per rank: rank | local rank | pid | hash of the device uuid.
+            import zlib
+            dev_hash = zlib.crc32(device_identity(torch, local_rank).encode()) & 0xFFFF
+            word = (rank & 0xFF) << 56 | (local_rank & 0xFF) << 48 | (os.getpid() & 0xFFFFFFFF) << 16 | dev_hash
+            words = ex.gather_u64(word)
+            seen = [{"rank": w >> 56 & 0xFF, "local_rank": w >> 48 & 0xFF, "pid": w >> 16 & 0xFFFFFFFF, "device_uuid_crc16": w & 0xFFFF} for w in words]
+            comm["rccl_ranks_seen"] = seen
+            comm["rccl_distinct_devices"] = len({(r["device_uuid_crc16"], r["local_rank"]) for r in seen})
+            comm["rccl_census_matches_process_group"] = sorted((r["rank"], r["pid"] & 0xFFFFFFFF) for r in seen) == sorted((i[0], i[3] & 0xFFFFFFFF) for i in ident)
 
     if rank == 0:
         sizes = [cfg["input_size"]] + cfg["hidden"]
@@ -429,6 +448,7 @@ def main():
                        "probed_block_ms": round(probed_ms, 4),
                        "backward_order": ("every updateGradInput, then the accGradParameters from the first layer up" if eng.dx_first
                                           and not eng.reduce else "layer by layer, accGradParameters (+ its all-reduce) first"),
+                       "cu_budget": (getattr(eng.ctx, "cu_budget", None) if args.cu_budget > 0 else None),
                        "launch": (f"ONE hipGraph launch per step: {graph.kernel_nodes} kernel nodes captured once (vbnn_capture_*), the draw "
                                   "counter in device memory (vbnn_sample is a node), bitwise the launch-by-launch step" if graph else
                                   "one stream launch per kernel")},

@@ -83,6 +83,15 @@ int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row);
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
  * (which is also what PyTorch-ROCm's default stream is, so the two stay ordered). */
 int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);
+/* The same with a stream of the library's own that may only use `n_cus` of the device's compute units
+ * (hipExtStreamCreateWithCUMask; the enabled units are spread evenly over the XCDs): the CU budget of the compute stream in
+ * a data-parallel run, where RCCL's channels hold some units for the whole step -- a 256-tile GEMM launched on all 256
+ * units then finishes the displaced tiles as a straggling second round, while a launch planned for the units it really
+ * has (vbnn_kmajor_supported* and the shape heuristics read the budget) tiles for them. n_cus <= 0 or >= the device's
+ * count: no mask, just an own stream. vbnn_ctx_stream returns the hipStream_t for hosts that enqueue their own work
+ * (PyTorch: torch.cuda.ExternalStream). */
+int vbnn_ctx_create_cu_budget(int device, int n_cus, vbnn_ctx** out);
+int vbnn_ctx_stream(vbnn_ctx* ctx, void** hip_stream_out, int* n_cus_out);
 int vbnn_ctx_destroy(vbnn_ctx* ctx);
 int vbnn_ctx_set_stream(vbnn_ctx* ctx, void* hip_stream);
 int vbnn_sync(vbnn_ctx* ctx);

@@ -18,6 +18,8 @@ int vbnn_debug_set(int key, int value);
 int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K);
 int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row);
 int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);
+int vbnn_ctx_create_cu_budget(int device, int n_cus, vbnn_ctx** out);
+int vbnn_ctx_stream(vbnn_ctx* ctx, void** hip_stream_out, int* n_cus_out);
 int vbnn_ctx_destroy(vbnn_ctx* ctx);
 int vbnn_ctx_set_stream(vbnn_ctx* ctx, void* hip_stream);
 int vbnn_sync(vbnn_ctx* ctx);

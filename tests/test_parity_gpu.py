@@ -942,6 +942,45 @@ def test_captured_step_is_bitwise_the_launched_step(nnmod, N, S, stack):
     g.close()
 
 
+def test_cu_budget_stream_computes_the_same_gradients(nnmod):
+    """opt.cu_budget: the engine on a CU-masked stream of the library's own (vbnn_ctx_create_cu_budget) -- the compute
+    stream of a data-parallel rank, beside RCCL's channels. The mask changes where workgroups run and how many rounds a
+    launch takes, never what they compute: the gradient arena is bitwise the unmasked engine's, for a budget that keeps
+    the same kernels (the plan is per process: checked in a child process so that this one's stays unmasked)."""
+    import subprocess, sys, os
+    code = r"""
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+from vbnn_amd.engine import FusedMLP
+from vbnn_amd.nn import fill_normal
+budget = int(sys.argv[1])
+opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=1, mode="lrt", dtype="bf16", seed=3, input_size=256, hidden=[512, 256], n_classes=10, fuse_kl=True)
+if budget: opt["cu_budget"] = budget
+eng = FusedMLP(opt)
+s = eng.ctx.torch_stream if budget else torch.cuda.current_stream()
+with torch.cuda.stream(s):
+    x = torch.empty(512, 256, dtype=torch.float32, device="cuda"); fill_normal(x, 3, 4, 0, 0)
+    t = (torch.arange(512, device="cuda", dtype=torch.int64) * 7 %% 10).to(torch.int32)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t); eng.finish()
+    loss, _ = eng.loss_and_accuracy()
+np.save(sys.argv[2], eng.grads.cpu().numpy())
+print("budget", budget, "cus", getattr(eng.ctx, "cu_budget", None), "loss", repr(loss))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        outs = []
+        for budget in (0, 192):
+            out = os.path.join(d, f"g{budget}.npy")
+            res = subprocess.run([sys.executable, "-c", code, str(budget), out], capture_output=True, text=True, timeout=300)
+            assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
+            print(res.stdout.strip())
+            outs.append(np.load(out))
+        assert "cus 192" in res.stdout
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
 # ------------------------------------------------------------------------------------------- update (SURVEY 8f next #1)
 OPT_STATES = dict(state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
 

@@ -36,6 +36,7 @@ struct EpiSum {          // keeps both accumulators live with one 16-byte store 
     __device__ __forceinline__ void set_part(int) {}
     static constexpr int FOLD_BATCH = 8;
     static constexpr int FOLD_SERIAL = 0;
+    static constexpr int FOLD_STAGE = 0;
     struct Pre {};
     struct FPre {};
     struct Lane { unsigned o; };

@@ -81,6 +81,8 @@ _SIGS = {
     "vbnn_kmajor_supported": ([_i64, _i64, _i64], _i),
     "vbnn_kmajor_supported_dw": ([_i64, _i64, _i64, _i], _i),
     "vbnn_ctx_create": ([_i, _vp, C.POINTER(_vp)], _i),
+    "vbnn_ctx_create_cu_budget": ([_i, _i, C.POINTER(_vp)], _i),
+    "vbnn_ctx_stream": ([_vp, C.POINTER(_vp), C.POINTER(_i)], _i),
     "vbnn_ctx_destroy": ([_vp], _i),
     "vbnn_ctx_set_stream": ([_vp, _vp], _i),
     "vbnn_sync": ([_vp], _i),

@@ -12,7 +12,11 @@ void vbnn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// compute units the shape heuristics plan for: the device's, or the CU budget of the process's compute stream
+// (vbnn_ctx_create_cu_budget: one data-parallel rank per process, so the budget is process-wide like the device itself)
+static int g_cu_budget_plan = 0;
 int vbnn_cu_count() {
+    if (g_cu_budget_plan > 0) return g_cu_budget_plan;
     static int cus = 0;
     if (cus <= 0) {
         int dev = 0;
@@ -56,6 +60,44 @@ extern "C" int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out) {
         vbnn_set_error("hipMalloc(counters): %s", hipGetErrorString(e)); return VBNN_ERR_NOMEM;
     }
     *out = c;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_ctx_create_cu_budget(int device, int n_cus, vbnn_ctx** out) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(out, "null out");
+    vbnn_ctx* c = nullptr;
+    int st = vbnn_ctx_create(device, nullptr, &c);
+    if (st != VBNN_OK) return st;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    const int total = e == hipSuccess ? prop.multiProcessorCount : 0;
+    hipStream_t s = nullptr;
+    if (n_cus > 0 && n_cus < total) {
+        // bit i of the mask enables compute unit i; consecutive indices go round the XCDs, so the first n_cus bits are an
+        // even share of every XCD (checked on the box by timing: a 128-unit budget doubles a 256-tile launch)
+        std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+        for (int i = 0; i < n_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+        e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+        c->cu_budget = n_cus;
+        g_cu_budget_plan = n_cus;                                 // tile the launches for the units they will really have
+    } else {
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    }
+    if (e != hipSuccess) { (void)vbnn_ctx_destroy(c); vbnn_set_error("stream creation: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+    c->stream = s;
+    c->own_stream = true;
+    *out = c;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_ctx_stream(vbnn_ctx* ctx, void** hip_stream_out, int* n_cus_out) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx, "null ctx");
+    if (hip_stream_out) *hip_stream_out = (void*)ctx->stream;
+    if (n_cus_out) *n_cus_out = ctx->cu_budget > 0 ? ctx->cu_budget : vbnn_cu_count();
     return VBNN_OK;
     VBNN_API_END
 }

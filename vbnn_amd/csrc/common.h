@@ -33,6 +33,7 @@ struct vbnn_ctx {
     float* park;           // gemm_v3's parking tiles (pass 1 of a GEMM pair), grown on demand
     size_t park_bytes;
     unsigned* counters;    // arrival tickets of the in-launch second stages (vbnn_last_arriver); zero between launches
+    int cu_budget = 0;     // > 0: the stream is CU-masked to this many compute units (vbnn_ctx_create_cu_budget)
 };
 // ticket slots
 constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TILES = 16, VBNN_CNT_TILES_MAX = 1008, VBNN_CNT_TOTAL = 1024;   // [16, 1024): one ticket per split-K tile

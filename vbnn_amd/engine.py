@@ -62,7 +62,14 @@ class FusedMLP:
         device's shared context on torch's current stream."""
         self.opt = opt
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.ctx = Context.get(self.device) if stream is None else Context(self.device.index or 0, stream=stream)
+        # opt.cu_budget (data-parallel runs): the engine's launches go on a stream of the library's own limited to that many
+        # compute units, leaving the rest to RCCL's channels for the whole step (Context.with_cu_budget)
+        cu_budget = int(opt.get("cu_budget", 0) or 0)
+        if cu_budget > 0:
+            assert stream is None, "cu_budget creates the engine's stream itself"
+            self.ctx = Context.with_cu_budget(self.device.index or 0, cu_budget)
+        else:
+            self.ctx = Context.get(self.device) if stream is None else Context(self.device.index or 0, stream=stream)
         self.dtype = opt.get("dtype", "bf16")
         self.code, self.tdt = _DT[self.dtype]
         self.mode = opt.get("mode", "lrt")

@@ -42,6 +42,23 @@ class Context:
         self.h = h
 
     @classmethod
+    def with_cu_budget(cls, device, n_cus):
+        """A context on a stream of the library's own that may use only `n_cus` compute units (vbnn_ctx_create_cu_budget):
+        the compute stream of a data-parallel rank, beside RCCL's channels. torch work for it goes on `torch_stream`
+        (a torch.cuda.ExternalStream over the same hipStream_t)."""
+        self = cls.__new__(cls)
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        L.check(L.lib().vbnn_ctx_create_cu_budget(device, int(n_cus), C.byref(h)))
+        self.h = h
+        sp, n = C.c_void_p(), C.c_int()
+        L.check(L.lib().vbnn_ctx_stream(h, C.byref(sp), C.byref(n)))
+        self.cu_budget = n.value
+        self.torch_stream = torch.cuda.ExternalStream(sp.value, device=self.device)
+        return self
+
+    @classmethod
     def get(cls, device=None):
         if device is None:
             device = torch.cuda.current_device()
