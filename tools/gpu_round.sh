@@ -14,6 +14,8 @@ timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpu
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --prepare-each-step > gpurun_out/${tag}_bench_wide_prep.json 2>> gpurun_out/${tag}_bench.err; echo "prepare-each-step rc=$?"
 timeout -k 10 300 python3 bench.py --config small > gpurun_out/${tag}_bench_small.json 2>> gpurun_out/${tag}_bench.err; echo "small rc=$?"
 timeout -k 10 300 python3 bench.py --config small --S 30 --batch 1 --stack-draws --no-cpu-baseline > gpurun_out/${tag}_bench_small_S30.json 2>> gpurun_out/${tag}_bench.err; echo "small S30 rc=$?"
+timeout -k 10 300 python3 bench.py --config small --graph on --no-cpu-baseline > gpurun_out/${tag}_bench_small_graph.json 2>> gpurun_out/${tag}_bench.err; echo "small graph rc=$?"
+timeout -k 10 300 python3 bench.py --config small --S 30 --batch 1 --stack-draws --graph on --no-cpu-baseline > gpurun_out/${tag}_bench_small_S30_graph.json 2>> gpurun_out/${tag}_bench.err; echo "small S30 graph rc=$?"
 timeout -k 10 400 python3 bench.py --config deep --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_bench_deep.json 2>> gpurun_out/${tag}_bench.err; echo "deep rc=$?"
 VBNN_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_bench_dist1.json 2>> gpurun_out/${tag}_bench.err; echo "dist1 rc=$?"
 cd /tmp && export TMPDIR=/tmp
@@ -22,10 +24,21 @@ cd $root
 python3 profiles/summarize_db.py gpurun_out/prof_${tag}/${tag}_results.db 70 > gpurun_out/${tag}_wide_kernel_stats.txt 2>&1
 python3 tools/step_timeline.py gpurun_out/prof_${tag}/${tag}_results.db > gpurun_out/${tag}_wide_step_timeline.txt 2>&1
 head -14 gpurun_out/${tag}_wide_kernel_stats.txt; cat gpurun_out/${tag}_wide_step_timeline.txt
+# the update sweep (VBLinear:update, excluded from the metric): its kernel rows
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}u -o ${tag}u -- python3 $root/bench.py --no-cpu-baseline --steps 10 --warmup 5 --repeats 1 --with-update > /dev/null 2>&1; echo "prof update rc=$?"
+cd $root
+python3 profiles/summarize_db.py gpurun_out/prof_${tag}u/${tag}u_results.db 70 | grep -i "update\|total ms" > gpurun_out/${tag}_update_kernel_stats.txt 2>&1; cat gpurun_out/${tag}_update_kernel_stats.txt
+# the fp32 configuration: kernel stats and one step's timeline
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}s -o ${tag}s -- python3 $root/bench.py --config small --no-cpu-baseline --steps 50 --warmup 10 --repeats 2 > /dev/null 2>&1; echo "prof small rc=$?"
+cd $root
+python3 profiles/summarize_db.py gpurun_out/prof_${tag}s/${tag}s_results.db 30 > gpurun_out/${tag}_small_kernel_stats.txt 2>&1
+python3 tools/step_timeline.py gpurun_out/prof_${tag}s/${tag}s_results.db 70 EpiFwd 2 > gpurun_out/${tag}_small_step_timeline.txt 2>&1; cat gpurun_out/${tag}_small_step_timeline.txt
 VBNN_PMC_EXTRA="TCC_EA0_RDREQ_sum,TCC_EA0_RDREQ_32B_sum,TCC_EA0_RDREQ_DRAM_sum;TCC_REQ_sum,TCC_READ_sum,TCC_WRITE_sum" timeout -k 10 900 python3 tools/collect_traffic.py ${tag} > gpurun_out/${tag}_traffic.log 2>&1; tail -6 gpurun_out/${tag}_traffic.log
 python3 - <<PY
 import json
-for f in ("bench_wide", "bench_wide_driver", "bench_wide_prep", "bench_small", "bench_small_S30", "bench_deep", "bench_dist1"):
+for f in ("bench_wide", "bench_wide_driver", "bench_wide_prep", "bench_small", "bench_small_S30", "bench_small_graph", "bench_small_S30_graph", "bench_deep", "bench_dist1"):
     try:
         d = json.loads(open("gpurun_out/${tag}_%s.json" % f).read().strip().splitlines()[-1])
         print(f, d["ms_per_step"], d["value"], d["config"]["repeats_wall_ms"], d["roofline"]["frac"], d["roofline"]["timed_region_kernels_ms"], d["config"].get("train", {}).get("ms_per_train_step"), (d.get("cpu_baseline") or {}).get("value"))
