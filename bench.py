@@ -163,6 +163,50 @@ def cpu_baseline(cfg, budget_s=25.0):
     return out
 
 
+def reporting_config_row(torch, L, FusedMLP, fill_normal, with_cpu):
+    """north_star's own reporting configuration beside the headline, in the same run: the synthetic 784-400-400-10 MLP at
+    batch 256, fp32, LRT, S = 1 (BASELINE.json configs[1]) -- forward + backward samples/s, the fraction of the fp32 MFMA
+    peak over the step, the CPU baseline on the same host cores -- and the reference's shipped operating point, batch 1 with
+    S = 30 draws (config.lua:11,32), the draws stacked as rows. Launch-bound: reported, not the metric."""
+    cfg = CONFIGS["small"]
+    out = {"workload": cfg["name"], "dtype": "f32", "launch": "one stream launch per kernel (7 per step)"}
+    for key, N, S, stack in (("batch256", cfg["batch"], 1, False), ("batch1_S30_stacked", 1, 30, True)):
+        opt = dict(var_init=1e-3, B=1e6, S=S, mode="lrt", dtype="f32", seed=3, input_size=cfg["input_size"], hidden=cfg["hidden"],
+                   n_classes=cfg["n_classes"], fuse_kl=True)
+        eng = FusedMLP(opt)
+        x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
+        fill_normal(x, 3, L.STREAM_DATA, 0, 0)
+        t = eng.synthetic_targets(x, 0)
+
+        def step():
+            eng.resetGradients()
+            if stack:
+                eng.run_draws(x, t, S)
+            else:
+                eng.sample()
+                eng.run(x, t)
+            eng.finish()
+        eng.prepare()
+        for _ in range(10):
+            step()
+        blocks = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / 50 * 1e3)
+        ms = sorted(blocks)[2]
+        fps = algorithmic_flops_per_sample([cfg["input_size"]] + cfg["hidden"], cfg["n_classes"]) * S
+        out[key] = {"ms_per_step": round(ms, 4), "samples_per_s": round(N * S / (ms * 1e-3), 1), "blocks_ms": [round(b, 4) for b in blocks],
+                    "step_frac_of_fp32_mfma_peak": round(fps * N / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["f32"], 4)}
+        del eng
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(dict(cfg), budget_s=4.0)
+    return out
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` from a bare shell: start the ranks as a CHILD process (never exec), before this
     process has imported torch or made any HIP call, and hand back the child's exit code."""
@@ -193,6 +237,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; ms_per_step is the median block")
     ap.add_argument("--config", default="wide", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reporting-config", action="store_true", help="skip the 784-400-400-10 / batch 256 / fp32 row measured beside the headline")
     ap.add_argument("--overlap", action="store_true", help="run accGradParameters on a second stream (A/B; slower)")
     ap.add_argument("--mode", default="lrt", choices=["lrt", "wn"])
     ap.add_argument("--batch", type=int, default=0, help="exploration only: rows per GPU instead of the configuration's")
@@ -490,6 +535,8 @@ def main():
             out["comm"] = comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
+        if world == 1 and args.config == "wide" and not use_graph and args.cu_budget == 0 and not args.no_reporting_config:
+            out["reporting_config"] = reporting_config_row(torch, L, FusedMLP, fill_normal, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
