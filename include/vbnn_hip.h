@@ -252,6 +252,13 @@ typedef struct vbnn_dw_args {
 /* accGradParameters (VBLinear.lua:112-118), one GEMM instead of the reference's two. */
 int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
 
+/* accGradParameters AND updateGradInput of one layer in one call: both consume that layer's gradOutput and neither reads
+ * what the other writes (nn.Sequential:backward runs them back to back, mlp.lua:79). Where one launch can carry both -- dtype
+ * F32 with the K-major operand forms, at the launch-bound tile geometry (BASELINE configs[1]: a launch there is 10 us of
+ * latency chain with the chip a fraction busy) -- it does, each tile computed exactly as by its own launch (bitwise the same
+ * outputs); everywhere else this IS the two calls, accGradParameters first. */
+int vbnn_backward_pair(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* dx, const vbnn_dw_args* dw);
+
 /* gradBias += scale * sum_n g[n][o]  (the parent call at VBLinear.lua:113). g is N x ld_g of
  * `dtype` (F32: the module's gradOutput; BF16: a packed operand of the fused path). */
 int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O,

@@ -225,7 +225,22 @@ function FusedMLP:run(inputs, ld, targets, N)
         xa.w, xa.w2, xa.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld
         return xa
     end
-    if self.dx_first then
+    if self.direct then
+        -- fp32: accGradParameters and updateGradInput of a layer are independent and go out as ONE launch where the library
+        -- can carry both (vbnn_backward_pair); each tile bitwise what its own launch computes
+        for li = #self.vb, 1, -1 do
+            local v = self.vb[li]
+            local dd = dw_block(li)
+            if li > 1 then
+                check(C.vbnn_backward_pair(vb.ctx, self.dtype, dx_block(li), dd))
+            else
+                check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, dd))
+            end
+            if li < #self.vb and not v.bias_from_dw then
+                check(C.vbnn_acc_grad_bias(vb.ctx, self.dtype, v.g_s.p, v.g_s.ld, N, v.O, 1, accumulate, v.gradBias))
+            end
+        end
+    elseif self.dx_first then
         for li = #self.vb, 2, -1 do
             check(C.vbnn_grad_input(vb.ctx, self.dtype, dx_block(li)))
         end

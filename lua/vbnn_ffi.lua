@@ -95,6 +95,7 @@ typedef struct vbnn_dw_args {
     const uint32_t* draw_dev;
 } vbnn_dw_args;
 int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a);
+int vbnn_backward_pair(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* dx, const vbnn_dw_args* dw);
 int vbnn_acc_grad_bias(vbnn_ctx* ctx, int dtype, const void* g, int64_t ld_g, int64_t N, int64_t O,
                        float scale, int accumulate, float* gradBias);
 int vbnn_prep_layer(vbnn_ctx* ctx, int dtype, const float* means, const float* lvars, int64_t O, int64_t I,

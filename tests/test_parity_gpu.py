@@ -930,7 +930,9 @@ def test_captured_step_is_bitwise_the_launched_step(nnmod, N, S, stack):
     g = eb.capture_step(issue_b)
     # fp32: no packing launch, no finish launch -- sample, 2 forwards, 2 head kernels, gradInput, 2 accGradParameters (+ one
     # more sample for the stacked draws)
-    want_nodes = 10 if stack else 8 * S          # stacked draws: + the packer (row n % rows_per_draw) and the closing sample(S - 1)
+    # sample, two forwards, two head kernels, the layer-2 accGradParameters + updateGradInput PAIR launch, layer 1's
+    # accGradParameters; stacked draws: + the packer (row n % rows_per_draw) and the closing sample(S - 1)
+    want_nodes = 9 if stack else 7 * S
     assert g.kernel_nodes == g.nodes == want_nodes, (g.kernel_nodes, g.nodes, want_nodes)
     print(f"captured step: {g.kernel_nodes} kernel nodes")
     for step in range(1, 4):                                    # steps 2..4 as graph replays
@@ -979,6 +981,27 @@ print("budget", budget, "cus", getattr(eng.ctx, "cu_budget", None), "loss", repr
             outs.append(np.load(out))
         assert "cus 192" in res.stdout
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("hidden,I0,N", [([400, 400], 784, 256), ([50, 34], 70, 37), ([64, 48, 40], 128, 100)])
+def test_backward_pair_launch_is_bitwise_the_two_launches(nnmod, hidden, I0, N):
+    """vbnn_backward_pair (accGradParameters + updateGradInput of a layer as ONE launch on the fp32 path) against the same engine
+    with the two calls issued separately (opt.keep_transposes: the packed / transposed operand path of r02, separate launches):
+    the K order of every accumulation chain is the same, so gradients and loss are bitwise equal -- ragged shapes included."""
+    from vbnn_amd.engine import FusedMLP
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    res = []
+    for keep in (False, True):
+        eng = FusedMLP(opt_for("lrt", "f32", input_size=I0, hidden=hidden, S=1, fuse_kl=True, keep_transposes=keep))
+        for _ in range(2):
+            eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t); eng.finish()
+        loss, _ = eng.loss_and_accuracy()
+        assert eng.f32_direct == (not keep)
+        res.append((eng.grads.clone(), loss))
+    assert res[0][1] == res[1][1]
+    assert torch.equal(res[0][0], res[1][0])
 
 
 # ------------------------------------------------------------------------------------------- update (SURVEY 8f next #1)

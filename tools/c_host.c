@@ -310,7 +310,22 @@ static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t*
                              vl->has_t ? vl->gT_s.p : NULL, vl->has_t ? vl->gvT_s.p : NULL, vl->has_t ? vl->gT_s.ld : 0));
     vbnn_dw_args dd;
     vbnn_dx_args xa;
-    if (m->dx_first) {
+    if (m->direct) {
+        /* fp32: accGradParameters and updateGradInput of a layer are independent and go out as ONE launch where the library
+           can carry both (vbnn_backward_pair); each tile bitwise what its own launch computes */
+        for (int li = nl - 1; li >= 0; --li) {
+            layer_t* v = &m->vb[li];
+            dw_block(m, li, N, accumulate, &dd);
+            if (li > 0) {
+                dx_block(m, li, N, &xa);
+                CHECK(vbnn_backward_pair(g_ctx, m->dtype, &xa, &dd));
+            } else {
+                CHECK(vbnn_acc_grad_parameters(g_ctx, m->dtype, &dd));
+            }
+            if (li < nl - 1 && !v->bias_from_dw)
+                CHECK(vbnn_acc_grad_bias(g_ctx, m->dtype, v->g_s.p, v->g_s.ld, N, v->O, 1.0f, accumulate, v->gradBias));
+        }
+    } else if (m->dx_first) {
         for (int li = nl - 1; li >= 1; --li) {
             dx_block(m, li, N, &xa);
             CHECK(vbnn_grad_input(g_ctx, m->dtype, &xa));

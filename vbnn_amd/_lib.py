@@ -98,6 +98,7 @@ _SIGS = {
     "vbnn_forward": ([_vp, _i, C.POINTER(FwdArgs)], _i),
     "vbnn_grad_input": ([_vp, _i, C.POINTER(DxArgs)], _i),
     "vbnn_acc_grad_parameters": ([_vp, _i, C.POINTER(DwArgs)], _i),
+    "vbnn_backward_pair": ([_vp, _i, C.POINTER(DxArgs), C.POINTER(DwArgs)], _i),
     "vbnn_acc_grad_bias": ([_vp, _i, _vp, _i64, _i64, _i64, _f, _i, _vp], _i),
     "vbnn_prep_layer": ([_vp, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp], _i),
     "vbnn_compute_mugrads": ([_vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),

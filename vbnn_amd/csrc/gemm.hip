@@ -126,7 +126,7 @@ static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
 }
 
 template <typename T>
-static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
+static EpiDx<T> make_dx_epi(const vbnn_dx_args* a) {
     EpiDx<T> e;
     e.dual = a->gv != nullptr;
     e.x = (const T*)a->x; e.ld_x = a->ld_x;
@@ -138,6 +138,12 @@ static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
     e.g_prev = (T*)a->g_prev; e.gv_prev = (T*)a->gv_prev; e.ld_gp = a->ld_gp;
     e.gT_prev = (T*)a->gT_prev; e.gvT_prev = (T*)a->gvT_prev; e.ld_gpT = a->ld_gpT;
     e.I = (int)a->I; e.N = (int)a->N;
+    return e;
+}
+
+template <typename T>
+static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
+    const EpiDx<T> e = make_dx_epi<T>(a);
     const bool dual = a->gv != nullptr;
     int st = VBNN_OK;                                        // K-major weights first (no transposed shadows needed)
     if (dual ? try_kmajor<T, true, true, false>(ctx, a->w, a->w2, a->ld_w, a->g, a->gv, a->ld_g, a->I, a->N, a->O, e, &st)
@@ -156,7 +162,7 @@ static int grad_input_t(vbnn_ctx* ctx, const vbnn_dx_args* a) {
 }
 
 template <typename T>
-static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
+static EpiDw make_dw_epi(const vbnn_dw_args* a) {
     EpiDw e;
     e.lrt = (a->x2T != nullptr) || (a->x2 != nullptr) || (a->gvT != nullptr) || (a->gv != nullptr);
     e.scale = a->scale; e.accumulate = a->accumulate;
@@ -173,6 +179,12 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
                          a->ld_w < (1ll << 31) / (a->O > 0 ? a->O : 1);
     e.mu_s = shadows ? (const bf16_t*)a->mu_s : nullptr; e.var_s = shadows ? (const bf16_t*)a->var_s : nullptr; e.ld_w = shadows ? (int)a->ld_w : 0;
     e.I = (int)a->I; e.O = (int)a->O;
+    return e;
+}
+
+template <typename T>
+static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
+    EpiDw e = make_dw_epi<T>(a);
     const int64_t M = a->I + (a->gradBias ? 1 : 0);          // the ones row of xT (K-major: column I of x) rides along as one more output row
     int st = VBNN_OK;
     if (a->part == 1 || a->part == 2) {
@@ -253,8 +265,7 @@ extern "C" int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a) {
     VBNN_API_END
 }
 
-extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) {
-    VBNN_API_BEGIN
+static int check_dx_args(vbnn_ctx* ctx, const vbnn_dx_args* a) {
     VBNN_REQUIRE(ctx && a, "null ctx/args");
     VBNN_REQUIRE((a->wT || a->w) && a->g, "wT (or the K-major w) and g are required");
     VBNN_REQUIRE(!a->wT || ((a->w2T == nullptr) == (a->gv == nullptr)), "w2T and gv go together (LRT pair)");
@@ -268,6 +279,13 @@ extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) 
     VBNN_REQUIRE(!a->gv_prev || a->g_prev, "gv_prev needs g_prev");
     VBNN_REQUIRE(!a->g_prev || (a->ld_gp >= a->I && a->ld_gp % 4 == 0), "ld_gp");
     VBNN_REQUIRE(!a->gT_prev || a->ld_gpT >= a->N, "ld_gpT");
+    return VBNN_OK;
+}
+
+extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) {
+    VBNN_API_BEGIN
+    const int chk = check_dx_args(ctx, a);
+    if (chk != VBNN_OK) return chk;
     if (dtype == VBNN_F32) return grad_input_t<float>(ctx, a);
     if (dtype == VBNN_BF16) return grad_input_t<bf16_t>(ctx, a);
     vbnn_set_error("unsupported dtype %d", dtype);
@@ -275,8 +293,7 @@ extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) 
     VBNN_API_END
 }
 
-extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a) {
-    VBNN_API_BEGIN
+static int check_dw_args(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a) {
     VBNN_REQUIRE(ctx && a, "null ctx/args");
     VBNN_REQUIRE((a->xT && a->gT) || (a->x && a->g) || (a->x && a->gT), "xT and gT (or the K-major x and g, or x with gT) are required");
     const bool f32_km = dtype == VBNN_F32 && !a->xT && a->x && a->g;       // fp32 K-major form: x.x may be left to the kernel
@@ -290,9 +307,51 @@ extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_
     VBNN_REQUIRE(!(a->grad_mu || a->grad_lv) || (a->means && a->lvars && a->stats && a->B > 0 && a->S > 0),
                  "fused total gradients need means, lvars, stats, B, S");
     VBNN_REQUIRE(a->part >= 0 && a->part <= 2 && (a->part == 0 || a->x2T || a->x2), "part: 0, or 1 / 2 of an LRT pair (with x.x given)");
+    return VBNN_OK;
+}
+
+extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a) {
+    VBNN_API_BEGIN
+    const int chk = check_dw_args(ctx, dtype, a);
+    if (chk != VBNN_OK) return chk;
     if (dtype == VBNN_F32) return acc_grad_t<float>(ctx, a);
     if (dtype == VBNN_BF16) return acc_grad_t<bf16_t>(ctx, a);
     vbnn_set_error("unsupported dtype %d", dtype);
     return VBNN_ERR_UNSUPPORTED;
+    VBNN_API_END
+}
+
+// updateGradInput and accGradParameters of ONE layer as one call (include/vbnn_hip.h): one launch for the fp32 K-major forms at
+// the launch-bound geometry, otherwise exactly the two calls in the order given
+extern "C" int vbnn_backward_pair(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* dx, const vbnn_dw_args* dw) {
+    VBNN_API_BEGIN
+    int chk = check_dx_args(ctx, dx);
+    if (chk != VBNN_OK) return chk;
+    chk = check_dw_args(ctx, dtype, dw);
+    if (chk != VBNN_OK) return chk;
+    VBNN_REQUIRE(dx->N == dw->N && dx->I == dw->I && dx->O == dw->O, "the two argument blocks describe one layer");
+    if (dtype == VBNN_F32 && !dx->wT && dx->w && !dw->xT && dw->x && dw->g && dw->part == 0 && g_force_kernel == 0) {
+        const bool dual = dx->gv != nullptr;
+        const bool dw_dual = dw->gv != nullptr;
+        if (dual == dw_dual && (!dual || (dx->w2 && !dw->x2))) {
+            const EpiDx<float> ea = make_dx_epi<float>(dx);
+            const EpiDw eb = make_dw_epi<float>(dw);
+            const int M2 = (int)dw->I + (dw->gradBias ? 1 : 0);
+            int st;
+            if (dual)
+                st = launch_gemm_v1_pair<true>(ctx->stream, (const float*)dx->w, (const float*)dx->w2, dx->ld_w, (const float*)dx->g,
+                                               (const float*)dx->gv, dx->ld_g, (int)dx->I, (int)dx->N, (int)dx->O, ea, (const float*)dw->x,
+                                               dw->ld_x, (const float*)dw->g, (const float*)dw->gv, dw->ld_g, M2, (int)dw->O, (int)dw->N,
+                                               dw->gradBias ? (int)dw->I : -1, eb);
+            else
+                st = launch_gemm_v1_pair<false>(ctx->stream, (const float*)dx->w, nullptr, dx->ld_w, (const float*)dx->g, nullptr, dx->ld_g,
+                                                (int)dx->I, (int)dx->N, (int)dx->O, ea, (const float*)dw->x, dw->ld_x, (const float*)dw->g,
+                                                nullptr, dw->ld_g, M2, (int)dw->O, (int)dw->N, dw->gradBias ? (int)dw->I : -1, eb);
+            if (st != VBNN_ERR_UNSUPPORTED) return st;
+        }
+    }
+    int st = vbnn_acc_grad_parameters(ctx, dtype, dw);
+    if (st != VBNN_OK) return st;
+    return vbnn_grad_input(ctx, dtype, dx);
     VBNN_API_END
 }

@@ -48,10 +48,17 @@ __device__ __forceinline__ f32x4 mfma_step<bf16_t>(const bf16x8& a, const bf16x8
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// LDS bytes of one workgroup's tile(s)
+template <typename T, bool DUAL, int WR, int KS>
+constexpr int v1_lds_bytes() { return (WR == 1 ? 2 : 1) * (DUAL ? 4 : 2) * (32 * WR) * (64 * KS + 16); }
+
+// one block tile (bx, by) of the GEMM; `lds` = v1_lds_bytes() of the workgroup's shared memory. A device function so that
+// one launch can carry the tiles of TWO independent GEMMs (gemm_nt_v1_pair below).
 template <typename T, bool DUAL, int WR, int KS, class Epi, bool TA = false, bool TB = false, int SQ = 0>
-__global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const T* __restrict__ A2, int64_t lda,
-                                                  const T* __restrict__ B, const T* __restrict__ B2, int64_t ldb,
-                                                  int M, int N, int Kp, int K, int ones_row, Epi epi) {
+__device__ __forceinline__ void gemm_v1_tile(const T* __restrict__ A, const T* __restrict__ A2, int64_t lda,
+                                             const T* __restrict__ B, const T* __restrict__ B2, int64_t ldb,
+                                             int M, int N, int Kp, int K, int ones_row, Epi& epi, int bx, int by,
+                                             unsigned char* __restrict__ lds) {
     constexpr int BT = 32 * WR;                       // block tile rows (M and N)
     constexpr int RB = 64 * KS;                       // bytes of K per row per step
     constexpr int PITCH = RB + 16;                    // + 16 B pad: conflict-free ds_read_b128 down a column
@@ -69,14 +76,14 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
     typedef typename Frag<T>::type frag_t;
 
     constexpr bool DB = (WR == 1);                    // double-buffered LDS: see the K walk
-    __shared__ __attribute__((aligned(16))) unsigned char lds[(DB ? 2 : 1) * NOP * BT * PITCH];
+    static_assert(v1_lds_bytes<T, DUAL, WR, KS>() == (DB ? 2 : 1) * NOP * BT * PITCH, "LDS size helper out of step");
 
     epi.bind_draw();                                  // device-resident draw counter, if the host gave one (vbnn_fwd_args.draw_dev)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BT, n0 = blockIdx.y * BT;
+    const int m0 = bx * BT, n0 = by * BT;
 
     // PD: register prefetch depth, in K steps. The 32 x 32 tile of latency-bound sizes does so little per step that each
     // step is one exposed global-load latency (the 784-deep forward of the small MLP: 25 steps, 37 us); four steps of
@@ -278,6 +285,38 @@ __global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const
         for (int j = 0; j < WR; ++j) epi(em + i * 16, en + j * 16, acc1[i][j], acc2[i][j]);
 }
 
+template <typename T, bool DUAL, int WR, int KS, class Epi, bool TA = false, bool TB = false, int SQ = 0>
+__global__ __launch_bounds__(256) void gemm_nt_v1(const T* __restrict__ A, const T* __restrict__ A2, int64_t lda,
+                                                  const T* __restrict__ B, const T* __restrict__ B2, int64_t ldb,
+                                                  int M, int N, int Kp, int K, int ones_row, Epi epi) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[v1_lds_bytes<T, DUAL, WR, KS>()];
+    gemm_v1_tile<T, DUAL, WR, KS, Epi, TA, TB, SQ>(A, A2, lda, B, B2, ldb, M, N, Kp, K, ones_row, epi, (int)blockIdx.x, (int)blockIdx.y, lds);
+}
+
+// ---- two INDEPENDENT GEMMs in one launch (fp32, the 32 x 32 tile of the launch-bound sizes): updateGradInput and
+// accGradParameters of a layer both consume g and neither reads what the other writes, but as two launches the second
+// waits for the first -- 10 us each at 784-400-400-10 / batch 256, of which the chip is busy a fraction. Workgroups
+// [0, a.blocks) compute problem A's tiles, the rest problem B's; each tile is computed exactly as its own launch would
+// (same code, same K order: bitwise the two-launch results).
+template <typename T, class Epi>
+struct V1Problem {
+    const T* A; const T* A2; int64_t lda; const T* B; const T* B2; int64_t ldb;
+    int M, N, Kp, K, ones_row, gx, blocks;
+    Epi epi;
+};
+template <typename T, bool DUAL_A, class EpiA, bool TA_A, bool TB_A, int SQ_A, bool DUAL_B, class EpiB, bool TA_B, bool TB_B, int SQ_B>
+__global__ __launch_bounds__(256) void gemm_nt_v1_pair(V1Problem<T, EpiA> a, V1Problem<T, EpiB> b) {
+    constexpr int LA = v1_lds_bytes<T, DUAL_A, 1, 2>(), LB = v1_lds_bytes<T, DUAL_B, 1, 2>();
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LA > LB ? LA : LB];
+    const int bid = (int)blockIdx.x;
+    if (bid < a.blocks)
+        gemm_v1_tile<T, DUAL_A, 1, 2, EpiA, TA_A, TB_A, SQ_A>(a.A, a.A2, a.lda, a.B, a.B2, a.ldb, a.M, a.N, a.Kp, a.K, a.ones_row, a.epi,
+                                                               bid % a.gx, bid / a.gx, lds);
+    else
+        gemm_v1_tile<T, DUAL_B, 1, 2, EpiB, TA_B, TB_B, SQ_B>(b.A, b.A2, b.lda, b.B, b.B2, b.ldb, b.M, b.N, b.Kp, b.K, b.ones_row, b.epi,
+                                                               (bid - a.blocks) % b.gx, (bid - a.blocks) / b.gx, lds);
+}
+
 // form of a launch's operands beyond the packed default (fp32 only): see the head of this file
 struct V1Form {
     bool ta = false, tb = false;      // A / B side stored K-major
@@ -346,4 +385,29 @@ static int launch_gemm_v1(hipStream_t stream, const T* A, const T* A2, int64_t l
         return VBNN_ERR_UNSUPPORTED;
     }
     return launch_gemm_v1_form<T, DUAL, Epi, false, false, 0>(stream, A, A2, lda, B, B2, ldb, M, N, K, epi, -1);
+}
+
+// would launch_gemm_v1 give this shape the 32 x 32 tile (the launch-bound geometry the pair launch exists for)?
+static inline bool v1_small_geometry(int M, int N) {
+    return (long)((M + 127) / 128) * ((N + 127) / 128) < 128 && (long)((M + 63) / 64) * ((N + 63) / 64) < 96;
+}
+// problem A: gradInput form (A K-major: TA), DUAL or not; problem B: accGradParameters form (both K-major, A2 = A.A when
+// DUAL: SQ = 2). fp32 only. VBNN_ERR_UNSUPPORTED (nothing launched) when a shape wants another geometry.
+template <bool DUAL, class EpiA, class EpiB>
+static int launch_gemm_v1_pair(hipStream_t stream, const float* A, const float* A2, int64_t lda, const float* B, const float* B2, int64_t ldb,
+                               int M, int N, int K, const EpiA& epi_a,
+                               const float* xA, int64_t ldx, const float* gB, const float* gvB, int64_t ldg, int M2, int N2, int K2,
+                               int ones_row, const EpiB& epi_b) {
+    if (!v1_small_geometry(M, N) || !v1_small_geometry(M2, N2)) return VBNN_ERR_UNSUPPORTED;
+    if ((((uintptr_t)A | (uintptr_t)A2 | (uintptr_t)B | (uintptr_t)B2 | (uintptr_t)xA | (uintptr_t)gB | (uintptr_t)gvB) & 15u) != 0 ||
+        lda % 4 || ldb % 4 || ldx % 4 || ldg % 4 || lda < M || ldx < M2 - (ones_row >= 0 ? 1 : 0) || ldg < N2)
+        return VBNN_ERR_UNSUPPORTED;
+    constexpr int KE2 = 32;
+    V1Problem<float, EpiA> pa{A, A2, lda, B, B2, ldb, M, N, (K + KE2 - 1) / KE2 * KE2, K, -1, (M + 31) / 32, ((M + 31) / 32) * ((N + 31) / 32), epi_a};
+    V1Problem<float, EpiB> pb{xA, nullptr, ldx, gB, gvB, ldg, M2, N2, (K2 + KE2 - 1) / KE2 * KE2, K2, ones_row, (M2 + 31) / 32,
+                              ((M2 + 31) / 32) * ((N2 + 31) / 32), epi_b};
+    if (ldb < pa.Kp && ldb < K) return VBNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((gemm_nt_v1_pair<float, DUAL, EpiA, true, false, 0, DUAL, EpiB, true, true, (DUAL ? 2 : 0)>), dim3(pa.blocks + pb.blocks),
+                       dim3(256), 0, stream, pa, pb);
+    return vbnn_check_launch("gemm_nt_v1_pair");
 }

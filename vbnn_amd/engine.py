@@ -542,7 +542,21 @@ class FusedMLP:
         # all-reduce) of layer li and updateGradInput of layer li are independent of each other (both consume
         # g_li): with `overlap` they run on two HIP streams, so the HBM-bound epilogue of one GEMM sits beside the
         # MFMA main loop of the other instead of every CU hitting its epilogue at the same moment.
-        if self.dx_first and not self.reduce and not self.overlap:
+        if self.f32_direct and not self.overlap:
+            # fp32, launch-bound sizes: accGradParameters and updateGradInput of a layer are independent (both consume g_li) and
+            # go out as ONE launch where the library can carry both (vbnn_backward_pair: the general kernel's K-major forms at
+            # its 32 x 32 geometry; elsewhere the call is the two launches) -- each tile bitwise what its own launch computes
+            for li in range(nl - 1, -1, -1):
+                v = self.vb[li]
+                d = self._dw_args(li, N, accumulate)
+                with self._probed("accGradParameters", li):
+                    if li > 0:
+                        L.check(lib.vbnn_backward_pair(ctx, code, C.byref(self._dx_args(li, N)), C.byref(d)))
+                    else:
+                        L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+                if not (fused_head and li == nl - 1) and not v.bias_from_dw:
+                    L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
+        elif self.dx_first and not self.reduce and not self.overlap:
             # every updateGradInput first, then the accGradParameters from the first layer up: in the wide net the two 4096^3
             # launches are then separated by the lighter 784-wide gradient. The chip is power-bound in these launches
             # (DESIGN.md): alternating heavy and light ones lets it hold a higher clock -- measured -25 / -7 / +3 us on a
