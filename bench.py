@@ -169,7 +169,7 @@ def reporting_config_row(torch, L, FusedMLP, fill_normal, with_cpu):
     peak over the step, the CPU baseline on the same host cores -- and the reference's shipped operating point, batch 1 with
     S = 30 draws (config.lua:11,32), the draws stacked as rows. Launch-bound: reported, not the metric."""
     cfg = CONFIGS["small"]
-    out = {"workload": cfg["name"], "dtype": "f32", "launch": "one stream launch per kernel (7 per step)"}
+    out = {"workload": cfg["name"], "dtype": "f32", "launch": "one stream launch per kernel (6 per step)"}
     for key, N, S, stack in (("batch256", cfg["batch"], 1, False), ("batch1_S30_stacked", 1, 30, True)):
         opt = dict(var_init=1e-3, B=1e6, S=S, mode="lrt", dtype="f32", seed=3, input_size=cfg["input_size"], hidden=cfg["hidden"],
                    n_classes=cfg["n_classes"], fuse_kl=True)
