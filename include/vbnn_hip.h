@@ -354,6 +354,12 @@ typedef struct vbnn_update_desc {
     float* bias; const float* grad_bias; float lr_bias;    /* optional (NULL): optim.sgd on the bias */
     float B;                                           /* opt.B: scale of the KL parts in the logged norms */
     double* log14;                                     /* optional */
+    /* 0 (default): grad_mu / grad_lv are the TOTAL gradients (the accGradParameters epilogue added the KL part, from the
+     * bf16 operand shadows in the fused bf16 configuration). > 0: they are the likelihood parts alone (the host passed
+     * vbnn_dw_args.kl_scale = 0) and the sweep adds kl_add x the KL gradient itself, from the fp32 means / lvars and stats[2]
+     * (VBLinear.lua:91,96 exactly as the reference computes them) -- the exact form: the shadow form's (bf16(s2) / var_hat - 1)
+     * cancels to ~2^-9 absolute. Data-parallel: 1 on every rank (the all-reduced likelihood sum + the KL gradient once). */
+    float kl_add;
 } vbnn_update_desc;
 int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra);
 

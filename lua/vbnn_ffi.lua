@@ -135,6 +135,7 @@ typedef struct vbnn_update_desc {
     float* bias; const float* grad_bias; float lr_bias;
     float B;
     double* log14;
+    float kl_add;
 } vbnn_update_desc;
 int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra);
 typedef struct vbnn_comm vbnn_comm;

@@ -1126,6 +1126,70 @@ def test_engine_update_matches_oracle(oracle, nnmod):
         np.testing.assert_allclose(host(eng.weight3), onet.last.weight, rtol=0, atol=1e-7 * np.abs(onet.last.weight).max() + 1e-9)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_kl_gradient_added_in_the_update_is_the_fp32_form(oracle, nnmod, dtype):
+    """opt.kl_in_update: the arena carries the likelihood parts only (vbnn_dw_args.kl_scale = 0) and vbnn_update adds the KL
+    gradient from the fp32 means / lvars (vbnn_update_desc.kl_add) -- VBLinear.lua:91,96 exactly. (1) arena + the KL gradient
+    formed here in float64 from the fp32 parameters = the total gradients of an engine whose epilogue added the fp32 KL terms
+    (kl_from_shadows = False). (2) After TWO steps with updates (the second Adam step depends on the gradients' values, not
+    just their signs) the parameters of the two engines agree to fp32 rounding; in bf16 the default shadow form --
+    bf16(s2) / var_hat - 1 -- is measurably further away."""
+    from vbnn_amd.engine import FusedMLP
+    I0, N, hidden, B = 256, 512, [512, 256], 50.0
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    out = {}
+    for name, extra in (("in_update", dict(kl_in_update=True)), ("fp32_epilogue", dict(kl_from_shadows=False)), ("shadows", {})):
+        opt = opt_for("lrt", dtype, input_size=I0, hidden=hidden, S=1, fuse_kl=True, B=B, **OPT_STATES, **extra)   # small B: the KL part matters
+        eng = FusedMLP(opt)
+        for v in eng.vb:                                    # posterior variances away from the prior's: a KL gradient that is not ~0
+            v.lvars.add_(0.7 * torch.sin(torch.arange(v.lvars.numel(), device="cuda", dtype=torch.float32)).view_as(v.lvars))
+        eng.prepare()
+        first = None
+        for step in range(2):
+            eng.resetGradients(); eng.sample(); eng.run(x, t); eng.finish()
+            if step == 0:
+                kl, kls = [], []
+                for v in eng.vb:                            # VBLinear.lua:91,96 in float64 from the fp32 parameters ...
+                    mu, lv = v.means.double(), v.lvars.double()
+                    var_hat = float((lv.exp() + mu * mu).mean().item())
+                    kl.append(((lv.exp() / var_hat - 1.0) / (2.0 * B), mu / (B * var_hat)))
+                    # ... and as the shadow form has them: from the operand shadows (bf16 mu, bf16 exp(lvars))
+                    ms, vs = v.mu_s.t[:, :v.I].double(), v.var_s.t[:, :v.I].double()
+                    kls.append(((vs / var_hat - 1.0) / (2.0 * B), ms / (B * var_hat)))
+                first = ([v.gradSum.double().clone() for v in eng.vb], [v.gradWeight.double().clone() for v in eng.vb], kl, kls)
+            eng.update(opt)
+        torch.cuda.synchronize()
+        out[name] = (first, [v.lvars.clone() for v in eng.vb], [v.means.clone() for v in eng.vb])
+    for k in range(2):
+        # (1) the arena of the in-update engine IS the likelihood part: + the KL gradient = another engine's totals. fp32: + the
+        # exact KL = the fp32-epilogue engine's. bf16: the likelihood factor of d/dlvars is the bf16 sigma^2 the forward multiplied
+        # by (in both shadow engines; the fp32-epilogue engine uses exp(lvars) there), so the like-for-like check is
+        # + the KL gradient as the shadow form has it = the shadow engine's totals.
+        glv_lik, gmu_lik, kl, kls = (out["in_update"][0][j][k] for j in range(4))
+        ref, klr = ("fp32_epilogue", kl) if dtype == "f32" else ("shadows", kls)
+        glv_tot, gmu_tot = out[ref][0][0][k], out[ref][0][1][k]
+        e_lv = float(((glv_lik + klr[0]) - glv_tot).abs().max() / glv_tot.abs().max())
+        e_mu = float(((gmu_lik + klr[1]) - gmu_tot).abs().max() / gmu_tot.abs().max())
+        assert e_lv <= 2e-6 and e_mu <= 2e-6, (k, ref, e_lv, e_mu)
+        assert float(kl[0].abs().max()) > 1e-2 * float(glv_tot.abs().max())          # the KL part is not negligible here
+        # what the shadow form loses: its KL gradient against the exact one (bf16: ~2^-9 absolute in the bracket)
+        kl_err = float((kls[0] - kl[0]).abs().max() / kl[0].abs().max())
+        # (2) parameters after two updates (the second Adam step depends on the gradients' values)
+        a, b, c = out["in_update"][1][k], out["fp32_epilogue"][1][k], out["shadows"][1][k]
+        d_exact, d_shadow = float((a - b).abs().max()), float((c - b).abs().max())
+        m_exact = float((out["in_update"][2][k] - out["fp32_epilogue"][2][k]).abs().max())
+        print(f"layer {k}: shadow-form KL gradient off by {kl_err:.2e} of its max; lvars after two updates: |in-update - fp32 epilogue| "
+              f"{d_exact:.3e}, |shadows - fp32 epilogue| {d_shadow:.3e}; means {m_exact:.3e}")
+        if dtype == "f32":
+            assert d_exact <= 2e-5 and m_exact <= 2e-6, (k, d_exact, m_exact)
+            assert kl_err <= 1e-6                              # (fp32 "shadows" are the parameters themselves)
+        else:
+            assert kl_err > 1e-4                               # the deviation ADVICE r02 described is real ...
+            assert d_exact <= d_shadow + 1e-7, (k, d_exact, d_shadow)      # ... and the in-update form does not have it
+
+
 def test_update_leaves_what_prepare_would_and_logs_the_14_series(oracle, nnmod):
     """vbnn_update = VBLinear:update + the next minibatch's parameter sweep in one pass. After two minibatches with
     updates (Adam state carried): (1) the operand shadows it wrote are BITWISE what vbnn_prepare writes from the updated

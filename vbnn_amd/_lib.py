@@ -61,7 +61,7 @@ class UpdateDesc(C.Structure):        # vbnn_update_desc
     _fields_ = [("means", _vp), ("lvars", _vp), ("O", _i64), ("I", _i64), ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64),
                 ("muT_s", _vp), ("varT_s", _vp), ("ld_wT", _i64), ("stats", _vp), ("grad_mu", _vp), ("grad_lv", _vp),
                 ("m_mu", _vp), ("v_mu", _vp), ("m_lv", _vp), ("v_lv", _vp), ("mu", AdamCfg), ("lv", AdamCfg),
-                ("bias", _vp), ("grad_bias", _vp), ("lr_bias", _f), ("B", _f), ("log14", _vp)]
+                ("bias", _vp), ("grad_bias", _vp), ("lr_bias", _f), ("B", _f), ("log14", _vp), ("kl_add", _f)]
 
 
 class DwArgs(C.Structure):

@@ -758,6 +758,7 @@ struct UpdLayer {
     const double* stats;
     const float* g_mu; const float* g_lv; float* m_mu; float* v_mu; float* m_lv; float* v_lv;
     float b1_mu, b2_mu, eps_mu, step_mu, b1_lv, b2_lv, eps_lv, step_lv, B;
+    float kl_add;          // weight of the KL gradient added HERE, from the fp32 parameters (vbnn_update_desc.kl_add); 0: the gradients are totals
     double* partial;
 };
 __device__ __forceinline__ double wave_min(double v) {
@@ -829,6 +830,10 @@ __global__ __launch_bounds__(256) void k_vb_update(UpdLayer a) {
                     if (e < valid) {
                         // the two parts of each total gradient (logging only)
                         const float mlc = k_mu * m[e], vlc = k_lv * fmaf(expf(l[e]), inv_vh, -1.0f);
+                        if (a.kl_add != 0.f) {            // likelihood-only gradients in: the KL part joins them here, in fp32
+                            gm[e] = fmaf(a.kl_add, mlc, gm[e]);
+                            gl[e] = fmaf(a.kl_add, vlc, gl[e]);
+                        }
                         const float mle = gm[e] - mlc, vle = gl[e] - vlc;
                         acc[6] += (double)mlc * mlc; acc[7] += (double)mle * mle;
                         acc[8] += (double)vlc * vlc; acc[9] += (double)vle * vle;
@@ -973,6 +978,7 @@ extern "C" int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_up
         a.step_mu = adam_step_size(d.mu, &a.b1_mu); a.b2_mu = d.mu.beta2; a.eps_mu = d.mu.eps;
         a.step_lv = adam_step_size(d.lv, &a.b1_lv); a.b2_lv = d.lv.beta2; a.eps_lv = d.lv.eps;
         a.B = d.B;
+        a.kl_add = d.kl_add;
         a.partial = ctx->scratch + (size_t)l * MAXB * UPD_NSUM;
         if (dtype == VBNN_F32) hipLaunchKernelGGL(k_vb_update<float>, dim3(nb), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(k_vb_update<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, a);

@@ -88,6 +88,11 @@ class FusedMLP:
         self.criterion = opt.get("criterion", "nll")
         assert self.criterion in ("nll", "mse")
         self.kl_from_shadows = self.dtype == "bf16" and bool(opt.get("kl_from_shadows", True))
+        # opt.kl_in_update: the gradient arena holds the LIKELIHOOD parts only (vbnn_dw_args.kl_scale = 0) and update() adds the
+        # KL gradient from the fp32 means / lvars (vbnn_update_desc.kl_add) -- exact, where the epilogue's shadow form carries
+        # bf16(sigma^2) / var_hat - 1; in a data-parallel run the exchanged sum is then a pure sum of likelihoods.
+        self.kl_in_update = bool(opt.get("kl_in_update", False))
+        assert not self.kl_in_update or (self.fuse_kl and self.mode == "lrt"), "kl_in_update: the fused LRT engine"
         # optional second HIP stream (+ its own context, hence its own reduction scratch) for the accGradParameters
         # GEMMs. Measured on MI355X (wide config): 1.32 ms with, 1.29 ms without -- two 512-block GEMMs sharing the
         # CUs thrash each other's L2 panels more than the staggered epilogues save -- so it is off by default.
@@ -449,6 +454,8 @@ class FusedMLP:
             d.grad_mu, d.grad_lv = _p(v.gradWeight), _p(v.gradSum)
             d.means, d.stats = _p(v.means), _p(v.stats)
             d.B, d.S, d.kl_scale = self.B, float(self._draws or self.S), partition.scales(1, self.world)["kl_scale"]
+            if self.kl_in_update:
+                d.kl_scale = 0.0                      # likelihood parts only: update() adds the KL gradient from the fp32 parameters
             if self.kl_from_shadows and lrt:
                 # the epilogue reads mu, sigma^2 from the bf16 operand shadows (4 B per weight instead of 8, no exp): the
                 # values the forward GEMMs multiplied by
@@ -798,7 +805,8 @@ class FusedMLP:
                                     ld_wT=v.muT_s.ld if v.muT_s else 0, stats=_p(v.stats), grad_mu=_p(v.gradWeight),
                                     grad_lv=_p(v.gradSum), m_mu=_p(sm["m"]), v_mu=_p(sm["v"]), m_lv=_p(sv["m"]), v_lv=_p(sv["v"]),
                                     mu=cm, lv=cv, bias=_p(v.bias), grad_bias=_p(v.gradBias), lr_bias=lr, B=self.B,
-                                    log14=C.c_void_p(self.update_log[k].data_ptr()) if log else None)
+                                    log14=C.c_void_p(self.update_log[k].data_ptr()) if log else None,
+                                    kl_add=1.0 if self.kl_in_update else 0.0)
         w3 = L.PackDesc(src=_p(self.weight3), rows=self.n_classes, cols=self.sizes[-1], ld_src=self.sizes[-1],
                         dst=self.w3_s.ptr, ld_dst=self.w3_s.ld, dstT=self.w3T_s.ptr, ld_dstT=self.w3T_s.ld)
         L.check(lib.vbnn_update(h, self.code, len(self.vb), descs, C.byref(w3)))
