@@ -73,6 +73,7 @@ function FusedMLP.new(opt)
     self.w3_s = packed(self.n_classes, H, self.esize)
     self.acc, self.corr = vb.alloc(16), vb.alloc(4)
     self.draw, self.first = 0, true
+    if opt.device_draw then self.draw_dev = ffi.cast('uint32_t*', vb.alloc(4)) end   -- the draw counter on the device
     if self.world > 1 then                                        -- the exchange (include/vbnn_hip.h: vbnn_comm_*)
         local box = ffi.new('vbnn_comm*[1]')
         check(C.vbnn_comm_create(vb.ctx, self.rank, self.world, opt.comm_id, box))
@@ -159,7 +160,10 @@ function FusedMLP:prepare()
     check(C.vbnn_prepare(vb.ctx, self.dtype, n, d, w3))
 end
 
-function FusedMLP:sample() self.draw = self.draw + 1 end          -- mlp.lua:69-74: LRT draws its noise in the forward epilogue
+function FusedMLP:sample()                                        -- mlp.lua:69-74: LRT draws its noise in the forward epilogue
+    self.draw = self.draw + 1
+    if self.draw_dev then check(C.vbnn_sample(vb.ctx, self.draw_dev, 1)) end   -- opt.device_draw: capturable (vbnn_capture_*)
+end
 
 -- mlp.lua:76-84, fused. inputs: DEVICE pointer to N x input_size floats (row pitch ld), targets: device int32[N], 0-based
 function FusedMLP:run(inputs, ld, targets, N)
@@ -181,7 +185,8 @@ function FusedMLP:run(inputs, ld, targets, N)
         local fa = ffi.new('vbnn_fwd_args')
         fa.w, fa.w2, fa.x, fa.x2, fa.ld_w, fa.ld_x = v.mu_s.p, v.var_s.p, v.x_in, v.x2_s and v.x2_s.p or nil, v.mu_s.ld, v.ld_in
         fa.N, fa.I, fa.O, fa.bias = N, v.I, v.O, f32(v.bias)
-        fa.seed, fa.layer, fa.draw, fa.row0 = self.seed, v.layer_id, self.draw, row0
+        fa.seed, fa.layer, fa.draw, fa.row0 = self.seed, v.layer_id, self.draw_dev and 0 or self.draw, row0
+        fa.draw_dev = self.draw_dev
         fa.r, fa.ld_r, fa.r_packed, fa.relu = v.r, v.O, 1, 1
         fa.h = nxt and nxt.x_s.p or self.h_s.p
         fa.h2 = (nxt and nxt.x2_s) and nxt.x2_s.p or nil

@@ -93,13 +93,15 @@ def _read_arena(path, n_layers_sizes=None):
 
 
 CASES = [
-    # dtype, input, hidden, batch, S, steps, update, comm
+    # dtype, input, hidden, batch, S, steps, update, comm (comm = "graph": steps 2.. replayed from ONE captured graph)
     ("f32", 784, [400, 400], 256, 1, 2, False, False),          # BASELINE configs[1]: the numerics configuration
     ("f32", 784, [400, 400], 100, 3, 2, True, False),           # configs[0]'s batch, S draws accumulating, an update between
     ("bf16", 256, [512, 256], 512, 1, 2, False, False),         # transposed operands (no K-major form at this size)
     ("bf16", 256, [512, 256], 512, 1, 3, True, True),           # + update + the RCCL exchange (layerwise order)
     ("bf16", 784, [4096, 4096], 4096, 1, 2, True, False),       # the bench's configuration: K-major, split launch, dx-first
     ("bf16", 784, [4096, 4096], 4096, 1, 2, False, True),       # + RCCL: early d/dlvars messages, three all-reduces per step
+    ("f32", 784, [400, 400], 256, 1, 4, False, "graph"),        # the C host captures its step and replays it: own stream, device draw counter
+    ("f32", 784, [400, 400], 100, 3, 3, False, "graph"),        # ... with S = 3 accumulating draws inside the graph
 ]
 
 
@@ -113,12 +115,16 @@ def test_c_host_gradient_arena_is_bitwise_the_python_engines(tmp_path, dtype, I0
     out = str(tmp_path / "arena.bin")
     cmd = [exe, "--dtype", dtype, "--input", str(I0), "--hidden", ",".join(str(h) for h in hidden), "--classes", "10",
            "--batch", str(N), "--S", str(S), "--steps", str(steps), "--out", out]
+    graph = comm == "graph"
+    comm = bool(comm) and not graph
     cmd += ["--update"] if update else []
     cmd += ["--comm"] if comm else []
+    cmd += ["--graph"] if graph else []
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VBNN_RCCL_PATH="/opt/rocm/lib/librccl.so.1")
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
     print(res.stdout.strip())
+    assert not graph or "replays of one captured graph" in res.stdout
     n, loss_c, correct_c, flags, arena_c, rest = _read_arena(out)
 
     opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=S, mode="lrt", dtype=dtype, seed=3, input_size=I0, hidden=hidden,

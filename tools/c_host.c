@@ -13,7 +13,9 @@
  * vbnn_amd/engine.py:FusedMLP on the same configuration.
  *
  *   c_host --dtype f32|bf16 --input 784 --hidden 400,400 --classes 10 --batch 256 [--S 1] [--steps 2] [--update]
- *          [--comm] [--seed 3] --out arena.bin
+ *          [--comm] [--graph] [--seed 3] --out arena.bin
+ *   --graph: the context gets a stream of its own (vbnn_ctx_create_cu_budget), the draw counter lives on the device
+ *   (vbnn_fwd_args.draw_dev, vbnn_sample), step 2 is CAPTURED (vbnn_capture_begin / _end) and steps 2.. are replays of it.
  *   arena.bin: int64 n_grads, double loss, int32 correct, int32 flags, then n_grads floats (the arena after the last
  *   step), then per VB layer the O x I means after the last update (only with --update).
  *
@@ -90,6 +92,7 @@ typedef struct {
     double* acc;
     int32_t* corr;
     uint32_t draw;
+    uint32_t* draw_dev;       /* --graph: the draw counter in device memory (vbnn_fwd_args.draw_dev), advanced by vbnn_sample */
     int first;
     int64_t N;
     vbnn_comm* comm;
@@ -241,7 +244,10 @@ static void fm_prepare(fused_mlp* m) {
     CHECK(vbnn_prepare(g_ctx, m->dtype, m->n_layers, d, &w3));
 }
 
-static void fm_sample(fused_mlp* m) { m->draw += 1; }          /* mlp.lua:69-74: LRT draws its noise in the forward epilogue */
+static void fm_sample(fused_mlp* m) {                          /* mlp.lua:69-74: LRT draws its noise in the forward epilogue */
+    m->draw += 1;
+    if (m->draw_dev) CHECK(vbnn_sample(g_ctx, m->draw_dev, 1));   /* capturable: the counter lives on the device */
+}
 
 static void dw_block(fused_mlp* m, int li, int64_t N, int accumulate, vbnn_dw_args* d) {
     layer_t* v = &m->vb[li];
@@ -292,7 +298,7 @@ static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t*
         memset(&fa, 0, sizeof fa);
         fa.w = v->mu_s.p; fa.w2 = v->var_s.p; fa.x = v->x_in; fa.x2 = m->direct ? NULL : v->x2_s.p; fa.ld_w = v->mu_s.ld; fa.ld_x = v->ld_in;
         fa.N = N; fa.I = v->I; fa.O = v->O; fa.bias = v->bias;
-        fa.seed = m->seed; fa.layer = v->layer_id; fa.draw = m->draw; fa.row0 = row0;
+        fa.seed = m->seed; fa.layer = v->layer_id; fa.draw = m->draw_dev ? 0 : m->draw; fa.draw_dev = m->draw_dev; fa.row0 = row0;
         fa.r = v->r; fa.ld_r = v->O; fa.r_packed = 1; fa.relu = 1;
         fa.h = nxt ? nxt->x_s.p : m->h_s.p;
         fa.h2 = (nxt && !m->direct) ? nxt->x2_s.p : NULL;
@@ -444,11 +450,19 @@ int main(int argc, char** argv) {
     const int steps = atoi(arg_value(argc, argv, "--steps", "2"));
     const uint64_t seed = (uint64_t)atoll(arg_value(argc, argv, "--seed", "3"));
     const int with_update = arg_flag(argc, argv, "--update"), with_comm = arg_flag(argc, argv, "--comm");
+    const int with_graph = arg_flag(argc, argv, "--graph");      /* steps 2.. as replays of ONE captured graph (vbnn_capture_*) */
     if (n_layers < 1 || n_classes < 1 || n_classes > 16 || N < 1 || S < 1) { fprintf(stderr, "c_host: bad configuration\n"); return 1; }
 
-    CHECK(vbnn_ctx_create(atoi(arg_value(argc, argv, "--device", "0")), NULL, &g_ctx));
+    if (with_graph) {
+        /* the NULL stream cannot be captured: a context with a stream of the library's own (no CU mask) */
+        if (with_comm || with_update) { fprintf(stderr, "c_host: --graph captures the plain step (no --comm / --update)\n"); return 1; }
+        CHECK(vbnn_ctx_create_cu_budget(atoi(arg_value(argc, argv, "--device", "0")), 0, &g_ctx));
+    } else {
+        CHECK(vbnn_ctx_create(atoi(arg_value(argc, argv, "--device", "0")), NULL, &g_ctx));
+    }
     fused_mlp net;
     fm_new(&net, dtype, sizes, n_layers, n_classes, seed, 1e-3, 1e6f, (float)S, with_comm);
+    if (with_graph) net.draw_dev = (uint32_t*)dev_alloc(4);
 
     /* the synthetic minibatch of the parity tests: x ~ N(0,1) from the Philox contract (stream DATA), targets by row */
     float* x = (float*)dev_alloc((size_t)N * sizes[0] * 4);
@@ -459,13 +473,23 @@ int main(int argc, char** argv) {
     CHECK(vbnn_buf_upload(g_ctx, t, t_host, (size_t)N * 4));
     free(t_host);
 
+    vbnn_graph* graph = NULL;
+    int graph_nodes = 0;
     for (int step = 0; step < steps; ++step) {                   /* main.lua:28-40 */
+        if (graph) { CHECK(vbnn_graph_launch(graph)); continue; }     /* every replay advances the device counter: its own noise */
+        const int capture = with_graph && step == 1;             /* step 1 ran launch by launch (allocations, first launches) */
+        if (capture) { CHECK(vbnn_sync(g_ctx)); CHECK(vbnn_capture_begin(g_ctx)); }
         fm_reset_gradients(&net);
         for (int s = 0; s < S; ++s) {
             fm_sample(&net);
             fm_run(&net, x, sizes[0], t, N);
         }
         fm_finish(&net);
+        if (capture) {
+            CHECK(vbnn_capture_end(g_ctx, &graph));
+            CHECK(vbnn_graph_info(graph, &graph_nodes, NULL));
+            CHECK(vbnn_graph_launch(graph));                      /* recorded, not run: this is step 2 */
+        }
         if (with_update && step + 1 < steps) fm_update(&net, 1e-3f, 1e-4f, 5e-2f);
     }
     double loss = 0;
@@ -496,6 +520,7 @@ int main(int argc, char** argv) {
            with_comm ? " +rccl(world 1)" : "", loss, correct, net.dx_first ? "dx-first" : "layerwise");
     for (int li = 0; li < n_layers; ++li) printf(" | L%d dw_km %d dx_km %d bias_from_dw %d", li, net.vb[li].dw_km, net.vb[li].dx_km, net.vb[li].bias_from_dw);
     printf("\n");
+    if (graph) { printf("c_host: steps 2..%d were replays of one captured graph of %d kernel nodes\n", steps, graph_nodes); CHECK(vbnn_graph_destroy(graph)); }
     if (net.comm) CHECK(vbnn_comm_destroy(net.comm));
     CHECK(vbnn_ctx_destroy(g_ctx));                               /* (device buffers are released with the process) */
     return 0;
