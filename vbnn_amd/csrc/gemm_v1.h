@@ -190,6 +190,21 @@ __device__ __forceinline__ void gemm_v1_tile(const T* __restrict__ A, const T* _
             for (int c = 0; c < CPT; ++c)
                 if (loaded(op)) stage[d][op][c] = load_chunk(op, c, min(d, nk - 1));
 
+    // The epilogue's own operands (bias; x and r of the layer below; ...) are fetched NOW, before the K walk, through the
+    // functor's FAST protocol when it applies (packed outputs, no transposed copies) and the wave's 16 x 16 tile lies inside
+    // the matrix: at the launch-bound sizes the K walk is a handful of steps and an epilogue that starts its loads after it
+    // adds a full memory round trip to every launch. Same arithmetic as the guarded form (the pipelined kernels' protocol).
+    const int um = __builtin_amdgcn_readfirstlane(m0 + wm * WR * 16), un = __builtin_amdgcn_readfirstlane(n0 + wn * WR * 16);
+    bool fast = false;
+    typename Epi::Lane eln = {};
+    typename Epi::Pre epre = {};
+    if constexpr (WR == 1) {
+        fast = epi.fast_ok() && !epi.t1_ptr() && !epi.t2_ptr() && um + 16 <= epi.m_dim() && un + 16 <= epi.n_dim();   // wave-uniform
+        if (fast) {
+            eln = epi.lane_init(lane & 15, (lane >> 4) * 4);
+            epre = epi.load_fast(um, un, eln);
+        }
+    }
     const int a_row = (wm * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
     const int b_row = (wn * WR * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
 
@@ -277,6 +292,13 @@ __device__ __forceinline__ void gemm_v1_tile(const T* __restrict__ A, const T* _
         }
     }
 
+    if constexpr (WR == 1) {
+        if (fast) {
+            float t1[4], t2[4];
+            epi.apply_fast(um, un, eln, acc1[0][0], acc2[0][0], epre, t1, t2);
+            return;
+        }
+    }
     const int em = m0 + wm * WR * 16 + (lane >> 4) * 4;
     const int en = n0 + wn * WR * 16 + (lane & 15);
 #pragma unroll
