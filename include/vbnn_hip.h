@@ -396,6 +396,26 @@ int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int6
  * lets the host verify that `world` distinct processes / devices take part in the exchange. */
 int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
 
+/* ---- the same exchange WITHOUT a collective library: direct reduce-scatter + all-gather over peer-mapped arenas
+ * (vbnn_amd/csrc/p2p.hip; SURVEY.md section 5's fallback should RCCL put the 160 MB all-reduce on a single ring: every GPU of an
+ * 8-GPU node has seven point-to-point xGMI links, and this form moves an eighth of the bucket over each of them at once).
+ * vbnn_p2p_create allocates THE gradient arena of this rank (arena_floats fp32, zeroed: the host keeps its gradients there, as
+ * engine.py's flat arena) and returns its device pointer and this rank's VBNN_P2P_HANDLE_BYTES handle; the host passes the
+ * handles round by its own means (as the RCCL unique id), every rank calls vbnn_p2p_connect with all of them in rank order
+ * (world x VBNN_P2P_HANDLE_BYTES), and from then on vbnn_p2p_allreduce(offset, n) sums arena[offset, offset + n) over the ranks
+ * in place: ordered behind the context's stream, run on a high-priority stream of its own, the sum formed in rank order (bitwise
+ * the same arena on every rank). vbnn_p2p_finish orders the context's stream behind it. Every rank issues the same sequence.
+ * A barrier whose peers never arrive gives up after about two seconds instead of hanging the device: vbnn_p2p_status (blocking)
+ * reports it. At most 8 ranks (one node); peers on other devices need peer access (xGMI / PCIe P2P). */
+#define VBNN_P2P_HANDLE_BYTES 128
+typedef struct vbnn_p2p vbnn_p2p;
+int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_floats, vbnn_p2p** out, void** arena_out, void* handle_out);
+int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles);
+int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n);
+int vbnn_p2p_finish(vbnn_p2p* p);
+int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up);
+int vbnn_p2p_destroy(vbnn_p2p* p);
+
 /* ---- a whole step as ONE graph launch (launch-bound configurations: BASELINE configs[1], the reference's own batch-1
  * S = 30 operating point, config.lua:11,32) ----------------------------------------------------------------------------
  * mlp:sample() (mlp.lua:69-74) on the device: *draw_dev += by, ordered on the context's stream like any launch. With

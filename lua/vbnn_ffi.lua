@@ -148,6 +148,13 @@ int vbnn_comm_finish(vbnn_comm* comm);
 int vbnn_allreduce_grads_bf16(vbnn_comm* comm, void* buf_bf16, int64_t n);
 int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int64_t n);
 int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
+typedef struct vbnn_p2p vbnn_p2p;
+int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_floats, vbnn_p2p** out, void** arena_out, void* handle_out);
+int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles);
+int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n);
+int vbnn_p2p_finish(vbnn_p2p* p);
+int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up);
+int vbnn_p2p_destroy(vbnn_p2p* p);
 int vbnn_sample(vbnn_ctx* ctx, uint32_t* draw_dev, uint32_t by);
 typedef struct vbnn_graph vbnn_graph;
 int vbnn_capture_begin(vbnn_ctx* ctx);

@@ -33,10 +33,14 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hid
     from vbnn_amd.nn import fill_normal
     out = str(tmp_path / "r")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    if os.environ.get("VBNN_EXCHANGE_FOR_WORKER"):
+        env["VBNN_EXCHANGE"] = os.environ["VBNN_EXCHANGE_FOR_WORKER"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), out, dtype, hidden, str(I0), str(N), xdt, str(S)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    if os.environ.get("VBNN_EXCHANGE_FOR_WORKER") == "p2p":
+        assert res.stdout.count("exchange: vbnn_p2p/ipc") == 2, res.stdout[-1500:]
     got = np.load(out + ".grads.npy")
     loss2 = float(np.load(out + ".loss.npy")[0])
     opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=S, mode="lrt", dtype=dtype, seed=3, input_size=I0,
@@ -91,3 +95,29 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2p_exchange_sums_peer_mapped_arenas_bitwise(world):
+    """vbnn_p2p_* (csrc/p2p.hip): the exchange without a collective library -- IPC-mapped arenas, a reduce-scatter and an
+    all-gather kernel, flag-page barriers -- with `world` processes sharing the box's one GPU: every rank ends with, bitwise,
+    the rank-ordered fp32 sum of every region (aligned and odd offsets, lengths that do not divide by the world), three
+    rounds, no barrier ever giving up."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_p2p_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    print("\n".join(l for l in res.stdout.splitlines() if "rank" in l))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count("bitwise equal") == 3 * world
+
+
+def test_two_ranks_through_the_p2p_exchange_match_the_single_process_step(tmp_path):
+    """The engine's two-rank step with opt.exchange = "p2p" (VBNN_EXCHANGE=p2p): the gradient arena is the exchange's own
+    IPC-exported allocation, the buckets are all-reduced by vbnn_p2p_allreduce inside the step."""
+    os.environ["VBNN_EXCHANGE_FOR_WORKER"] = "p2p"
+    try:
+        test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, "bf16", "512,256", 256, 512, 2e-3, "f32", 1)
+    finally:
+        os.environ.pop("VBNN_EXCHANGE_FOR_WORKER", None)
+

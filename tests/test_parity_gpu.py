@@ -1261,6 +1261,40 @@ def test_rccl_exchange_through_the_c_abi_one_rank(nnmod):
     ex.close()
 
 
+def test_p2p_exchange_with_one_rank_and_engine_arena(nnmod):
+    """vbnn_p2p_* with a world of one (all an in-process test can host; tests/test_dist_gpu.py runs 2 and 3 ranks): the arena is
+    the exchange's own allocation wrapped as a tensor without a copy, an all-reduce leaves it unchanged and is ordered between
+    producer and consumer on the compute stream, and an engine with opt.exchange = "p2p" keeps its gradients in that arena and
+    computes bitwise what the plain engine computes."""
+    from vbnn_amd.comm import P2PExchange
+    from vbnn_amd.engine import FusedMLP
+    ctx = nnmod.Context.get()
+    ex = P2PExchange(ctx, 0, 1, 1_000_003)
+    assert ex.backend == "vbnn_p2p/ipc" and ex.arena.numel() == 1_000_003 and float(ex.arena.abs().sum()) == 0.0
+    for rep in range(2):
+        ex.arena.normal_()
+        want = ex.arena.clone()
+        ex.allreduce(ex.arena[5:900_000])
+        ex.finish()
+        got = ex.arena * 1.0
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and ex.gave_up() == 0
+    ex.close()
+    x = torch.empty(64, 70, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = (torch.arange(64, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    arenas = []
+    for kind in ("", "p2p"):
+        eng = FusedMLP(opt_for("lrt", "bf16", input_size=70, hidden=[50, 34], fuse_kl=True, exchange=kind), force_reduce=bool(kind))
+        for _ in range(2):
+            eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t); eng.finish()
+        torch.cuda.synchronize()
+        if kind:
+            assert eng.comm_backend() == "vbnn_p2p/ipc" and eng.exchange().gave_up() == 0
+        arenas.append(eng.grads.clone())
+    assert torch.equal(arenas[0], arenas[1])
+
+
 @pytest.mark.parametrize("hidden,I0,N", [([50, 34], 70, 64), ([512, 256], 256, 512)])
 def test_bf16_exchange_option_with_one_rank(nnmod, hidden, I0, N):
     """opt.exchange_dtype = "bf16" (the optional half-size exchange) through RCCL with a world of one: every bucket is

@@ -117,6 +117,12 @@ _SIGS = {
     "vbnn_allreduce_grads_bf16": ([_vp, _vp, _i64], _i),
     "vbnn_cast_grads": ([_vp, _i, _vp, _vp, _i64], _i),
     "vbnn_comm_allgather_u64": ([_vp, _vp, _vp], _i),
+    "vbnn_p2p_create": ([_vp, _i, _i, C.c_size_t, C.POINTER(_vp), C.POINTER(_vp), _vp], _i),
+    "vbnn_p2p_connect": ([_vp, _vp], _i),
+    "vbnn_p2p_allreduce": ([_vp, C.c_size_t, _i64], _i),
+    "vbnn_p2p_finish": ([_vp], _i),
+    "vbnn_p2p_status": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_uint)], _i),
+    "vbnn_p2p_destroy": ([_vp], _i),
     "vbnn_sample": ([_vp, _vp, _u32], _i),
     "vbnn_capture_begin": ([_vp], _i),
     "vbnn_capture_end": ([_vp, C.POINTER(_vp)], _i),

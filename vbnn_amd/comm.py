@@ -79,6 +79,60 @@ class RcclExchange:
             self.h = None
 
 
+class _DevArray:
+    """A device allocation of the library's as something torch.as_tensor can wrap without copying."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class P2PExchange:
+    """vbnn_p2p_*: direct reduce-scatter + all-gather over peer-mapped arenas (xGMI), no collective library. It OWNS the
+    gradient arena (one exportable hipMalloc allocation): the engine takes `self.arena` as its flat gradient tensor.
+    `process_group` (any backend) only carries the 128-byte IPC handles, once."""
+
+    def __init__(self, ctx, rank, world, arena_floats, process_group=None):
+        lib = L.lib()
+        self.ctx, self.rank, self.world = ctx, rank, world
+        h, arena = C.c_void_p(), C.c_void_p()
+        mine = (C.c_ubyte * 128)()
+        L.check(lib.vbnn_p2p_create(ctx.h, rank, world, arena_floats, C.byref(h), C.byref(arena), mine))
+        self.h, self._ptr = h, arena.value
+        if world > 1:
+            import torch.distributed as dist
+            box = [None] * world
+            dist.all_gather_object(box, bytes(mine), group=process_group)
+            allh = (C.c_ubyte * (128 * world)).from_buffer_copy(b"".join(box))
+            L.check(lib.vbnn_p2p_connect(h, allh))
+        else:
+            L.check(lib.vbnn_p2p_connect(h, None))
+        self._keep = _DevArray(self._ptr, arena_floats)
+        self.arena = torch.as_tensor(self._keep, device=ctx.device)
+        assert self.arena.data_ptr() == self._ptr and self.arena.dtype == torch.float32
+        self.backend = "vbnn_p2p/ipc"
+
+    def allreduce(self, bucket):
+        assert bucket.dtype == torch.float32 and bucket.is_contiguous()
+        off = bucket.data_ptr() - self._ptr
+        assert off >= 0 and off % 4 == 0 and off // 4 + bucket.numel() <= self.arena.numel(), "the bucket must lie in the exchange's arena"
+        L.check(L.lib().vbnn_p2p_allreduce(self.h, off // 4, bucket.numel()))
+
+    def finish(self):
+        L.check(L.lib().vbnn_p2p_finish(self.h))
+
+    def gave_up(self):
+        """Blocks until the exchange stream is idle; the epoch of a barrier that timed out waiting for a peer, or 0."""
+        g = C.c_uint()
+        L.check(L.lib().vbnn_p2p_status(self.h, None, None, C.byref(g)))
+        return g.value
+
+    def close(self):
+        if self.h:
+            self.arena = None
+            L.check(L.lib().vbnn_p2p_destroy(self.h))
+            self.h = None
+
+
 def make_exchange(ctx, rank, world, process_group=None):
     """RCCL through the C ABI unless VBNN_EXCHANGE=torch (or the torch backend is not nccl: a gloo rehearsal has no
     device per rank for RCCL); a failure to bind librccl falls back to torch.distributed and says so.

@@ -1,0 +1,258 @@
+// p2p.hip -- the data-parallel exchange WITHOUT a collective library: a direct reduce-scatter + all-gather over peer-mapped
+// gradient arenas (include/vbnn_hip.h, vbnn_p2p_*). SURVEY.md section 5's fallback for the case that RCCL serialises the SUM
+// all-reduce of a 160 MB arena onto one ring: on an 8-GPU MI355X node every GPU has seven point-to-point xGMI links, a ring
+// is bound by ONE of them (2 (7/8) 160 MB / 153 GB/s = 1.8 ms, twice the compute step), while a direct exchange moves an
+// eighth of the bucket over EACH link at once in both phases (0.26 ms by the same arithmetic).
+//
+//   memory     every rank's arena is ONE hipMalloc allocation owned by this library and exported with hipIpcGetMemHandle; the
+//              host hands the 128-byte handles (arena + flag page) round by its own means (as RCCL's unique id) and every rank
+//              maps its peers' (hipIpcOpenMemHandle): kernels then read a peer's arena over xGMI like local memory.
+//   all-reduce of arena[off, off + n), in place, on the exchange stream (ordered behind the compute stream by an event):
+//     barrier   every rank's bucket is complete (each rank signals behind its own accGradParameters)
+//     reduce-scatter   rank r sums chunk r of every rank's bucket IN RANK ORDER into its own arena (7 remote reads + 1 local
+//                      per element, one link per peer) -- nobody else reads or writes that chunk of rank r's arena
+//     barrier   every chunk is reduced
+//     all-gather       rank r copies chunk q (q != r) from rank q's arena into its own
+//     barrier   nobody still reads this rank's chunk: the arena may be overwritten (the next minibatch)
+//   The sum has ONE order (rank 0 + rank 1 + ...), so every rank holds bitwise the same arena afterwards.
+//   coherence  data crosses devices only at KERNEL BOUNDARIES (a kernel's stores are written back when it ends, a kernel's
+//              loads see them when it starts after the barrier kernel that observed the producer's signal): the arena is
+//              ordinary coarse-grained memory at full speed. Only the barrier's flag words are polled while a kernel runs:
+//              they live in an uncached (fine-grained) page and are accessed with system-scope atomics.
+//   barrier    a one-workgroup kernel: lane p stores this rank's epoch into slot `rank` of peer p's flag page and polls slot p
+//              of its own page. The poll is BOUNDED (about a second): a peer that never arrives makes the barrier give up and
+//              raise the status word (vbnn_p2p_status) instead of hanging the device.
+// The reference has nothing of this (single process, main.lua:142 sets BLAS threads): the exchange step is north_star's.
+#include "common.h"
+
+constexpr int P2P_MAX_WORLD = 8;
+constexpr unsigned P2P_SPIN_LIMIT = 1u << 21;              // x s_sleep(32) = 2048 cycles each: about two seconds
+
+struct P2PFlags { unsigned* page[P2P_MAX_WORLD]; };
+struct P2PArenas { float* a[P2P_MAX_WORLD]; };
+
+__global__ __launch_bounds__(64) void k_p2p_barrier(P2PFlags peers, unsigned* mine, int rank, int world, unsigned epoch, unsigned* status) {
+    const int p = threadIdx.x;
+    if (p >= world) return;
+    __hip_atomic_store(peers.page[p] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    bool ok = false;
+    for (unsigned spin = 0; spin < P2P_SPIN_LIMIT; ++spin) {
+        const unsigned seen = __hip_atomic_load(mine + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)(seen - epoch) >= 0) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (!ok) __hip_atomic_store(status, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // gave up: never hang the device
+}
+
+// out[i] = sum over ranks p = 0 .. world - 1 of arena_p[base + i], i in [0, n): into this rank's own arena
+__global__ __launch_bounds__(256) void k_p2p_reduce_scatter(P2PArenas peers, int rank, int world, size_t base, int64_t n, int vec) {
+    float* out = peers.a[rank] + base;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            f32x4 s = reinterpret_cast<const f32x4*>(peers.a[0] + base)[i];
+            for (int p = 1; p < world; ++p) s += reinterpret_cast<const f32x4*>(peers.a[p] + base)[i];
+            reinterpret_cast<f32x4*>(out)[i] = s;
+        }
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            float s = peers.a[0][base + i];
+            for (int p = 1; p < world; ++p) s += peers.a[p][base + i];
+            out[i] = s;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            float s = peers.a[0][base + i];
+            for (int p = 1; p < world; ++p) s += peers.a[p][base + i];
+            out[i] = s;
+        }
+    }
+}
+
+// mine[base_q + i] = arena_q[base_q + i] for every peer chunk q != rank (blockIdx.y = q)
+__global__ __launch_bounds__(256) void k_p2p_all_gather(P2PArenas peers, int rank, size_t off, int64_t n, int64_t cs, int vec) {
+    const int q = blockIdx.y;
+    if (q == rank) return;
+    const int64_t c0 = (int64_t)q * cs;
+    const int64_t cn = min(cs, n - c0);
+    if (cn <= 0) return;
+    const float* src = peers.a[q] + off + c0;
+    float* dst = peers.a[rank] + off + c0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (vec) {
+        const int64_t n4 = cn >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+            reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < cn; i += stride) dst[i] = src[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cn; i += stride) dst[i] = src[i];
+    }
+}
+
+struct vbnn_p2p {
+    vbnn_ctx* ctx;
+    int rank, world;
+    float* arena; size_t arena_floats;
+    unsigned* flags;                 // this rank's flag page: slot p is written by peer p
+    unsigned* status;                // device word (same uncached page, slot P2P_MAX_WORLD): epoch of a barrier that gave up, else 0
+    P2PArenas arenas;                // every rank's arena as THIS process maps it (own pointer at [rank])
+    P2PFlags pages;
+    bool connected;
+    hipStream_t stream;
+    hipEvent_t ready, done;
+    int64_t pending;
+    unsigned epoch;
+};
+
+static_assert(VBNN_P2P_HANDLE_BYTES == 2 * sizeof(hipIpcMemHandle_t), "the handle the host passes round: arena + flag page");
+
+extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_floats, vbnn_p2p** out, void** arena_out, void* handle_out) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && out && arena_out && handle_out, "null argument");
+    VBNN_REQUIRE(world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world, "rank / world (at most 8 ranks: one node)");
+    VBNN_REQUIRE(arena_floats > 0, "arena size");
+    VBNN_CHECK_HIP(hipSetDevice(ctx->device));
+    vbnn_p2p* p = new vbnn_p2p();
+    p->ctx = ctx; p->rank = rank; p->world = world; p->arena_floats = arena_floats; p->pending = 0; p->epoch = 0; p->connected = world == 1;
+    hipError_t e = hipMalloc((void**)&p->arena, arena_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(p->arena, 0, arena_floats * sizeof(float));
+    // the flag page is polled by running kernels of OTHER devices: uncached (fine-grained) memory
+    if (e == hipSuccess) e = hipExtMallocWithFlags((void**)&p->flags, 4096, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(p->flags, 0, 4096);
+    if (e != hipSuccess) {
+        vbnn_set_error("p2p arena / flag page: %s", hipGetErrorString(e));
+        if (p->arena) (void)hipFree(p->arena);
+        if (p->flags) (void)hipFree(p->flags);
+        delete p;
+        return VBNN_ERR_NOMEM;
+    }
+    p->status = p->flags + P2P_MAX_WORLD;
+    for (int q = 0; q < P2P_MAX_WORLD; ++q) { p->arenas.a[q] = nullptr; p->pages.page[q] = nullptr; }
+    p->arenas.a[rank] = p->arena; p->pages.page[rank] = p->flags;
+    hipIpcMemHandle_t h[2];
+    memset(h, 0, sizeof h);
+    if (world > 1) {
+        e = hipIpcGetMemHandle(&h[0], p->arena);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&h[1], p->flags);
+    }
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, greatest);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        vbnn_set_error("p2p export / stream: %s", hipGetErrorString(e));
+        (void)hipFree(p->arena); (void)hipFree(p->flags);
+        delete p;
+        return VBNN_ERR_HIP;
+    }
+    memcpy(handle_out, h, sizeof h);
+    *arena_out = p->arena;
+    *out = p;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p && (all_handles || p->world == 1), "argument");
+    if (p->connected) return VBNN_OK;
+    VBNN_CHECK_HIP(hipSetDevice(p->ctx->device));
+    const hipIpcMemHandle_t* h = static_cast<const hipIpcMemHandle_t*>(all_handles);
+    for (int q = 0; q < p->world; ++q) {
+        if (q == p->rank) continue;
+        void* a = nullptr; void* f = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&a, h[2 * q], hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) e = hipIpcOpenMemHandle(&f, h[2 * q + 1], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { vbnn_set_error("hipIpcOpenMemHandle(rank %d's arena / flags): %s", q, hipGetErrorString(e)); return VBNN_ERR_HIP; }
+        p->arenas.a[q] = static_cast<float*>(a);
+        p->pages.page[q] = static_cast<unsigned*>(f);
+    }
+    p->connected = true;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+static int p2p_barrier(vbnn_p2p* p) {
+    p->epoch += 1;
+    hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, p->stream, p->pages, p->flags, p->rank, p->world, p->epoch, p->status);
+    return vbnn_check_launch("k_p2p_barrier");
+}
+
+extern "C" int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p && n > 0 && offset_floats + (size_t)n <= p->arena_floats, "bucket outside the arena");
+    VBNN_REQUIRE(p->connected, "vbnn_p2p_connect first");
+    // everything enqueued on the compute stream so far (the accGradParameters launch that fills the bucket) comes first
+    VBNN_CHECK_HIP(hipEventRecord(p->ready, p->ctx->stream));
+    VBNN_CHECK_HIP(hipStreamWaitEvent(p->stream, p->ready, 0));
+    p->pending += 1;
+    if (p->world == 1) return VBNN_OK;                            // the sum over one rank (still ordered: finish waits for the stream)
+    const int W = p->world;
+    const int64_t cs = ((n + W - 1) / W + 3) / 4 * 4;             // chunk length: a multiple of 4 floats
+    const int vec = (offset_floats % 4 == 0) ? 1 : 0;             // (hipMalloc bases are 256-byte aligned in every process)
+    const int64_t c0 = (int64_t)p->rank * cs, cn = n - c0 < cs ? n - c0 : cs;
+    int st = p2p_barrier(p);
+    if (st != VBNN_OK) return st;
+    if (cn > 0) {
+        const unsigned nb = (unsigned)(((cn + 3) / 4 + 255) / 256 < 1024 ? ((cn + 3) / 4 + 255) / 256 : 1024);
+        hipLaunchKernelGGL(k_p2p_reduce_scatter, dim3(nb ? nb : 1), dim3(256), 0, p->stream, p->arenas, p->rank, W, offset_floats + (size_t)c0, cn, vec);
+    }
+    st = p2p_barrier(p);
+    if (st != VBNN_OK) return st;
+    {
+        const unsigned nb = (unsigned)(((cs + 3) / 4 + 255) / 256 < 256 ? ((cs + 3) / 4 + 255) / 256 : 256);
+        hipLaunchKernelGGL(k_p2p_all_gather, dim3(nb ? nb : 1, W), dim3(256), 0, p->stream, p->arenas, p->rank, offset_floats, n, cs, vec);
+    }
+    st = p2p_barrier(p);
+    if (st != VBNN_OK) return st;
+    return vbnn_check_launch("vbnn_p2p_allreduce");
+    VBNN_API_END
+}
+
+extern "C" int vbnn_p2p_finish(vbnn_p2p* p) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p, "null p2p");
+    if (p->pending == 0) return VBNN_OK;
+    VBNN_CHECK_HIP(hipEventRecord(p->done, p->stream));
+    VBNN_CHECK_HIP(hipStreamWaitEvent(p->ctx->stream, p->done, 0));
+    p->pending = 0;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+// blocks until the exchange stream is idle; *gave_up = the epoch of a barrier whose peers never arrived (0: none)
+extern "C" int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p, "null p2p");
+    if (rank) *rank = p->rank;
+    if (world) *world = p->world;
+    if (gave_up) {
+        VBNN_CHECK_HIP(hipStreamSynchronize(p->stream));
+        unsigned v = 0;
+        VBNN_CHECK_HIP(hipMemcpy(&v, p->status, sizeof v, hipMemcpyDeviceToHost));
+        *gave_up = v;
+    }
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_p2p_destroy(vbnn_p2p* p) {
+    VBNN_API_BEGIN
+    if (!p) return VBNN_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->stream);
+    for (int q = 0; q < p->world; ++q) {
+        if (q == p->rank) continue;
+        if (p->arenas.a[q]) (void)hipIpcCloseMemHandle(p->arenas.a[q]);
+        if (p->pages.page[q]) (void)hipIpcCloseMemHandle(p->pages.page[q]);
+    }
+    (void)hipEventDestroy(p->ready);
+    (void)hipEventDestroy(p->done);
+    (void)hipStreamDestroy(p->stream);
+    (void)hipFree(p->arena);
+    (void)hipFree(p->flags);
+    delete p;
+    return VBNN_OK;
+    VBNN_API_END
+}

@@ -121,7 +121,17 @@ class FusedMLP:
         self.early_lv = list(el)
         lay, fin, n_g, self._bucket_ranges = partition.arena_layout(sizes, self.n_classes, self.early_lv)
         self._lay = lay
-        self.grads = torch.zeros(n_g, **f32)
+        # opt.exchange = "p2p" (or VBNN_EXCHANGE=p2p): the direct reduce-scatter + all-gather over peer-mapped arenas
+        # (vbnn_p2p_*, csrc/p2p.hip) instead of RCCL; that exchange owns the arena (an IPC-exportable allocation of the library's)
+        import os
+        self.exchange_kind = str(opt.get("exchange", os.environ.get("VBNN_EXCHANGE", "")) or "")
+        if self.reduce and self.exchange_kind == "p2p":
+            assert self.exchange_dtype == "f32", "the p2p exchange sums fp32 arenas"
+            from .comm import P2PExchange
+            self._exchange = P2PExchange(self.ctx, rank, world_size, n_g, process_group)
+            self.grads = self._exchange.arena
+        else:
+            self.grads = torch.zeros(n_g, **f32)
 
         def take(span, shape):
             return self.grads[span[0]:span[0] + span[1]].view(*shape)
@@ -726,7 +736,10 @@ class FusedMLP:
         import time
         out = []
         for b in self.buckets():
-            scratch = torch.zeros_like(b) if self.exchange_dtype == "f32" else torch.zeros(b.numel(), dtype=torch.bfloat16, device=b.device)
+            if self.exchange_kind == "p2p":
+                scratch = b                                # the p2p exchange sums regions of ITS arena: time it on the bucket itself
+            else:
+                scratch = torch.zeros_like(b) if self.exchange_dtype == "f32" else torch.zeros(b.numel(), dtype=torch.bfloat16, device=b.device)
             for _ in range(2):
                 self.exchange().allreduce(scratch); self.finish()
             torch.cuda.synchronize(self.device)
