@@ -122,6 +122,73 @@ def test_two_rank_allreduce_equals_single_process():
     np.testing.assert_allclose(flat2, flat1, rtol=5e-6, atol=1e-8)
 
 
+def _agree_worker(rank, world, port, q, break_probe_on):
+    """One rank of comm.make_exchange's collective decision on the CPU: there is no HIP device here, so building the RCCL
+    communicator cannot succeed -- what must hold is that every rank reaches the SAME fallback without waiting for a peer
+    that took another path (rank 0 raising before the id broadcast left the others in it)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from vbnn_amd import _lib as L
+    from vbnn_amd import comm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["VBNN_EXCHANGE"] = "rccl"                      # take the RCCL attempt although the out-of-band group is gloo
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Ctx:                                                # no device: vbnn_comm_create must fail on every rank
+        h = None
+        device = torch.device("cpu")
+    if rank == break_probe_on:                                # this rank cannot even bind librccl
+        lib = L.lib()
+        real = lib.vbnn_comm_unique_id
+
+        class Broken:
+            def __getattr__(self, name):
+                if name == "vbnn_comm_unique_id":
+                    return lambda buf: 4
+                return getattr(lib, name)
+        L._lib = Broken()
+        try:
+            ex = comm.make_exchange(Ctx(), rank, world)
+        finally:
+            L._lib = lib
+        assert real is lib.vbnn_comm_unique_id
+    else:
+        ex = comm.make_exchange(Ctx(), rank, world)
+    t = torch.tensor([float(rank + 1)])
+    ex.allreduce(t); ex.finish()                              # the chosen transport works, on every rank
+    q.put((rank, ex.backend, float(t[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("break_probe_on", [-1, 1])
+def test_exchange_backend_decision_is_collective(break_probe_on):
+    """Two gloo ranks call comm.make_exchange with the RCCL path forced. -1: every rank can bind librccl (or none can) and the
+    communicator cannot be built (no device): all fall back after the SECOND agreement. 1: rank 1 alone cannot bind it: all
+    fall back at the FIRST agreement, nobody is left in the unique-id broadcast. Either way both ranks return the same
+    transport within the timeout and an all-reduce through it gives 1 + 2."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q, break_probe_on)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=200) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == [0, 1] and all(g[2] == 3.0 for g in got), got
+    assert all(g[1].startswith("torch.distributed/gloo") for g in got), got
+    assert ("unavailable on some rank" in got[0][1]) == ("unavailable on some rank" in got[1][1])
+    assert ("vbnn_comm_create failed" in got[0][1]) == ("vbnn_comm_create failed" in got[1][1])
+    if break_probe_on >= 0:
+        assert all("unavailable on some rank" in g[1] for g in got), got
+
+
 def test_partition_host_logic():
     """Row shards tile the global batch; the scales make a plain SUM the global-batch mean; the arena is covered once."""
     from vbnn_amd import partition
