@@ -17,8 +17,12 @@
 //   The sum has ONE order (rank 0 + rank 1 + ...), so every rank holds bitwise the same arena afterwards.
 //   coherence  data crosses devices only at KERNEL BOUNDARIES (a kernel's stores are written back when it ends, a kernel's
 //              loads see them when it starts after the barrier kernel that observed the producer's signal): the arena is
-//              ordinary coarse-grained memory at full speed. Only the barrier's flag words are polled while a kernel runs:
-//              they live in an uncached (fine-grained) page and are accessed with system-scope atomics.
+//              ordinary coarse-grained memory at full speed. On this chip that is not an assumption about the runtime's
+//              fence scopes but a necessity of the hardware: the eight XCDs' L2s are not coherent with EACH OTHER
+//              (MI355X_MICROARCH.md), so consecutive kernels of one device already need every L2 written back to memory at
+//              a kernel's end and non-coherent lines dropped at the next kernel's start -- a peer's read over xGMI is
+//              served by the owner's memory side, behind that write-back. Only the barrier's flag words are polled while
+//              a kernel runs: they live in an uncached (fine-grained) page and are accessed with system-scope atomics.
 //   barrier    a one-workgroup kernel: lane p stores this rank's epoch into slot `rank` of peer p's flag page and polls slot p
 //              of its own page. The poll is BOUNDED (about a second): a peer that never arrives makes the barrier give up and
 //              raise the status word (vbnn_p2p_status) instead of hanging the device.
