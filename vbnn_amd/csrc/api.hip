@@ -111,6 +111,7 @@ extern "C" int vbnn_ctx_destroy(vbnn_ctx* ctx) {
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->park) (void)hipFree(ctx->park);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->cu_budget > 0 && g_cu_budget_plan == ctx->cu_budget) g_cu_budget_plan = 0;     // the process plans for the whole device again
     delete ctx;
     return VBNN_OK;
     VBNN_API_END

@@ -828,6 +828,10 @@ class FusedMLP:
     def loss_and_accuracy(self):
         self.finish()
         torch.cuda.synchronize(self.device)
+        if self._exchange is not None and hasattr(self._exchange, "gave_up"):
+            epoch = self._exchange.gave_up()             # (p2p exchange) a barrier whose peers never arrived: the sums are not sums
+            if epoch:
+                raise RuntimeError(f"vbnn_p2p: barrier {epoch} gave up waiting for a peer rank -- the gradient arena is incomplete")
         loss = float(self._acc[0].item())
         correct = int(self._corr[0].item())
         return loss, correct
