@@ -983,7 +983,7 @@ print("budget", budget, "cus", getattr(eng.ctx, "cu_budget", None), "loss", repr
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
 
 
-@pytest.mark.parametrize("hidden,I0,N", [([400, 400], 784, 256), ([50, 34], 70, 37), ([64, 48, 40], 128, 100)])
+@pytest.mark.parametrize("hidden,I0,N", [([400, 400], 784, 256), ([50, 34], 70, 37), ([64, 48, 40], 128, 100), ([256, 48, 40], 64, 33)])
 def test_backward_pair_launch_is_bitwise_the_two_launches(nnmod, hidden, I0, N):
     """vbnn_backward_pair (accGradParameters + updateGradInput of a layer as ONE launch on the fp32 path) against the same engine
     with the two calls issued separately (opt.keep_transposes: the packed / transposed operand path of r02, separate launches):
