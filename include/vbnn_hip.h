@@ -63,6 +63,7 @@ const char* vbnn_last_error(void);
                                       gradients only): -1 = by shape (default), 0 = never, 1 = whenever possible */
 #define VBNN_DEBUG_V3_SPLIT 8      /* two-pass kernel's pair-split + split-K launch for few-tile parameter gradients: -1 = by shape (default), 0 = never, 1 = whenever possible */
 #define VBNN_DEBUG_FAKE_NOISE 7    /* TIMING ONLY, wrong results: 1 = the two-pass kernel's forward fold skips the Philox draw */
+#define VBNN_DEBUG_V0 9            /* fp32 shapes of the launch-bound geometry: 1 = the latency kernel (gemm_v0.h; default), 0 = gemm_v1's 32 x 32 tile */
 #define VBNN_DEBUG_KMAJOR 6        /* K-major operands (gemm_v3.h AK / BK): 1 = use when the shape allows (default), 0 = never, 2 = gemm_v3 only */
 int vbnn_debug_set(int key, int value);
 

@@ -1004,6 +1004,34 @@ def test_backward_pair_launch_is_bitwise_the_two_launches(nnmod, hidden, I0, N):
     assert torch.equal(res[0][0], res[1][0])
 
 
+@pytest.mark.parametrize("hidden,I0,N", [([400, 400], 784, 256), ([50, 34], 70, 37), ([64, 48, 40], 128, 100), ([256, 48, 40], 64, 33)])
+def test_latency_kernel_agrees_with_the_general_kernel(nnmod, hidden, I0, N):
+    """The fp32 step on the latency kernel (csrc/gemm_v0.h: 16-row tiles, K split over the workgroup's waves, fragments straight
+    from global memory) against the same step on gemm_v1's LDS-staged 32 x 32 tile (vbnn_debug_set(VBNN_DEBUG_V0, 0)): the two
+    differ in summation order only -- the same Philox draws, the same operands -- so loss and gradients agree to rounding. (Each
+    is compared with the oracle by the parity tests of this file under the default, the latency kernel.)"""
+    from vbnn_amd import _lib as L
+    from vbnn_amd.engine import FusedMLP
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    res = []
+    try:
+        for v0 in (1, 0):
+            L.check(L.lib().vbnn_debug_set(9, v0))
+            eng = FusedMLP(opt_for("lrt", "f32", input_size=I0, hidden=hidden, S=1, fuse_kl=True))
+            for _ in range(2):
+                eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t); eng.finish()
+            loss, _ = eng.loss_and_accuracy()
+            res.append((eng.grads.clone(), loss))
+    finally:
+        L.check(L.lib().vbnn_debug_set(9, 1))
+    assert abs(res[0][1] - res[1][1]) <= 2e-6 * abs(res[1][1])
+    assert not torch.equal(res[0][0], res[1][0]), "the debug key selected nothing"
+    scale = float(res[1][0].abs().max())
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * scale
+
+
 # ------------------------------------------------------------------------------------------- update (SURVEY 8f next #1)
 OPT_STATES = dict(state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
 

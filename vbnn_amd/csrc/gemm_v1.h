@@ -28,6 +28,11 @@
 // The K order of every accumulation chain is unchanged: results are bitwise those of the packed / transposed operands.
 #pragma once
 #include "common.h"
+#include "gemm_v0.h"
+
+// 1 (default): the fp32 shapes of the 32 x 32 geometry run on the latency kernel (gemm_v0.h); 0: on this file's tile.
+// Test / A-B hook: vbnn_debug_set(VBNN_DEBUG_V0, ..).
+static int g_v0 = 1;
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x4 type; };
@@ -382,7 +387,13 @@ static int launch_gemm_v1_form(hipStream_t stream, const T* A, const T* A2, int6
         if (blocks64 >= 96) {
             dim3 grid((M + 63) / 64, (N + 63) / 64);
             hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 2, KS, Epi, TA, TB, SQ>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, K, ones_row, epi);
-        } else {        // latency-bound sizes (the 256 x 400 outputs of the small MLP): 32 x 32 tiles, 4x the blocks
+        } else {        // latency-bound sizes (the 256 x 400 outputs of the small MLP): the latency kernel, or 32 x 32 tiles, 4x the blocks
+            if constexpr (sizeof(T) == 4) {
+                if (g_v0) {
+                    const int st = launch_gemm_v0<DUAL, Epi, TA, TB, SQ>(stream, A, A2, lda, B, B2, ldb, M, N, K, epi, ones_row);
+                    if (st != VBNN_ERR_UNSUPPORTED) return st;
+                }
+            }
             dim3 grid((M + 31) / 32, (N + 31) / 32);
             hipLaunchKernelGGL((gemm_nt_v1<T, DUAL, 1, KS, Epi, TA, TB, SQ>), grid, dim3(256), 0, stream, A, A2, lda, B, B2, ldb, M, N, Kp, K, ones_row, epi);
         }
@@ -424,6 +435,21 @@ static int launch_gemm_v1_pair(hipStream_t stream, const float* A, const float* 
     if ((((uintptr_t)A | (uintptr_t)A2 | (uintptr_t)B | (uintptr_t)B2 | (uintptr_t)xA | (uintptr_t)gB | (uintptr_t)gvB) & 15u) != 0 ||
         lda % 4 || ldb % 4 || ldx % 4 || ldg % 4 || lda < M || ldx < M2 - (ones_row >= 0 ? 1 : 0) || ldg < N2)
         return VBNN_ERR_UNSUPPORTED;
+    if (g_v0 && v0_operands_ok<true, false>(A, A2, lda, B, B2, ldb, M, N, K, -1) &&
+        v0_operands_ok<true, true>(xA, nullptr, ldx, gB, gvB, ldg, M2, N2, K2, ones_row)) {
+        // the latency kernel's tiles, each problem with the tile its own launch would take (launch_gemm_v0)
+        const bool wide = v0_wide_tile(M, N);
+        const int gxa = (M + 15) / 16, gya = wide ? (N + 31) / 32 : (N + 15) / 16, gxb = (M2 + 15) / 16, gyb = (N2 + 15) / 16;
+        V0Problem<EpiA> qa{A, A2, lda, B, B2, ldb, M, N, K, -1, gxa, gxa * gya, epi_a};
+        V0Problem<EpiB> qb{xA, nullptr, ldx, gB, gvB, ldg, M2, N2, K2, ones_row, gxb, gxb * gyb, epi_b};
+        if (wide)
+            hipLaunchKernelGGL((gemm_nt_v0_pair<1, 2, DUAL, EpiA, true, false, 0, 1, 1, DUAL, EpiB, true, true, (DUAL ? 2 : 0)>),
+                               dim3(qa.blocks + qb.blocks), dim3(64 * V0_W), 0, stream, qa, qb);
+        else
+            hipLaunchKernelGGL((gemm_nt_v0_pair<1, 1, DUAL, EpiA, true, false, 0, 1, 1, DUAL, EpiB, true, true, (DUAL ? 2 : 0)>),
+                               dim3(qa.blocks + qb.blocks), dim3(64 * V0_W), 0, stream, qa, qb);
+        return vbnn_check_launch("gemm_nt_v0_pair");
+    }
     constexpr int KE2 = 32;
     V1Problem<float, EpiA> pa{A, A2, lda, B, B2, ldb, M, N, (K + KE2 - 1) / KE2 * KE2, K, -1, (M + 31) / 32, ((M + 31) / 32) * ((N + 31) / 32), epi_a};
     V1Problem<float, EpiB> pb{xA, nullptr, ldx, gB, gvB, ldg, M2, N2, (K2 + KE2 - 1) / KE2 * KE2, K2, ones_row, (M2 + 31) / 32,
