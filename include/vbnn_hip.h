@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
 #endif
 
-#define VBNN_ABI_VERSION 3
+#define VBNN_ABI_VERSION 4
 #define VBNN_KPAD 64            /* packed leading dimensions are multiples of this */
 
 enum { VBNN_OK = 0, VBNN_ERR_INVALID = 1, VBNN_ERR_HIP = 2, VBNN_ERR_NOMEM = 3, VBNN_ERR_UNSUPPORTED = 4 };
@@ -480,6 +480,33 @@ int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, co
                        float* gradBias, float* gradBias_prev, int relu_mask, const void* r_prev, int64_t ld_r_prev,
                        int r_prev_packed, void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev,
                        int64_t ld_gpT);
+
+/* mlp.lua:77-83 for the fused head in ONE call: model:forward's last three modules, criterion:forward / :backward and
+ * model:backward's first three -- exactly vbnn_head_forward followed by vbnn_head_backward on the same arguments (the
+ * fields below carry the names and meanings of those two calls' parameters). For fp32 at launch-bound sizes
+ * (N x H <= 2^20, H even, no transposed copies asked for) it is ONE launch: every workgroup recomputes the logits of its 16
+ * rows (same bits as vbnn_head_forward's) instead of waiting for a first kernel's g_logits, forms its 16 x 64 tile of the
+ * gradInput and its rows' terms of gradWeight / gradBias / gradBias_prev, and the last workgroup of a column block adds the
+ * partials in row order (bitwise reproducible; the sums are formed in a different order from vbnn_head_backward's, so
+ * the two paths agree to rounding). Everywhere else the call IS the two launches. */
+typedef struct vbnn_head_args {
+    const void* h; int64_t ld_h;            /* packed N x ld_h input of the final Linear */
+    const void* w3; int64_t ld_w;           /* packed C x ld_w weight */
+    const float* bias;                      /* C, or NULL */
+    const int32_t* target;                  /* rows_per_draw (stacked draws) or N entries */
+    int64_t N, H, C;
+    int64_t rows_per_draw;
+    float inv_n;
+    int32_t accumulate;                     /* of loss / hits and of the three gradients alike (the S draws of a minibatch) */
+    float* logits; float* out; float* g_logits;         /* N x C each; logits, out optional */
+    double* loss_sum_dev; int32_t* correct_dev;
+    float* gradWeight; float* gradBias; float* gradBias_prev;   /* C x H, C, H; NULL to skip */
+    int32_t relu_mask; int32_t r_prev_packed;
+    const void* r_prev; int64_t ld_r_prev;
+    void* g_prev; void* gv_prev; int64_t ld_gp;
+    void* gT_prev; void* gvT_prev; int64_t ld_gpT;
+} vbnn_head_args;
+int vbnn_head_forward_backward(vbnn_ctx* ctx, int dtype, const vbnn_head_args* a);
 
 /* The same criterion as separate modules, for the module-level call order of mlp.lua:77-80:
  * nn.LogSoftMax:updateOutput is vbnn_logsoftmax_nll with g_logits = loss = correct = NULL. */

@@ -196,13 +196,17 @@ function FusedMLP:run(inputs, ld, targets, N)
     end
     -- final Linear + LogSoftMax + ClassNLL (mlp.lua:29-32), forward and backward
     local vl, H = self.vb[#self.vb], self.sizes[#self.sizes]
-    check(C.vbnn_head_forward(vb.ctx, self.dtype, self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.bias3),
-                              ffi.cast('const int32_t*', targets), N, H, self.n_classes, inv_n, f32(self.logits), f32(self.out),
-                              f32(self.g_logits), accumulate, ffi.cast('double*', self.acc), ffi.cast('int32_t*', self.corr), 0))
-    check(C.vbnn_head_backward(vb.ctx, self.dtype, self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.g_logits), N, H,
-                               self.n_classes, accumulate, self.gradWeight3, self.gradBias3, vl.gradBias, 1, vl.r, vl.O, 1,
-                               vl.g_s.p, vl.gv_s.p, vl.g_s.ld, vl.has_t and vl.gT_s.p or nil, vl.has_t and vl.gvT_s.p or nil,
-                               vl.has_t and vl.gT_s.ld or 0))
+    local ha = ffi.new('vbnn_head_args')
+    ha.h, ha.ld_h, ha.w3, ha.ld_w, ha.bias = self.h_s.p, self.h_s.ld, self.w3_s.p, self.w3_s.ld, f32(self.bias3)
+    ha.target = ffi.cast('const int32_t*', targets)
+    ha.N, ha.H, ha.C, ha.rows_per_draw, ha.inv_n, ha.accumulate = N, H, self.n_classes, 0, inv_n, accumulate
+    ha.logits, ha.out, ha.g_logits = f32(self.logits), f32(self.out), f32(self.g_logits)
+    ha.loss_sum_dev, ha.correct_dev = ffi.cast('double*', self.acc), ffi.cast('int32_t*', self.corr)
+    ha.gradWeight, ha.gradBias, ha.gradBias_prev = self.gradWeight3, self.gradBias3, vl.gradBias
+    ha.relu_mask, ha.r_prev_packed, ha.r_prev, ha.ld_r_prev = 1, 1, vl.r, vl.O
+    ha.g_prev, ha.gv_prev, ha.ld_gp = vl.g_s.p, vl.gv_s.p, vl.g_s.ld
+    if vl.has_t then ha.gT_prev, ha.gvT_prev, ha.ld_gpT = vl.gT_s.p, vl.gvT_s.p, vl.gT_s.ld end
+    check(C.vbnn_head_forward_backward(vb.ctx, self.dtype, ha))
     -- backward. The argument blocks of layer li (no library call in these two):
     local function dw_block(li)
         local v = self.vb[li]

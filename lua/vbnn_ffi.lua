@@ -180,6 +180,24 @@ int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, co
                        float* gradBias, float* gradBias_prev, int relu_mask, const void* r_prev, int64_t ld_r_prev,
                        int r_prev_packed, void* g_prev, void* gv_prev, int64_t ld_gp, void* gT_prev, void* gvT_prev,
                        int64_t ld_gpT);
+typedef struct vbnn_head_args {
+    const void* h; int64_t ld_h;
+    const void* w3; int64_t ld_w;
+    const float* bias;
+    const int32_t* target;
+    int64_t N, H, C;
+    int64_t rows_per_draw;
+    float inv_n;
+    int32_t accumulate;
+    float* logits; float* out; float* g_logits;
+    double* loss_sum_dev; int32_t* correct_dev;
+    float* gradWeight; float* gradBias; float* gradBias_prev;
+    int32_t relu_mask; int32_t r_prev_packed;
+    const void* r_prev; int64_t ld_r_prev;
+    void* g_prev; void* gv_prev; int64_t ld_gp;
+    void* gT_prev; void* gvT_prev; int64_t ld_gpT;
+} vbnn_head_args;
+int vbnn_head_forward_backward(vbnn_ctx* ctx, int dtype, const vbnn_head_args* a);
 int vbnn_nll_forward(vbnn_ctx* ctx, const float* out, int64_t ld, const int32_t* target, int64_t N, int64_t C,
                      float inv_n, double* loss_sum_dev, int32_t* correct_dev);
 int vbnn_nll_backward(vbnn_ctx* ctx, const int32_t* target, int64_t N, int64_t C, float inv_n, float* g);

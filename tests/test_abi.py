@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes table covers exactly the header
     assert sorted(L.exported_symbols()) == names
     L.lib()
-    assert L.lib().vbnn_abi_version() == 3
+    assert L.lib().vbnn_abi_version() == 4
 
 
 def test_no_gpu_is_an_error_not_a_fallback():
@@ -63,7 +63,7 @@ def test_ctypes_structs_match_the_header():
     from vbnn_amd import _lib as L
     structs = {"vbnn_fwd_args": L.FwdArgs, "vbnn_dx_args": L.DxArgs, "vbnn_dw_args": L.DwArgs,
                "vbnn_prep_desc": L.PrepDesc, "vbnn_pack_desc": L.PackDesc, "vbnn_adam_cfg": L.AdamCfg,
-               "vbnn_update_desc": L.UpdateDesc}
+               "vbnn_update_desc": L.UpdateDesc, "vbnn_head_args": L.HeadArgs}
     cfield = lambda f: f.rstrip("_")                       # `lambda` is a Python keyword: the mirror calls it lambda_
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
@@ -218,7 +218,8 @@ def test_lua_fused_mlp_structure():
             lua_order.append(name)
     eng = open(os.path.join(ROOT, "vbnn_amd", "engine.py")).read()
     run = eng[eng.index("    def run(self, inputs, targets"):eng.index("            main, side, ctx2 =")]
-    run = run[:run.index("            self._generic_head(")] + run[run.index("        # ---------------- backward: VB layers"):]
+    # (the head: the one-call form is what the Lua host issues; engine.py's two-call branch -- test path, opt.head_step = False -- is cut)
+    run = run[:run.index("                L.check(lib.vbnn_head_forward(ctx")] + run[run.index("        # ---------------- backward: VB layers"):]
     py_order = []
     for m in re.finditer(r"lib\.(vbnn_[a-z0-9_]+)\(|self\.(_reduce)\(", run):
         name = m.group(1) or "vbnn_allreduce_grads"

@@ -932,7 +932,8 @@ def test_captured_step_is_bitwise_the_launched_step(nnmod, N, S, stack):
     # more sample for the stacked draws)
     # sample, two forwards, two head kernels, the layer-2 accGradParameters + updateGradInput PAIR launch, layer 1's
     # accGradParameters; stacked draws: + the packer (row n % rows_per_draw) and the closing sample(S - 1)
-    want_nodes = 9 if stack else 7 * S
+    # (r03 late: the head's forward + backward are one launch as well, vbnn_head_forward_backward)
+    want_nodes = 8 if stack else 6 * S
     assert g.kernel_nodes == g.nodes == want_nodes, (g.kernel_nodes, g.nodes, want_nodes)
     print(f"captured step: {g.kernel_nodes} kernel nodes")
     for step in range(1, 4):                                    # steps 2..4 as graph replays
@@ -994,7 +995,9 @@ def test_backward_pair_launch_is_bitwise_the_two_launches(nnmod, hidden, I0, N):
     t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
     res = []
     for keep in (False, True):
-        eng = FusedMLP(opt_for("lrt", "f32", input_size=I0, hidden=hidden, S=1, fuse_kl=True, keep_transposes=keep))
+        # (head_step = False: the head as its two launches in both engines -- its one-launch form does not write the transposed
+        # copies the r02 path wants, and sums gradWeight3 in another order)
+        eng = FusedMLP(opt_for("lrt", "f32", input_size=I0, hidden=hidden, S=1, fuse_kl=True, keep_transposes=keep, head_step=False))
         for _ in range(2):
             eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t); eng.finish()
         loss, _ = eng.loss_and_accuracy()
@@ -1030,6 +1033,33 @@ def test_latency_kernel_agrees_with_the_general_kernel(nnmod, hidden, I0, N):
     assert not torch.equal(res[0][0], res[1][0]), "the debug key selected nothing"
     scale = float(res[1][0].abs().max())
     assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("hidden,I0,N,S", [([400, 400], 784, 256, 1), ([50, 34], 70, 37, 2), ([64, 48, 40], 128, 100, 1), ([48, 130], 64, 16, 3)])
+def test_head_as_one_launch_agrees_with_its_two_launches(nnmod, hidden, I0, N, S):
+    """vbnn_head_forward_backward (mlp.lua:77-83 for the fused head in one call; fp32 at launch-bound sizes: ONE launch that
+    recomputes the logits per workgroup) against vbnn_head_forward + vbnn_head_backward (opt.head_step = False): logits, output,
+    d(loss)/d(logits) and the loss bit for bit (the same K split and MFMA order), the gradients to summation-order rounding --
+    ragged shapes, S accumulated draws."""
+    from vbnn_amd.engine import FusedMLP
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    res = []
+    for one in (True, False):
+        eng = FusedMLP(opt_for("lrt", "f32", input_size=I0, hidden=hidden, S=S, fuse_kl=True, head_step=one))
+        eng.resetGradients(); eng.prepare()
+        for _ in range(S):
+            eng.sample(); eng.run(x, t)
+        eng.finish()
+        loss, acc = eng.loss_and_accuracy()
+        res.append((eng.grads.clone(), loss, acc, eng.logits.clone(), eng.out.clone(), eng.g_logits.clone()))
+    a, b = res
+    assert a[1] == b[1] and a[2] == b[2]
+    for k in (3, 4, 5):
+        assert torch.equal(a[k], b[k])
+    scale = float(b[0].abs().max())
+    assert float((a[0] - b[0]).abs().max()) <= 2e-6 * scale
 
 
 # ------------------------------------------------------------------------------------------- update (SURVEY 8f next #1)

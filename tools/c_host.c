@@ -309,11 +309,16 @@ static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t*
     /* final Linear + LogSoftMax + ClassNLL (mlp.lua:29-32), forward and backward */
     layer_t* vl = &m->vb[nl - 1];
     const int64_t H = m->sizes[nl];
-    CHECK(vbnn_head_forward(g_ctx, m->dtype, m->h_s.p, m->h_s.ld, m->w3_s.p, m->w3_s.ld, m->bias3, targets, N, H, m->n_classes, inv_n,
-                            m->logits, m->out, m->g_logits, accumulate, m->acc, m->corr, 0));
-    CHECK(vbnn_head_backward(g_ctx, m->dtype, m->h_s.p, m->h_s.ld, m->w3_s.p, m->w3_s.ld, m->g_logits, N, H, m->n_classes, accumulate,
-                             m->gradWeight3, m->gradBias3, vl->gradBias, 1, vl->r, vl->O, 1, vl->g_s.p, vl->gv_s.p, vl->g_s.ld,
-                             vl->has_t ? vl->gT_s.p : NULL, vl->has_t ? vl->gvT_s.p : NULL, vl->has_t ? vl->gT_s.ld : 0));
+    vbnn_head_args ha;
+    memset(&ha, 0, sizeof ha);
+    ha.h = m->h_s.p; ha.ld_h = m->h_s.ld; ha.w3 = m->w3_s.p; ha.ld_w = m->w3_s.ld; ha.bias = m->bias3; ha.target = targets;
+    ha.N = N; ha.H = H; ha.C = m->n_classes; ha.rows_per_draw = 0; ha.inv_n = inv_n; ha.accumulate = accumulate;
+    ha.logits = m->logits; ha.out = m->out; ha.g_logits = m->g_logits; ha.loss_sum_dev = m->acc; ha.correct_dev = m->corr;
+    ha.gradWeight = m->gradWeight3; ha.gradBias = m->gradBias3; ha.gradBias_prev = vl->gradBias;
+    ha.relu_mask = 1; ha.r_prev_packed = 1; ha.r_prev = vl->r; ha.ld_r_prev = vl->O;
+    ha.g_prev = vl->g_s.p; ha.gv_prev = vl->gv_s.p; ha.ld_gp = vl->g_s.ld;
+    if (vl->has_t) { ha.gT_prev = vl->gT_s.p; ha.gvT_prev = vl->gvT_s.p; ha.ld_gpT = vl->gT_s.ld; }
+    CHECK(vbnn_head_forward_backward(g_ctx, m->dtype, &ha));
     vbnn_dw_args dd;
     vbnn_dx_args xa;
     if (m->direct) {

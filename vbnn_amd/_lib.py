@@ -74,6 +74,15 @@ class DwArgs(C.Structure):
                 ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64), ("part", _i), ("draw_dev", _vp)]
 
 
+class HeadArgs(C.Structure):          # vbnn_head_args
+    _fields_ = [("h", _vp), ("ld_h", _i64), ("w3", _vp), ("ld_w", _i64), ("bias", _vp), ("target", _vp),
+                ("N", _i64), ("H", _i64), ("C", _i64), ("rows_per_draw", _i64), ("inv_n", _f), ("accumulate", _i),
+                ("logits", _vp), ("out", _vp), ("g_logits", _vp), ("loss_sum_dev", _vp), ("correct_dev", _vp),
+                ("gradWeight", _vp), ("gradBias", _vp), ("gradBias_prev", _vp), ("relu_mask", _i), ("r_prev_packed", _i),
+                ("r_prev", _vp), ("ld_r_prev", _i64), ("g_prev", _vp), ("gv_prev", _vp), ("ld_gp", _i64),
+                ("gT_prev", _vp), ("gvT_prev", _vp), ("ld_gpT", _i64)]
+
+
 _SIGS = {
     "vbnn_abi_version": ([], _i),
     "vbnn_last_error": ([], C.c_char_p),
@@ -99,6 +108,7 @@ _SIGS = {
     "vbnn_grad_input": ([_vp, _i, C.POINTER(DxArgs)], _i),
     "vbnn_acc_grad_parameters": ([_vp, _i, C.POINTER(DwArgs)], _i),
     "vbnn_backward_pair": ([_vp, _i, C.POINTER(DxArgs), C.POINTER(DwArgs)], _i),
+    "vbnn_head_forward_backward": ([_vp, _i, C.POINTER(HeadArgs)], _i),
     "vbnn_acc_grad_bias": ([_vp, _i, _vp, _i64, _i64, _i64, _f, _i, _vp], _i),
     "vbnn_prep_layer": ([_vp, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp], _i),
     "vbnn_compute_mugrads": ([_vp, _vp, _vp, _f, _f, _vp, _vp, _i64], _i),

@@ -67,6 +67,28 @@ template <> struct Vec8<float> {
     }
 };
 
+// R partials `stride` apart, added in order r = 0, 1, ...: eight write-through-visible loads in flight at a time (a loop of
+// one load per iteration pays the L2 round trip R times: 16 partials = 10 us at the tail of a 10 us kernel)
+__device__ __forceinline__ float head_sum_partials(const float* src, int64_t stride, int R) {
+    float tot = 0.f;
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = vbnn_load_wt(src + (int64_t)(r + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += p[u];
+    }
+    if (r < R) {
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = (r + u < R) ? vbnn_load_wt(src + (int64_t)(r + u) * stride) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (r + u < R) tot += p[u];
+    }
+    return tot;
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // MFMA orientation: M = class (A operand = w3 rows, rows >= C clamped and ignored), N = minibatch row.
 // Accumulator layout: lane (q = l >> 4, c = l & 15) holds classes 4q .. 4q+3 of row n0 + c.
@@ -458,13 +480,11 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
         if (!dst) continue;
         const float* src = is_w ? partial_w + (int64_t)(k >> 6) * H + i : partial_bp + i;
         const int64_t stride = is_w ? nw : H;
-        float tot = 0.f;
-        for (int r = 0; r < R; ++r) tot += vbnn_load_wt(src + (int64_t)r * stride);
+        const float tot = head_sum_partials(src, stride, R);
         *dst = (fin_accumulate ? *dst : 0.f) + tot;
     }
     if (blockIdx.x == 0 && tid < C && fin_gb) {
-        float tot = 0.f;
-        for (int r = 0; r < R; ++r) tot += vbnn_load_wt(partial_b + r * C + tid);
+        const float tot = head_sum_partials(partial_b + tid, C, R);
         fin_gb[tid] = (fin_accumulate ? fin_gb[tid] : 0.f) + tot;
     }
 }
@@ -497,6 +517,226 @@ __global__ __launch_bounds__(256) void k_head_backward_finish(const float* __res
         float tot = 0.f;
         for (int r = 0; r < R; ++r) tot += partial_b[r * C + threadIdx.x];
         gradBias[threadIdx.x] = (accumulate ? gradBias[threadIdx.x] : 0.f) + tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward + backward, one launch
+// The fp32 launch-bound configurations (784-400-400-10 at batch 256: 256 x 400 activations) spend 7 + 13.5 us in the two
+// head kernels above -- two launches, two drains, 16 resp. 28 workgroups, g_logits out and back -- of a 57 us step. Here
+// workgroup (cb, rb) owns rows [16 rb, 16 rb + 16) x hidden units [64 cb, 64 cb + 64):
+//   1. it computes the logits of its 16 rows over ALL of H exactly as k_head_forward does (same K split over the 8 waves,
+//      same MFMA order: the same bits) -- redundantly in every cb, 1 MFLOP in all, instead of waiting for another
+//      workgroup's; log-softmax, loss, arg-max and d(loss)/d(logits) in wave 0's registers; only cb = 0 stores them and
+//      takes part in the loss's last-arriver sum;
+//   2. with d(loss)/d(logits) of its rows in LDS it forms its 16 x 64 tile of the gradInput (through the ReLU, times r) from
+//      h, r (loaded before step 1) and the 64 columns of w3, stores g_prev / gv_prev, and adds its rows' contributions to
+//      gradWeight (C x 64), gradBias_prev (64) and gradBias (C; cb = 0) in row order;
+//   3. the LAST of a column block's row-block workgroups to arrive adds the partials in row-block order (no float atomics).
+template <int DUMMY = 0>
+__global__ __launch_bounds__(64 * HEAD_FW) void k_head_step_f32(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ w3, int64_t ld_w, const float* __restrict__ bias,
+    const int32_t* __restrict__ target, int64_t N, int64_t H, int64_t Hp, int C, float inv_n, int64_t rpd, float* out, float* g_logits,
+    float* logits, double* loss_sum, int32_t* correct, int accumulate, double* part_loss, int32_t* part_corr, unsigned* loss_ticket,
+    int relu_mask, const float* __restrict__ r_prev, int64_t ld_r, float* g_prev, float* gv_prev, int64_t ld_gp,
+    float* __restrict__ partial_w /* [R][C][H] */, float* __restrict__ partial_b /* [R][C] */, float* __restrict__ partial_bp /* [R][H] */,
+    unsigned* fin_tickets, float* gradWeight, float* gradBias, float* gradBias_prev) {
+    constexpr int NT = 64 * HEAD_FW;
+    __shared__ f32x4 part[HEAD_FW][64];
+    __shared__ double red_l[HEAD_FW];
+    __shared__ int red_c[HEAD_FW];
+    __shared__ int last;
+    __shared__ float gs[16][HEAD_CMAX + 1];                  // d(loss)/d(logits) of the block's rows (0 for rows >= N, classes >= C)
+    __shared__ float ws[HEAD_CMAX][64];                      // the block's 64 columns of w3
+    __shared__ float hs[16][65], ps[16][65];                 // h and g_prev tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n0 = (int64_t)blockIdx.y * 16, c0 = (int64_t)blockIdx.x * 64;
+    const bool first_cb = blockIdx.x == 0;
+    const int R = (int)gridDim.y;
+
+    // ---- step 2's operands, requested before step 1 needs anything: thread (row = tid >> 5, columns 2 (tid & 31), + 1)
+    const int prow = tid >> 5, pcol = (tid & 31) * 2;
+    const int64_t pn = n0 + prow, pi = c0 + pcol;
+    const bool p_ok = pn < N && pi < H;                      // (H is even: the pair is in or out together)
+    float2 hv = {0.f, 0.f}, rv = {0.f, 0.f};
+    if (p_ok) {
+        hv = *reinterpret_cast<const float2*>(h + pn * ld_h + pi);
+        if (r_prev) rv = *reinterpret_cast<const float2*>(r_prev + pn * ld_r + pi);
+    }
+    float wv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int k = tid + NT * u, wc = k >> 6, wi = k & 63;
+        wv[u] = (wc < C && c0 + wi < H) ? w3[(int64_t)wc * ld_w + c0 + wi] : 0.f;
+    }
+
+    // ---- step 1: k_head_forward's logits of rows n0 .. n0 + 15 (M = class, N = minibatch row; lane (q, c16): classes 4q .. 4q + 3 of row n0 + c16)
+    constexpr int KE = 16, CE = 4;
+    const int q = lane >> 4, c16 = lane & 15;
+    const float* hp = h + min(n0 + c16, N - 1) * ld_h + q * CE;
+    const float* wp = w3 + (int64_t)min(c16, C - 1) * ld_w + q * CE;
+    const int64_t ksteps = Hp / KE;
+    const int64_t k_lo = ksteps * wave / HEAD_FW, k_hi = ksteps * (wave + 1) / HEAD_FW;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int64_t ks = k_lo;
+    for (; ks + 8 <= k_hi; ks += 8) {
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(wp + (ks + u) * KE);
+            b[u] = *reinterpret_cast<const f32x4*>(hp + (ks + u) * KE);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma_step<float>(a[u], b[u], acc);
+    }
+    for (; ks + 2 <= k_hi; ks += 2) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(wp + (ks + u) * KE);
+            b[u] = *reinterpret_cast<const f32x4*>(hp + (ks + u) * KE);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc = mfma_step<float>(a[u], b[u], acc);
+    }
+    for (; ks < k_hi; ++ks) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wp + ks * KE);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(hp + ks * KE);
+        acc = mfma_step<float>(a, b, acc);
+    }
+    part[wave][lane] = acc;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int k = tid + NT * u;
+        ws[k >> 6][k & 63] = wv[u];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 s = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < HEAD_FW; ++w) s += part[w][lane];
+        const int64_t n = n0 + c16;
+        const bool row_ok = n < N;
+        float lg[4];
+        float mx = -INFINITY; int arg = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            lg[j] = (c < C) ? s[j] + (bias ? bias[c] : 0.f) : -INFINITY;
+            if (lg[j] > mx) { mx = lg[j]; arg = c; }
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float om = __shfl_xor(mx, off, 64);
+            const int oa = __shfl_xor(arg, off, 64);
+            if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * q + j < C) se += expf(lg[j] - mx);
+        se += __shfl_xor(se, 16, 64);
+        se += __shfl_xor(se, 32, 64);
+        const float lse = mx + logf(se);
+        const int t = row_ok ? min(max(target[rpd > 0 ? n % rpd : n], 0), C - 1) : 0;
+        double loss_acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            float gl = 0.f;
+            if (row_ok && c < C) {
+                const float o = lg[j] - lse;
+                gl = (expf(o) - (c == t ? 1.0f : 0.0f)) * inv_n;
+                if (first_cb) {
+                    if (logits) logits[n * C + c] = lg[j];
+                    if (out) out[n * C + c] = o;
+                    if (g_logits) g_logits[n * C + c] = gl;
+                }
+                if (c == t) loss_acc -= (double)o * (double)inv_n;
+            }
+            gs[c16][c] = gl;
+        }
+        if (first_cb) {
+            int corr = (row_ok && q == 0 && arg == t) ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { loss_acc += __shfl_xor(loss_acc, off, 64); corr += __shfl_xor(corr, off, 64); }
+            if (lane == 0) { vbnn_store_wt(&part_loss[blockIdx.y], loss_acc); vbnn_store_wt(&part_corr[blockIdx.y], (int32_t)corr); }
+        }
+    }
+    __syncthreads();
+
+    // ---- step 2: the block's tile of the gradInput, and its rows' terms of the three sums
+    {
+        float gx0 = 0.f, gx1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < HEAD_CMAX; ++c) {
+            if (c < C) { gx0 += gs[prow][c] * ws[c][pcol]; gx1 += gs[prow][c] * ws[c][pcol + 1]; }
+        }
+        const float gp0 = (relu_mask && !(hv.x > 0.f)) ? 0.f : gx0, gp1 = (relu_mask && !(hv.y > 0.f)) ? 0.f : gx1;
+        if (p_ok) {
+            if (g_prev) *reinterpret_cast<float2*>(g_prev + pn * ld_gp + pi) = float2{gp0, gp1};
+            if (gv_prev) *reinterpret_cast<float2*>(gv_prev + pn * ld_gp + pi) = float2{gp0 * rv.x, gp1 * rv.y};
+        }
+        hs[prow][pcol] = hv.x; hs[prow][pcol + 1] = hv.y;            // (0 outside the matrix)
+        ps[prow][pcol] = p_ok ? gp0 : 0.f; ps[prow][pcol + 1] = p_ok ? gp1 : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < (C + 1) * 64; k += NT) {                   // C rows of gradWeight, then gradBias_prev
+        const int c = k >> 6, col = k & 63;
+        const int64_t i = c0 + col;
+        float tot = 0.f;
+        if (c < C) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) tot += gs[rr][c] * hs[rr][col];
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) tot += ps[rr][col];
+        }
+        if (i < H) {
+            if (c < C) { if (partial_w) vbnn_store_wt(&partial_w[((int64_t)blockIdx.y * C + c) * H + i], tot); }
+            else if (partial_bp) vbnn_store_wt(&partial_bp[(int64_t)blockIdx.y * H + i], tot);
+        }
+    }
+    if (first_cb && partial_b && tid < C) {
+        float tot = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) tot += gs[rr][tid];
+        vbnn_store_wt(&partial_b[(int64_t)blockIdx.y * C + tid], tot);
+    }
+
+    // ---- step 3: the column block's last arriver adds the R partials in row-block order; cb = 0's workgroups also settle the loss
+    if (vbnn_last_arriver(fin_tickets + blockIdx.x, (unsigned)R, &last)) {
+        const int64_t nw = (int64_t)C * H;
+        for (int k = tid; k < (C + 1) * 64; k += NT) {
+            const bool is_w = k < C * 64;
+            const int64_t i = c0 + (k & 63);
+            if (i >= H) continue;
+            float* dst = is_w ? (gradWeight ? gradWeight + (int64_t)(k >> 6) * H + i : nullptr) : (gradBias_prev ? gradBias_prev + i : nullptr);
+            if (!dst) continue;
+            const float* src = is_w ? partial_w + (int64_t)(k >> 6) * H + i : partial_bp + i;
+            const int64_t stride = is_w ? nw : H;
+            const float tot = head_sum_partials(src, stride, R);
+            *dst = (accumulate ? *dst : 0.f) + tot;
+        }
+        if (first_cb && tid < C && gradBias) {
+            const float tot = head_sum_partials(partial_b + tid, C, R);
+            gradBias[tid] = (accumulate ? gradBias[tid] : 0.f) + tot;
+        }
+    }
+    if (!first_cb) return;
+    if (!vbnn_last_arriver(loss_ticket, (unsigned)R, &last)) return;
+    double ls = 0.0;
+    int cs = 0;
+    for (int b = tid; b < R; b += NT) { ls += vbnn_load_wt(&part_loss[b]); cs += vbnn_load_wt(&part_corr[b]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ls += __shfl_xor(ls, off, 64); cs += __shfl_xor(cs, off, 64); }
+    if (lane == 0) { red_l[wave] = ls; red_c[wave] = cs; }
+    __syncthreads();
+    if (tid == 0) {
+        double lt = 0.0;
+        int ct = 0;
+#pragma unroll
+        for (int w = 0; w < HEAD_FW; ++w) { lt += red_l[w]; ct += red_c[w]; }
+        if (loss_sum) loss_sum[0] = (accumulate ? loss_sum[0] : 0.0) + lt;
+        if (correct) correct[0] = (accumulate ? correct[0] : 0) + ct;
     }
 }
 
@@ -620,5 +860,50 @@ extern "C" int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64
                                        (bf16_t*)gv_prev, ld_gp, (bf16_t*)gT_prev, (bf16_t*)gvT_prev, ld_gpT);
     vbnn_set_error("unsupported dtype %d", dtype);
     return VBNN_ERR_UNSUPPORTED;
+    VBNN_API_END
+}
+
+static int g_head_step = 1;               // A/B: VBNN_HEAD_STEP=0 in the environment keeps the two launches
+
+extern "C" int vbnn_head_forward_backward(vbnn_ctx* ctx, int dtype, const vbnn_head_args* a) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && a, "null argument");
+    static const bool env_read = [] { const char* e = getenv("VBNN_HEAD_STEP"); if (e && e[0] == '0') g_head_step = 0; return true; }();
+    (void)env_read;
+    const int64_t N = a->N, H = a->H, C = a->C;
+    const int64_t R = (N + 15) / 16, tiles_c = (H + 63) / 64;
+    const bool sums = a->gradWeight || a->gradBias || a->gradBias_prev;
+    // scratch: [R] loss partials (double) + [R] hit partials (int), then the row-block partials of the three sums
+    const int64_t head_floats = 4 * R, per_block = C * H + C + H;
+    const bool one_launch =
+        g_head_step && dtype == VBNN_F32 && a->h && a->w3 && a->target && a->g_logits && N > 0 && H > 0 && C > 0 && C <= HEAD_CMAX &&
+        a->rows_per_draw >= 0 && !a->gT_prev && !a->gvT_prev && N * H <= (1ll << 20) && H % 2 == 0 && tiles_c <= VBNN_CNT_TILES_MAX &&
+        R <= 65535 && a->ld_h % VBNN_KPAD == 0 && a->ld_w % VBNN_KPAD == 0 && a->ld_h >= H && a->ld_w >= H &&
+        (((uintptr_t)a->h | (uintptr_t)a->w3) & 15u) == 0 && (sums || a->g_prev) && (!a->gv_prev || (a->g_prev && a->r_prev)) &&
+        (!a->r_prev || (a->ld_r_prev % 2 == 0 && a->ld_r_prev >= H && ((uintptr_t)a->r_prev & 7u) == 0)) &&
+        (!a->g_prev || (a->ld_gp % 2 == 0 && a->ld_gp >= H && (((uintptr_t)a->g_prev | (uintptr_t)a->gv_prev) & 7u) == 0)) &&
+        (int64_t)(ctx->scratch_doubles * 2) >= head_floats + R * per_block;
+    if (!one_launch) {
+        const int st = vbnn_head_forward(ctx, dtype, a->h, a->ld_h, a->w3, a->ld_w, a->bias, a->target, N, H, C, a->inv_n, a->logits, a->out,
+                                         a->g_logits, a->accumulate, a->loss_sum_dev, a->correct_dev, a->rows_per_draw);
+        if (st != VBNN_OK) return st;
+        return vbnn_head_backward(ctx, dtype, a->h, a->ld_h, a->w3, a->ld_w, a->g_logits, N, H, C, a->accumulate, a->gradWeight,
+                                  a->gradBias, a->gradBias_prev, a->relu_mask, a->r_prev, a->ld_r_prev, a->r_prev_packed, a->g_prev,
+                                  a->gv_prev, a->ld_gp, a->gT_prev, a->gvT_prev, a->ld_gpT);
+    }
+    double* part_loss = ctx->scratch;
+    int32_t* part_corr = reinterpret_cast<int32_t*>(ctx->scratch + R);
+    float* partial_w = reinterpret_cast<float*>(ctx->scratch) + head_floats;
+    float* partial_b = partial_w + R * C * H;
+    float* partial_bp = partial_b + R * C;
+    const int64_t Hp = (H + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_head_step_f32<0>, dim3((unsigned)tiles_c, (unsigned)R), dim3(64 * HEAD_FW), 0, ctx->stream, (const float*)a->h,
+                       a->ld_h, (const float*)a->w3, a->ld_w, a->bias, a->target, N, H, Hp, (int)C, a->inv_n, a->rows_per_draw, a->out,
+                       a->g_logits, a->logits, a->loss_sum_dev, a->correct_dev, a->accumulate, part_loss, part_corr,
+                       ctx->counters + VBNN_CNT_HEAD_FWD, a->relu_mask, (const float*)a->r_prev, a->ld_r_prev, (float*)a->g_prev,
+                       (float*)a->gv_prev, a->ld_gp, (a->gradWeight ? partial_w : nullptr), (a->gradBias ? partial_b : nullptr),
+                       (a->gradBias_prev ? partial_bp : nullptr), ctx->counters + VBNN_CNT_TILES, a->gradWeight, a->gradBias,
+                       a->gradBias_prev);
+    return vbnn_check_launch("k_head_step_f32");
     VBNN_API_END
 }

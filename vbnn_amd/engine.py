@@ -97,6 +97,7 @@ class FusedMLP:
         # GEMMs. Measured on MI355X (wide config): 1.32 ms with, 1.29 ms without -- two 512-block GEMMs sharing the
         # CUs thrash each other's L2 panels more than the staggered epilogues save -- so it is off by default.
         self.overlap = bool(opt.get("overlap", False))
+        self.head_step = bool(opt.get("head_step", True))     # the fused head's forward + backward as one call (A/B, tests: False = two calls)
         if self.overlap:
             self._side = torch.cuda.Stream(device=self.device)
             self.ctx2 = Context(self.device.index or 0, stream=self._side)
@@ -536,18 +537,35 @@ class FusedMLP:
         fused_head = Cn <= 16 and self.criterion == "nll"
         if fused_head:
             # ---------------- fused classifier head (mlp.lua:29-32): streaming kernels, no 10-wide MFMA tiles
-            L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
-                                          _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
-                                          _p(self.g_logits), accumulate, _p(self._acc), _p(self._corr), self._rpd))
-            if not backward:
-                self._first = False
-                return
-            L.check(lib.vbnn_head_backward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
-                                           _p(self.g_logits), N, H, Cn, accumulate, _p(self.gradWeight3),
-                                           _p(self.gradBias3), _p(vl.gradBias), 1, _p(vl.r) if lrt else None, vl.O, 1,
-                                           vl.g_s.ptr,
-                                           vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr if vl.gT_s else None,
-                                           vl.gvT_s.ptr if (lrt and vl.gvT_s) else None, vl.gT_s.ld if vl.gT_s else 0))
+            if backward and self.head_step:
+                # forward + backward of the head as ONE call (vbnn_head_forward_backward: one launch for fp32 at launch-bound
+                # sizes -- the logits recomputed per workgroup instead of a second kernel waiting for g_logits --, the two
+                # launches below everywhere else)
+                a = L.HeadArgs()
+                a.h, a.ld_h, a.w3, a.ld_w, a.bias, a.target = self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld, _p(self.bias3), _p(targets)
+                a.N, a.H, a.C, a.rows_per_draw, a.inv_n, a.accumulate = N, H, Cn, self._rpd, inv_n, accumulate
+                a.logits, a.out, a.g_logits = _p(self.logits), _p(self.out), _p(self.g_logits)
+                a.loss_sum_dev, a.correct_dev = _p(self._acc), _p(self._corr)
+                a.gradWeight, a.gradBias, a.gradBias_prev = _p(self.gradWeight3), _p(self.gradBias3), _p(vl.gradBias)
+                a.relu_mask, a.r_prev_packed, a.r_prev, a.ld_r_prev = 1, 1, (_p(vl.r) if lrt else None), vl.O
+                a.g_prev, a.gv_prev, a.ld_gp = vl.g_s.ptr, (vl.gv_s.ptr if lrt else None), vl.g_s.ld
+                a.gT_prev = vl.gT_s.ptr if vl.gT_s else None
+                a.gvT_prev = vl.gvT_s.ptr if (lrt and vl.gvT_s) else None
+                a.ld_gpT = vl.gT_s.ld if vl.gT_s else 0
+                L.check(lib.vbnn_head_forward_backward(ctx, code, C.byref(a)))
+            else:
+                L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
+                                              _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
+                                              _p(self.g_logits), accumulate, _p(self._acc), _p(self._corr), self._rpd))
+                if not backward:
+                    self._first = False
+                    return
+                L.check(lib.vbnn_head_backward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
+                                               _p(self.g_logits), N, H, Cn, accumulate, _p(self.gradWeight3),
+                                               _p(self.gradBias3), _p(vl.gradBias), 1, _p(vl.r) if lrt else None, vl.O, 1,
+                                               vl.g_s.ptr,
+                                               vl.gv_s.ptr if lrt else None, vl.g_s.ld, vl.gT_s.ptr if vl.gT_s else None,
+                                               vl.gvT_s.ptr if (lrt and vl.gvT_s) else None, vl.gT_s.ld if vl.gT_s else 0))
         else:
             if self._rpd:                                 # (the generic criteria take one target per operand row)
                 targets = targets.repeat(self._draws) if targets.dim() == 1 else targets.repeat(self._draws, 1)
