@@ -1484,7 +1484,9 @@ def test_early_dlvars_message_is_bitwise_the_fused_launch(oracle, nnmod, dtype, 
     nnmod.fill_normal(x, SEED, 4, 0, 0)
     arenas = []
     for early, reduce in ((False, False), (True, False), (True, True)):
-        opt = opt_for("lrt", dtype, input_size=I0, hidden=hidden, S=1, fuse_kl=True, early_lv=early)
+        # (head_step = False: the fp32 head as its two launches in all three -- its one-launch form, taken only without transposed
+        # copies, sums the head's gradients in another order)
+        opt = opt_for("lrt", dtype, input_size=I0, hidden=hidden, S=1, fuse_kl=True, early_lv=early, head_step=False)
         eng = FusedMLP(opt, force_reduce=reduce)
         assert eng.early_lv == [early] * len(hidden)
         t = eng.synthetic_targets(x)
@@ -1567,6 +1569,7 @@ def test_staged_stores_stay_inside_their_tensors(oracle, nnmod, hidden, I0, N):
     eng.gradWeight3 = arena[off:off + Cn * H].view(Cn, H)
     eng.gradBias3 = arena[off + Cn * H:off + Cn * H + Cn]
     eng._acc = guarded(eng._acc, 3.0e300)
+    eng._argcache.clear()                     # the engine keeps its argument blocks: rebuild them around the guarded tensors
     for _ in range(2):
         eng.resetGradients(); eng.sample(); eng.run(x, t)
     loss, _ = eng.loss_and_accuracy()

@@ -23,9 +23,11 @@
  * configuration bench.py times. Shapes whose GEMMs do not take K-major operands get the transposed copies, as engine.py
  * gives them (vbnn_kmajor_supported*).
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -525,6 +527,24 @@ int main(int argc, char** argv) {
            with_comm ? " +rccl(world 1)" : "", loss, correct, net.dx_first ? "dx-first" : "layerwise");
     for (int li = 0; li < n_layers; ++li) printf(" | L%d dw_km %d dx_km %d bias_from_dw %d", li, net.vb[li].dw_km, net.vb[li].dx_km, net.vb[li].bias_from_dw);
     printf("\n");
+    const int timed = atoi(arg_value(argc, argv, "--time", "0"));
+    if (timed > 0) {           /* --time K: K more steps (after the results above were taken), wall clock around issue + vbnn_sync */
+        struct timespec t0, t1;
+        for (int rep = 0; rep < 3; ++rep) {
+            CHECK(vbnn_sync(g_ctx));
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (int step = 0; step < timed; ++step) {
+                if (graph) { CHECK(vbnn_graph_launch(graph)); continue; }
+                fm_reset_gradients(&net);
+                for (int s = 0; s < S; ++s) { fm_sample(&net); fm_run(&net, x, sizes[0], t, N); }
+                fm_finish(&net);
+            }
+            CHECK(vbnn_sync(g_ctx));
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            printf("c_host: %d steps%s: %.2f us per step (issue + sync, wall clock)\n", timed, graph ? " (graph replays)" : "",
+                   ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / timed);
+        }
+    }
     if (graph) { printf("c_host: steps 2..%d were replays of one captured graph of %d kernel nodes\n", steps, graph_nodes); CHECK(vbnn_graph_destroy(graph)); }
     if (net.comm) CHECK(vbnn_comm_destroy(net.comm));
     CHECK(vbnn_ctx_destroy(g_ctx));                               /* (device buffers are released with the process) */

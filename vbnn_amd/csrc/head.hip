@@ -536,7 +536,7 @@ template <int DUMMY = 0>
 __global__ __launch_bounds__(64 * HEAD_FW) void k_head_step_f32(
     const float* __restrict__ h, int64_t ld_h, const float* __restrict__ w3, int64_t ld_w, const float* __restrict__ bias,
     const int32_t* __restrict__ target, int64_t N, int64_t H, int64_t Hp, int C, float inv_n, int64_t rpd, float* out, float* g_logits,
-    float* logits, double* loss_sum, int32_t* correct, int accumulate, double* part_loss, int32_t* part_corr, unsigned* loss_ticket,
+    float* logits, double* loss_sum, int32_t* correct, int accumulate, double* part_loss, int32_t* part_corr,
     int relu_mask, const float* __restrict__ r_prev, int64_t ld_r, float* g_prev, float* gv_prev, int64_t ld_gp,
     float* __restrict__ partial_w /* [R][C][H] */, float* __restrict__ partial_b /* [R][C] */, float* __restrict__ partial_bp /* [R][H] */,
     unsigned* fin_tickets, float* gradWeight, float* gradBias, float* gradBias_prev) {
@@ -702,27 +702,25 @@ __global__ __launch_bounds__(64 * HEAD_FW) void k_head_step_f32(
         vbnn_store_wt(&partial_b[(int64_t)blockIdx.y * C + tid], tot);
     }
 
-    // ---- step 3: the column block's last arriver adds the R partials in row-block order; cb = 0's workgroups also settle the loss
-    if (vbnn_last_arriver(fin_tickets + blockIdx.x, (unsigned)R, &last)) {
-        const int64_t nw = (int64_t)C * H;
-        for (int k = tid; k < (C + 1) * 64; k += NT) {
-            const bool is_w = k < C * 64;
-            const int64_t i = c0 + (k & 63);
-            if (i >= H) continue;
-            float* dst = is_w ? (gradWeight ? gradWeight + (int64_t)(k >> 6) * H + i : nullptr) : (gradBias_prev ? gradBias_prev + i : nullptr);
-            if (!dst) continue;
-            const float* src = is_w ? partial_w + (int64_t)(k >> 6) * H + i : partial_bp + i;
-            const int64_t stride = is_w ? nw : H;
-            const float tot = head_sum_partials(src, stride, R);
-            *dst = (accumulate ? *dst : 0.f) + tot;
-        }
-        if (first_cb && tid < C && gradBias) {
-            const float tot = head_sum_partials(partial_b + tid, C, R);
-            gradBias[tid] = (accumulate ? gradBias[tid] : 0.f) + tot;
-        }
+    // ---- step 3: the column block's last arriver adds the R partials in row-block order; column block 0's also settles the
+    // loss and the hit count (its R workgroups are the ones that stored those partials: one ticket round for everything)
+    if (!vbnn_last_arriver(fin_tickets + blockIdx.x, (unsigned)R, &last)) return;
+    const int64_t nw = (int64_t)C * H;
+    for (int k = tid; k < (C + 1) * 64; k += NT) {
+        const bool is_w = k < C * 64;
+        const int64_t i = c0 + (k & 63);
+        if (i >= H) continue;
+        float* dst = is_w ? (gradWeight ? gradWeight + (int64_t)(k >> 6) * H + i : nullptr) : (gradBias_prev ? gradBias_prev + i : nullptr);
+        if (!dst) continue;
+        const float* src = is_w ? partial_w + (int64_t)(k >> 6) * H + i : partial_bp + i;
+        const float tot = head_sum_partials(src, is_w ? nw : H, R);
+        *dst = (accumulate ? *dst : 0.f) + tot;
     }
     if (!first_cb) return;
-    if (!vbnn_last_arriver(loss_ticket, (unsigned)R, &last)) return;
+    if (tid < C && gradBias) {
+        const float tot = head_sum_partials(partial_b + tid, C, R);
+        gradBias[tid] = (accumulate ? gradBias[tid] : 0.f) + tot;
+    }
     double ls = 0.0;
     int cs = 0;
     for (int b = tid; b < R; b += NT) { ls += vbnn_load_wt(&part_loss[b]); cs += vbnn_load_wt(&part_corr[b]); }
@@ -899,8 +897,7 @@ extern "C" int vbnn_head_forward_backward(vbnn_ctx* ctx, int dtype, const vbnn_h
     const int64_t Hp = (H + 15) / 16 * 16;
     hipLaunchKernelGGL(k_head_step_f32<0>, dim3((unsigned)tiles_c, (unsigned)R), dim3(64 * HEAD_FW), 0, ctx->stream, (const float*)a->h,
                        a->ld_h, (const float*)a->w3, a->ld_w, a->bias, a->target, N, H, Hp, (int)C, a->inv_n, a->rows_per_draw, a->out,
-                       a->g_logits, a->logits, a->loss_sum_dev, a->correct_dev, a->accumulate, part_loss, part_corr,
-                       ctx->counters + VBNN_CNT_HEAD_FWD, a->relu_mask, (const float*)a->r_prev, a->ld_r_prev, (float*)a->g_prev,
+                       a->g_logits, a->logits, a->loss_sum_dev, a->correct_dev, a->accumulate, part_loss, part_corr, a->relu_mask, (const float*)a->r_prev, a->ld_r_prev, (float*)a->g_prev,
                        (float*)a->gv_prev, a->ld_gp, (a->gradWeight ? partial_w : nullptr), (a->gradBias ? partial_b : nullptr),
                        (a->gradBias_prev ? partial_bp : nullptr), ctx->counters + VBNN_CNT_TILES, a->gradWeight, a->gradBias,
                        a->gradBias_prev);

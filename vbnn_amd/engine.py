@@ -191,6 +191,7 @@ class FusedMLP:
         self._exchange_now = True
         self._exchange_done = False
         self._N = None
+        self._argcache = {}
         self._rpd = 0            # > 0 inside run_draws: rows per Monte-Carlo draw of the stacked minibatch
         self._x_in = None        # fp32: the raw minibatch of the current run, read in place by layer 1's GEMMs
         self._draws = None
@@ -210,6 +211,7 @@ class FusedMLP:
         if self._N == N:
             return
         self._N = N
+        self._argcache = {}                     # the argument blocks hold pointers into the buffers allocated below
         dev, tdt = self.device, self.tdt
         lib = L.lib()
         # K-major operands (vbnn_kmajor_supported): when a layer's parameter-gradient GEMM reads x and g as the forward
@@ -431,7 +433,21 @@ class FusedMLP:
 
     # ---- argument blocks of the three GEMM families for VB layer `li` (also used by bench.py to time
     # exactly the launches of the step in isolation)
+    # The blocks are built once per (layer, batch shape, ...) and kept (the launch-bound step is ~50 us of GPU time: rebuilding
+    # five ctypes structures per step cost the Python host ~20 us of it); what varies from call to call -- the draw counter, the
+    # raw minibatch's address -- is patched in.
     def _fwd_args(self, li, N, row0):
+        direct_x = li == 0 and self._x_in is not None
+        key = ("fwd", li, N, row0, self._rpd, direct_x)
+        a = self._argcache.get(key)
+        if a is None:
+            a = self._argcache[key] = self._build_fwd_args(li, N, row0)
+        if direct_x:
+            a.x, a.ld_x = self._x_in.ptr, self._x_in.ld
+        a.draw = 0 if self.device_draw else self.draw
+        return a
+
+    def _build_fwd_args(self, li, N, row0):
         v, lrt = self.vb[li], self._lrt()
         last = li == len(self.vb) - 1
         nxt = None if last else self.vb[li + 1]
@@ -450,6 +466,17 @@ class FusedMLP:
                          ld_hT=self.hT_s.ld if last else (nxt.xT_s.ld if nxt.xT_s else 0), rows_per_draw=self._rpd)
 
     def _dw_args(self, li, N, accumulate):
+        direct_x = li == 0 and self._x_in is not None
+        key = ("dw", li, N, accumulate, float(self._draws or self.S), direct_x)
+        d = self._argcache.get(key)
+        if d is None:
+            d = self._argcache[key] = self._build_dw_args(li, N, accumulate)
+        if direct_x:
+            d.x, d.ld_x = self._x_in.ptr, self._x_in.ld
+        d.draw, d.part = self.draw, 0
+        return d
+
+    def _build_dw_args(self, li, N, accumulate):
         v, lrt = self.vb[li], self._lrt()
         has_t = v.xT_s is not None
         has_gt = v.gT_s is not None
@@ -477,6 +504,13 @@ class FusedMLP:
         return d
 
     def _dx_args(self, li, N):
+        key = ("dx", li, N)
+        a = self._argcache.get(key)
+        if a is None:
+            a = self._argcache[key] = self._build_dx_args(li, N)
+        return a
+
+    def _build_dx_args(self, li, N):
         v, p, lrt = self.vb[li], self.vb[li - 1], self._lrt()
         use_t = v.use_muT
         return L.DxArgs(wT=v.muT_s.ptr if use_t else None, w2T=v.varT_s.ptr if (lrt and use_t) else None, g=v.g_s.ptr,
@@ -541,17 +575,21 @@ class FusedMLP:
                 # forward + backward of the head as ONE call (vbnn_head_forward_backward: one launch for fp32 at launch-bound
                 # sizes -- the logits recomputed per workgroup instead of a second kernel waiting for g_logits --, the two
                 # launches below everywhere else)
-                a = L.HeadArgs()
-                a.h, a.ld_h, a.w3, a.ld_w, a.bias, a.target = self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld, _p(self.bias3), _p(targets)
-                a.N, a.H, a.C, a.rows_per_draw, a.inv_n, a.accumulate = N, H, Cn, self._rpd, inv_n, accumulate
-                a.logits, a.out, a.g_logits = _p(self.logits), _p(self.out), _p(self.g_logits)
-                a.loss_sum_dev, a.correct_dev = _p(self._acc), _p(self._corr)
-                a.gradWeight, a.gradBias, a.gradBias_prev = _p(self.gradWeight3), _p(self.gradBias3), _p(vl.gradBias)
-                a.relu_mask, a.r_prev_packed, a.r_prev, a.ld_r_prev = 1, 1, (_p(vl.r) if lrt else None), vl.O
-                a.g_prev, a.gv_prev, a.ld_gp = vl.g_s.ptr, (vl.gv_s.ptr if lrt else None), vl.g_s.ld
-                a.gT_prev = vl.gT_s.ptr if vl.gT_s else None
-                a.gvT_prev = vl.gvT_s.ptr if (lrt and vl.gvT_s) else None
-                a.ld_gpT = vl.gT_s.ld if vl.gT_s else 0
+                key = ("head", N, self._rpd, accumulate, lrt)
+                a = self._argcache.get(key)
+                if a is None:
+                    a = self._argcache[key] = L.HeadArgs()
+                    a.h, a.ld_h, a.w3, a.ld_w, a.bias = self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld, _p(self.bias3)
+                    a.N, a.H, a.C, a.rows_per_draw, a.inv_n, a.accumulate = N, H, Cn, self._rpd, inv_n, accumulate
+                    a.logits, a.out, a.g_logits = _p(self.logits), _p(self.out), _p(self.g_logits)
+                    a.loss_sum_dev, a.correct_dev = _p(self._acc), _p(self._corr)
+                    a.gradWeight, a.gradBias, a.gradBias_prev = _p(self.gradWeight3), _p(self.gradBias3), _p(vl.gradBias)
+                    a.relu_mask, a.r_prev_packed, a.r_prev, a.ld_r_prev = 1, 1, (_p(vl.r) if lrt else None), vl.O
+                    a.g_prev, a.gv_prev, a.ld_gp = vl.g_s.ptr, (vl.gv_s.ptr if lrt else None), vl.g_s.ld
+                    a.gT_prev = vl.gT_s.ptr if vl.gT_s else None
+                    a.gvT_prev = vl.gvT_s.ptr if (lrt and vl.gvT_s) else None
+                    a.ld_gpT = vl.gT_s.ld if vl.gT_s else 0
+                a.target = _p(targets)
                 L.check(lib.vbnn_head_forward_backward(ctx, code, C.byref(a)))
             else:
                 L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
