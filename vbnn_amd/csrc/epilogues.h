@@ -162,11 +162,22 @@ struct EpiFwd {
         p.b = bias ? *reinterpret_cast<const f32x4*>(bias + um + ln.ml) : f32x4{0.f, 0.f, 0.f, 0.f};
         return p;
     }
+    // the position's four normals, separately: they depend on indices alone, so a kernel with nothing to issue while its
+    // first operand loads are in flight (gemm_v0.h) draws them THEN and passes them to apply_fast_z
+    struct Noise { vbnn_f32x4 z; };
+    __device__ __forceinline__ Noise draw_fast(int um, int un, const Lane& ln) const {
+        Noise q = {};
+        if (noise) q.z = zeta4(un + ln.nl, (uint32_t)((um + ln.ml) >> 2));
+        return q;
+    }
     __device__ __forceinline__ void apply_fast(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre& pre, float (&t1)[4],
                                                float (&t2)[4]) const {
+        apply_fast_z(um, un, ln, a1, a2, pre, draw_fast(um, un, ln), t1, t2);
+    }
+    __device__ __forceinline__ void apply_fast_z(int um, int un, const Lane& ln, f32x4 a1, f32x4 a2, const Pre& pre, const Noise& q,
+                                                 float (&t1)[4], float (&t2)[4]) const {
         float yv[4], rv[4];
-        vbnn_f32x4 z;
-        if (noise) z = zeta4(un + ln.nl, (uint32_t)((um + ln.ml) >> 2));
+        const vbnn_f32x4 z = q.z;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float mb = a1[j] + pre.b[j];

@@ -20,6 +20,7 @@
 // k permutation inside a 16-wide group; the SUMMATION ORDER differs from gemm_v1's (four interleaved chains instead of
 // one), so the two kernels agree to rounding, not bitwise. fp32 only.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 // lane (i = l & 15, q = l >> 4) holds k = 4 q .. 4 q + 3 of its row; MFMA step j contracts the four k values {4 q + j}:
@@ -35,6 +36,10 @@ __device__ __forceinline__ f32x4 v0_mfma16(const f32x4& a, const f32x4& b, f32x4
 #endif
 constexpr int V0_W = 4;              // waves of a workgroup = K splits
 constexpr int V0_PD = V0_LAB_PD;     // k groups of loads in flight per wave
+// functors whose epilogue draws noise that depends on indices alone offer draw_fast / apply_fast_z (EpiFwd): detected here
+template <class E, class = void> struct v0_pre_noise : std::false_type { struct type {}; };
+template <class E> struct v0_pre_noise<E, std::void_t<typename E::Noise>> : std::true_type { typedef typename E::Noise type; };
+
 template <int FM, int FN> constexpr int v0_red_slots() { return V0_W * FM * FN * 2 * 64; }      // f32x4 slots of the reduction buffer
 
 template <int FM, int FN, bool DUAL, class Epi, bool TA, bool TB, int SQ>
@@ -192,11 +197,13 @@ __device__ __forceinline__ void gemm_v0_tile(const float* __restrict__ A, const 
     bool fast = false;
     typename Epi::Lane eln = {};
     typename Epi::Pre epre = {};
+    typename v0_pre_noise<Epi>::type enoise = {};
     if (wave < NF) {
         fast = epi.fast_ok() && !epi.t1_ptr() && !epi.t2_ptr() && um + 16 <= epi.m_dim() && un + 16 <= epi.n_dim();   // wave-uniform
         if (fast) {
             eln = epi.lane_init(li, kq * 4);
             epre = epi.load_fast(um, un, eln);
+            if constexpr (v0_pre_noise<Epi>::value) enoise = epi.draw_fast(um, un, eln);     // ~300 VALU instructions under the first loads' latency
         }
     }
     for (int s0 = 0; s0 < nsf; s0 += V0_PD) {
@@ -229,7 +236,8 @@ __device__ __forceinline__ void gemm_v0_tile(const float* __restrict__ A, const 
     }
     if (fast) {
         float t1[4], t2[4];
-        epi.apply_fast(um, un, eln, s1, s2, epre, t1, t2);
+        if constexpr (v0_pre_noise<Epi>::value) epi.apply_fast_z(um, un, eln, s1, s2, epre, enoise, t1, t2);
+        else epi.apply_fast(um, un, eln, s1, s2, epre, t1, t2);
         return;
     }
     epi(um + kq * 4, un + li, s1, s2);
