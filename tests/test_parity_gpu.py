@@ -126,7 +126,8 @@ def _layer_pair(nnmod, oracle, mode, I, O, dtype="f32"):
 
 
 @pytest.mark.parametrize("N,I,O", [(1, 4, 4), (3, 7, 5), (32, 64, 48), (100, 130, 70), (256, 784, 400),
-                                   (64, 256, 100), (64, 100, 10)])      # the last two: convnet.lua:24,30
+                                   (64, 256, 100), (64, 100, 10),       # these two: convnet.lua:24,30
+                                   (8, 3001, 24), (17, 1, 3)])          # a long ragged K walk and K = 1 (the latency kernel's ring and tail)
 @pytest.mark.parametrize("mode", ["wn", "lrt"])
 def test_layer_forward_backward_f32(nnmod, oracle, mode, N, I, O):
     """T1 (wn) / T2 (lrt): output, gradInput, gradWeight, gradSum, gradBias sample-exact vs the oracle."""
