@@ -61,7 +61,7 @@ const char* vbnn_last_error(void);
 #define VBNN_DEBUG_V3_MIN_K 4      /* shortest K for which shape selection picks the two-pass 256 x 256 kernel (default 704) */
 #define VBNN_DEBUG_V2_PSPLIT 5     /* pipelined kernel pair split (the pair's two GEMMs in different workgroups, parameter
                                       gradients only): -1 = by shape (default), 0 = never, 1 = whenever possible */
-#define VBNN_DEBUG_V3_SPLIT 8      /* two-pass kernel's pair-split + split-K launch for few-tile parameter gradients: -1 = by shape (default), 0 = never, 1 = whenever possible */
+#define VBNN_DEBUG_V3_SPLIT 8      /* two-pass kernel's pair-split launches for few-tile parameter gradients: -1 = by shape (default), 0 = never, 1 = whenever possible; its half-height form without a K split: 2 = never, 3 = where it fills the CUs in one round (default), 4 = whenever the launch is taken */
 #define VBNN_DEBUG_FAKE_NOISE 7    /* TIMING ONLY, wrong results: 1 = the two-pass kernel's forward fold skips the Philox draw */
 #define VBNN_DEBUG_V0 9            /* fp32 shapes of the launch-bound geometry: 1 = the latency kernel (gemm_v0.h; default), 0 = gemm_v1's 32 x 32 tile */
 #define VBNN_DEBUG_KMAJOR 6        /* K-major operands (gemm_v3.h AK / BK): 1 = use when the shape allows (default), 0 = never, 2 = gemm_v3 only */

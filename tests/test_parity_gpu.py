@@ -445,11 +445,14 @@ def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidd
 @pytest.mark.parametrize("hidden,I0,N", [([256, 512], 100, 256),      # layer 1: ragged M with the ones row (101 of 256); layer 2: whole tiles
                                          ([512, 256], 260, 384),      # two M tiles, the second ragged (261 of 512); 3 K steps per half
                                          ([256, 256], 252, 128)])     # the ones row is the LAST row of the quad before a tile edge
-def test_split_two_pass_gradient_against_rounding_emulation(oracle, nnmod, hidden, I0, N):
-    """accGradParameters on gemm_v3's pair-split + split-K launch (forced: debug key 8), the launch of the 784 x 4096
-    gradient: ragged output rows, the bias gradient from the ones row, the K halves' hand-off."""
+@pytest.mark.parametrize("form", ["ksplit", "half-height"])
+def test_split_two_pass_gradient_against_rounding_emulation(oracle, nnmod, hidden, I0, N, form):
+    """accGradParameters on gemm_v3's pair-split launches (forced: debug key 8), the launches of the 784 x 4096 gradient:
+    ragged output rows, the bias gradient from the ones row; `ksplit`: 256-row tiles, two K halves and their hand-off;
+    `half-height`: 128-row tiles, every workgroup walks all of K (what the wide configuration's input layer takes)."""
     from vbnn_amd import _lib as L
     L.check(L.lib().vbnn_debug_set(8, 1))
+    L.check(L.lib().vbnn_debug_set(8, 2 if form == "ksplit" else 4))
     try:
         eng = _check_bf16_step_against_emulation(oracle, hidden, I0, N, True)
         assert all(v.dw_km for v in eng.vb) and eng.vb[0].x_pad256
@@ -459,6 +462,7 @@ def test_split_two_pass_gradient_against_rounding_emulation(oracle, nnmod, hidde
             assert torch.equal(eng.grads, g1)
     finally:
         L.check(L.lib().vbnn_debug_set(8, -1))
+        L.check(L.lib().vbnn_debug_set(8, 3))
 
 
 def eng_x(eng, oracle, N, I0):

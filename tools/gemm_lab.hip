@@ -136,8 +136,14 @@ int main(int argc, char** argv) {
             }
             std::sort(ts.begin(), ts.end());
             const double fl = 2.0 * M * N * K * (dual ? 2 : 1);
-            printf("M=%d N=%d K=%d %s v3 (256x256%s): median %.1f us  %.0f TF\n", M, N, K, dual ? "dual  " : "single",
-                   dual ? ", two passes" : "", ts[2], fl / ts[2] / 1e6);
+            unsigned long long hsh = 1469598103934665603ull;       // FNV-1a over the output bits: equal across builds = bitwise equal
+            {
+                std::vector<unsigned> ho((size_t)M * N);
+                CK(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
+                for (unsigned v : ho) { hsh ^= v; hsh *= 1099511628211ull; }
+            }
+            printf("M=%d N=%d K=%d %s v3 (256x256%s): median %.1f us  %.0f TF  out hash %016llx\n", M, N, K, dual ? "dual  " : "single",
+                   dual ? ", two passes" : "", ts[2], fl / ts[2] / 1e6, hsh);
         }
     }
     return lab_half(M, N, K, A, A2, B, B2, out);

@@ -64,12 +64,19 @@ __device__ unsigned long long* g_v3_stamp = nullptr;
 // this kernel's main loop (1.4 us per step against 0.9-1.2 us per HALF-size step of gemm_v2's single-accumulator tile).
 // The output may be ragged in M (rows past m_dim() are computed on zero padding and never stored; the row AT m_dim() is
 // the ones row: edge_row).
-template <bool DUAL, bool AK, bool BK, class Epi, bool SPLIT = false>
+// HM (a form of SPLIT; r03): the pair split alone over HALF-HEIGHT tiles -- 128 x 256, the wave tile 64 x 64 = acc[0..3][], every K
+// step one phase of 32 MFMAs per wave -- each workgroup walking ALL of K: no partial tiles, no slabs, no tickets. For an output
+// whose 128-row tiles x 2 fill most of the CUs in one round (785 x 4096: 7 x 16 x 2 = 224 workgroups) the launch costs its
+// 64 K steps (0.98 us each in the lab: two A + four B pieces beside 32 MFMAs) + one epilogue, against 32 steps of 1.62 us
+// + slab store + ticket + the partner's slab + epilogue on the finishing half of the K-split form.
+// LDS: A parts as a ring of four (A of step t in part t & 3, refilled two steps ahead), B as before.
+template <bool DUAL, bool AK, bool BK, class Epi, bool SPLIT = false, bool HM = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                      const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
                                                      int M, int N, int nk, int tiles_m, int tiles_n, float* mscratch,
                                                      unsigned* tickets, Epi epi_in) {
     static_assert(!(SPLIT && DUAL), "the split form computes one GEMM of the pair per workgroup");
+    static_assert(!HM || (SPLIT && AK && BK), "the half-height form is a K-major pair-split launch");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     V3_ST(0);
     const int tid = threadIdx.x;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     Epi epi = epi_in;
 
     // ---- block -> tile mapping: as gemm_v2.h (blocks that share an XCD get a compact 4 x 8 group of tiles)
-    const int nblk = tiles_m * tiles_n * (SPLIT ? 4 : 1);
+    const int nblk = tiles_m * tiles_n * (SPLIT ? (HM ? 2 : 4) : 1);
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
@@ -98,15 +105,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         const int ntile = tiles_m * tiles_n;
         const int combo = bid / ntile;
         bid -= combo * ntile;
-        kslice = combo >> 1;
+        kslice = HM ? 0 : combo >> 1;
         const int part = combo & 1;
         unit = bid * 2 + part;
         epi.set_part(1 + part);
         if (part) { A = A2; B = B2; }
-        const int kt0 = kslice * (nk / 2);
-        nk = kslice ? nk - nk / 2 : nk / 2;
-        A += (int64_t)kt0 * (AK ? V2_BK * lda : V2_BK);
-        B += (int64_t)kt0 * (BK ? V2_BK * ldb : V2_BK);
+        if (!HM) {
+            const int kt0 = kslice * (nk / 2);
+            nk = kslice ? nk - nk / 2 : nk / 2;
+            A += (int64_t)kt0 * (AK ? V2_BK * lda : V2_BK);
+            B += (int64_t)kt0 * (BK ? V2_BK * ldb : V2_BK);
+        }
     }
     int tm, tn;
     {
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         tm = min(band * GM + in_grp / grp_cols, tiles_m - 1);
         tn = grp * GN + in_grp % grp_cols;
     }
-    const int m0 = tm * V3_BM, n0 = tn * V3_BN;
+    const int m0 = tm * (HM ? V3_BM / 2 : V3_BM), n0 = tn * V3_BN;
 
     // ---- LDS-DMA source offsets (elements), shared by both passes. A part P, DMA d: 8-row group g = wave + 8 d of
     // the part's 128 rows; part row s belongs to wave row s >> 6 and is tile row (s >> 6) * 128 + 64 P + (s & 63).
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             if (AK) {                          // instruction g = wave + 8 d: k-rows 4 g .. 4 g + 3, 16 chunks each
                 const int kr = 4 * (wave + 8 * d) + (lane >> 4);
                 const int cs = (lane & 15) ^ (hk(kr) << 1);
-                a_off[P][d] = kr * (int)lda + m0 + (cs >> 3) * 128 + 64 * P + (cs & 7) * 8;
+                a_off[P][d] = kr * (int)lda + m0 + (cs >> 3) * (HM ? 64 : 128) + 64 * P + (cs & 7) * 8;      // (HM: P = 0 only)
             } else {
                 const int s = 8 * (wave + 8 * d) + (lane >> 3);
                 const int row = (s >> 6) * 128 + 64 * P + (s & 63);
@@ -197,10 +206,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     // the main loop's form: LDS destination and K offset are LOOP-CARRIED scalars (run_pass), so a piece costs one
     // scalar add for M0 instead of six scalar operations recomputing both from the step index (lab: the address work
     // was 8-10 % of the loop, which is bound by the issue of these pieces)
+#if defined(V3_LAB_PIECE)
+    typedef int lab_i32x4 __attribute__((ext_vector_type(4)));
+    lab_i32x4 lab_stg[4] = {lab_i32x4{0, 0, 0, 0}, lab_i32x4{0, 0, 0, 0}, lab_i32x4{0, 0, 0, 0}, lab_i32x4{0, 0, 0, 0}};
+#endif
     auto dma_a_at = [&](unsigned lds_off, int so_bytes, auto P_c, auto d_c) {
         constexpr int P = decltype(P_c)::value, D = decltype(d_c)::value;
         unsigned char* dst = lds + lds_off + (P * V3_APART + D * 8192) + wave * 1024;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(V3_LAB_PIECE)
+        // tools/gemm_lab.hip only (timing, wrong results): what a piece costs in other forms. 1: no piece at all; 2: a plain
+        // 16-byte buffer load into registers, no LDS write; 3: that load + a ds_write_b128 of the registers loaded one phase ago
+        if constexpr (V3_LAB_PIECE >= 2) {
+            if constexpr (V3_LAB_PIECE == 3) *reinterpret_cast<lab_i32x4*>(dst + lane * 16) = lab_stg[D];
+            lab_stg[D] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(2u * (unsigned)a_off[P][D]), so_bytes, 0);
+        }
+#elif defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)dst, 16, (int)(2u * (unsigned)a_off[P][D]), so_bytes, 0, 0);
 #else
         __builtin_amdgcn_global_load_lds((gptr_t)(Ap + a_off[P][D] + so_bytes / 2), (lptr_t)dst, 16, 0, 0);
@@ -209,7 +229,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     auto dma_b_at = [&](unsigned lds_off, int so_bytes, auto d_c) {
         constexpr int D = decltype(d_c)::value;
         unsigned char* dst = lds + lds_off + (4 * V3_APART + D * 8192) + wave * 1024;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(V3_LAB_PIECE)
+        if constexpr (V3_LAB_PIECE >= 2) {
+            if constexpr (V3_LAB_PIECE == 3) *reinterpret_cast<lab_i32x4*>(dst + lane * 16) = lab_stg[2 + (D & 1)];
+            lab_stg[2 + (D & 1)] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(2u * (unsigned)b_off[D]), so_bytes, 0);
+        }
+#elif defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)dst, 16, (int)(2u * (unsigned)b_off[D]), so_bytes, 0, 0);
 #else
         __builtin_amdgcn_global_load_lds((gptr_t)(Bp + b_off[D] + so_bytes / 2), (lptr_t)dst, 16, 0, 0);
@@ -353,6 +378,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         dma_b(0, 0, c2); dma_b(0, 0, c3); dma_a(0, c1, c0); dma_a(0, c1, c1);
         if (nk > 1) {
             dma_b(1, 1, c0); dma_b(1, 1, c1); dma_a(1, c0, c0); dma_a(1, c0, c1);
+            dma_b(1, 1, c2); dma_b(1, 1, c3);
+        }
+    };
+    auto prologue_hm = [&]() {          // HM: the six pieces of step 0, then of step 1 (A parts 0 and 1 of the ring of four)
+        dma_b(0, 0, c0); dma_b(0, 0, c1); dma_a_at(0u, 0, c0, c0); dma_a_at(0u, 0, c0, c1);
+        dma_b(0, 0, c2); dma_b(0, 0, c3);
+        if (nk > 1) {
+            dma_b(1, 1, c0); dma_b(1, 1, c1); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c0); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c1);
             dma_b(1, 1, c2); dma_b(1, 1, c3);
         }
     };
@@ -508,6 +541,73 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
             ka += da; kb += db;
         };
+        if constexpr (HM) {
+            // ---- the half-height form: one phase per K step on the wave's 64 x 64 tile (acc[0..3][]), the A parts a ring of four.
+            // Step t: s_waitcnt vmcnt(6) (the six pieces of step t + 1 may stay in flight) -> barrier -> the phase-0 schedule of
+            // the K-major loop above with six pieces beside the 32 MFMAs: A of step t + 2 (two, into part (t + 2) & 3, last read
+            // in step t - 2), B of step t + 2 (four, into the slot step t - 1 read).
+            unsigned oa4 = 0;                                       // A part of step t: (t & 3) * V3_APART
+            auto kstep_hm = [&](const int t) {
+                const bool n2 = t + 2 < nk;
+                const int so_a2 = ka + 2 * da, so_b2 = kb + 2 * db;
+                const unsigned oa2 = oa4 ^ (2u * V3_APART);
+                const unsigned char* sb = lds + 4 * V3_APART + ob;
+                const unsigned char* sa = lds + oa4;
+                bf16x8 bf[2][4];
+                if (t + 1 < nk) v2_wait_barrier<6>(); else v2_wait_barrier<0>();
+                auto dma_slot = [&](int k) {
+                    if (!n2) return;
+                    if (k == 0) dma_a_at(oa2, so_a2, c0, c0);
+                    if (k == 1) dma_a_at(oa2, so_a2, c0, c1);
+                    if (k == 2) dma_b_at(ob2, so_b2, c0);
+                    if (k == 3) dma_b_at(ob2, so_b2, c1);
+                    if (k == 4) dma_b_at(ob2, so_b2, c2);
+                    if (k == 5) dma_b_at(ob2, so_b2, c3);
+                };
+                const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
+                TrPair g[3];
+                auto issue = [&](auto idx_c) {             // as in the full-height loop: three pairs in rotation, the two before kept
+                    constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                    if constexpr (IDX == 0)
+                        tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                  std::integral_constant<int, S * 8192 + 1024>(), g[0]);
+                    else
+                        tr_issue2_keep(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                       std::integral_constant<int, S * 8192 + 1024>(), g[IDX % 3], g[(IDX + 2) % 3],
+                                       g[IDX >= 2 ? (IDX + 1) % 3 : (IDX + 2) % 3]);
+                };
+                auto work = [&](auto idx_c) {
+                    constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                    TrPair& p = g[IDX % 3];
+                    tr_wait2(p);
+                    if constexpr (IDX < 3) issue(std::integral_constant<int, IDX + 1>());
+                    if constexpr (IDX == 1) {                            // the other k-half's B fragments
+                        const unsigned bb = (unsigned)(uintptr_t)(ldsb_t)sb;
+                        tr_load4_keep(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], std::integral_constant<int, 16384>(),
+                                      std::integral_constant<int, 16384 + 2048>(), bf[1], p, g[0]);
+                    }
+                    const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bf[S][j], acc[F][j], 0, 0, 0);
+                    if constexpr (IDX < 2) { dma_slot(2 * IDX); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[F + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bf[S][j], acc[F + 1][j], 0, 0, 0);
+                    dma_slot(IDX < 2 ? 2 * IDX + 1 : IDX + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                load_b(sb, c0, bf[0]);
+                issue(c0);
+                work(c0); work(c1); work(c2); work(c3);
+                keep_frags(bf[0]); keep_frags(bf[1]);
+                oa4 = (oa4 + V3_APART) & (4u * V3_APART - 1u);
+                ob = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+                ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
+                ka += da; kb += db;
+            };
+            for (int t = 0; t < nk; ++t) kstep_hm(t);
+            return;
+        }
         int t = 0;
         for (; t + 2 < nk; ++t) kstep(t, std::false_type());
         for (; t < nk; ++t) kstep(t, std::true_type());
@@ -542,7 +642,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     // PARK functors only: this workgroup's scratch tile, [8 i][4 j][512 threads] f32x4, written and read by the same thread
     f32x4* park = reinterpret_cast<f32x4*>(mscratch + (size_t)blockIdx.x * (V3_BM * V3_BN));
     auto for_quarters = [&](auto&& fn) {
-        fn(c0, c0, 0); fn(c0, c1, 1); fn(c1, c0, 2); fn(c1, c1, 3);
+        fn(c0, c0, 0); fn(c0, c1, 1);
+        if constexpr (!HM) { fn(c1, c0, 2); fn(c1, c1, 3); }
     };
 
     if (DUAL) {
@@ -720,13 +821,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         run_pass();
     } else {
         zero_acc();
-        prologue();
+        if constexpr (HM) prologue_hm(); else prologue();
         run_pass();
     }
     __syncthreads();
     V3_ST(1);
+#if defined(V3_LAB_PIECE)
+    asm volatile("" ::"v"(lab_stg[0]), "v"(lab_stg[1]), "v"(lab_stg[2]), "v"(lab_stg[3]));
+#endif
 
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT && !HM) {
         // ---- split-K hand-off (gemm_v2.h's protocol: cdna_hip_programming.md Guideline 16 R1 in its ticket form). Both K
         // halves store their partial tile as it stands in the MFMA layout (thread-private 16-byte slots, write-through),
         // drain, take a ticket; ticket 0 is done; ticket 1 acquires, adds the other half's partial and goes on.
@@ -779,7 +883,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     const bool any_t = (tp1 != nullptr) || (tp2 != nullptr);
     for_quarters([&](auto hh_c, auto jj_c, int qq) {
         constexpr int HH = decltype(hh_c)::value, JJ = decltype(jj_c)::value;
-        const int wm0 = m0 + wr * 128 + HH * 64, wn0 = n0 + wc * 64 + JJ * 32;
+        const int wm0 = m0 + wr * (HM ? 64 : 128) + HH * 64, wn0 = n0 + wc * 64 + JJ * 32;
         (void)qq;
         if constexpr (SPLIT) { if (wm0 > epi.m_dim()) return; }   // a quarter wholly past the ones row: nothing to store
         f32x4 r1[8], av[8];
@@ -961,6 +1065,8 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
 
 // ---- the SPLIT launch (K-major operands only: accGradParameters reading x and g as the other GEMMs hold them)
 static int g_v3_split = -1;         // -1 by shape, 0 never, 1 whenever possible (vbnn_debug_set key 8)
+static int g_v3_hm = 1;             // the half-height pair-split form (HM): 0 never, 1 where its grid fills the CUs in one round,
+                                    // 2 whenever the split launch is taken (vbnn_debug_set key 8, values 2 / 3 / 4)
 // shape part: M rows of output (the ones row included) on N columns, K deep. Wanted when the pair split alone would leave
 // half the CUs idle and both K halves are long enough to amortise the pipeline fill and the hand-off.
 static inline bool gemm_v3_split_shape_ok(int64_t M, int64_t N, int64_t K) {
@@ -985,8 +1091,13 @@ static int launch_gemm_v3_split(vbnn_ctx* ctx, const T* A, const T* A2, int64_t 
             (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2 | (uintptr_t)B2) & 15u) != 0 || lda % 8 || ldb % 8 ||
             lda < gemm_v3_split_lda(M) || ldb < N || (int64_t)K * lda >= (1ll << 30) || (int64_t)K * ldb >= (1ll << 30))
             return VBNN_ERR_UNSUPPORTED;
-        const int tiles_m = (M + V3_BM - 1) / V3_BM, tiles_n = N / V3_BN;
-        const size_t need = (size_t)tiles_m * tiles_n * 2 * 2 * V3_BM * V3_BN * sizeof(float);     // a partial tile per K half
+        const int tiles_n = N / V3_BN;
+        // the half-height form (HM) when its 128-row tiles x 2 make ONE round that fills at least 5/8 of the CUs: no K split
+        const int tiles_hm = (M + V3_BM / 2 - 1) / (V3_BM / 2);
+        const int64_t cus = vbnn_cu_count();
+        const bool hm = g_v3_hm == 2 || (g_v3_hm == 1 && (int64_t)tiles_hm * tiles_n * 2 <= cus && (int64_t)tiles_hm * tiles_n * 16 >= 5 * cus);
+        const int tiles_m = hm ? tiles_hm : (M + V3_BM - 1) / V3_BM;
+        const size_t need = hm ? 0 : (size_t)tiles_m * tiles_n * 2 * 2 * V3_BM * V3_BN * sizeof(float);     // a partial tile per K half
         if (need > ctx->park_bytes) {
             (void)hipStreamSynchronize(ctx->stream);
             if (ctx->park) (void)hipFree(ctx->park);
@@ -995,9 +1106,9 @@ static int launch_gemm_v3_split(vbnn_ctx* ctx, const T* A, const T* A2, int64_t 
             if (e != hipSuccess) { vbnn_set_error("hipMalloc(gemm_v3 split-K slabs, %zu bytes): %s", need, hipGetErrorString(e)); return VBNN_ERR_NOMEM; }
             ctx->park_bytes = need;
         }
-        const void* kern = (const void*)gemm_nt_v3<false, true, true, Epi, true>;
-        static vbnn_per_device_flag configured_on;
-        bool& configured = configured_on[ctx->device];
+        const void* kern = hm ? (const void*)gemm_nt_v3<false, true, true, Epi, true, true> : (const void*)gemm_nt_v3<false, true, true, Epi, true>;
+        static vbnn_per_device_flag configured_on[2];        // per form and device
+        bool& configured = configured_on[hm ? 1 : 0][ctx->device];
         if (!configured) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
@@ -1011,7 +1122,7 @@ static int launch_gemm_v3_split(vbnn_ctx* ctx, const T* A, const T* A2, int64_t 
         unsigned* tickets_ = ctx->counters + VBNN_CNT_TILES;
         Epi epi_ = epi;
         void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &park, &tickets_, &epi_};
-        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * 4), dim3(512), args, V3_LDS, ctx->stream);
+        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * (hm ? 2 : 4)), dim3(512), args, V3_LDS, ctx->stream);
         if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v3 (split) failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
         return vbnn_check_launch("gemm_nt_v3 split");
     }
