@@ -28,6 +28,14 @@
 #pragma once
 #include "gemm_v2.h"
 
+#ifndef V3_HM_AHEAD
+// 1: the half-height form reads a step's B fragments and its first A pair ONE STEP AHEAD into a second register set (pieces three
+// steps ahead), so a step opens with MFMAs instead of two LDS round trips behind its barrier. Parity-green and hazard-clean
+// (tests, tools/check_lds_war.py) and a WASH: 0.8297-0.8321 against 0.8290-0.8328 ms per wide step, three rounds on one box
+// (make LIBDIR=../lib/ab EXTRA=-DV3_HM_AHEAD=1). Like the half-phase stagger of waves 4-7 tried on the full-height loop the
+// same day (bitwise equal, 104.9 -> 105.0 us per 4096^3 pass), it says the start-of-phase LDS latency is not what these loops wait for.
+#define V3_HM_AHEAD 0
+#endif
 constexpr int V3_BM = 256, V3_BN = 256;
 constexpr int V3_APART = 128 * 128;                  // bytes: 128 rows x 128 B
 constexpr int V3_BTILE = 256 * 128;
@@ -388,6 +396,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             dma_b(1, 1, c0); dma_b(1, 1, c1); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c0); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c1);
             dma_b(1, 1, c2); dma_b(1, 1, c3);
         }
+#if V3_HM_AHEAD
+        if (nk > 2) {                   // ... and of step 2: the pieces run three steps ahead of the MFMAs (run_pass)
+            dma_b(2, 2, c0); dma_b(2, 2, c1); dma_a_at(2u * V3_APART, 4 * a_kstep, c0, c0); dma_a_at(2u * V3_APART, 4 * a_kstep, c0, c1);
+            dma_b(2, 2, c2); dma_b(2, 2, c3);
+        }
+#endif
     };
     auto run_pass = [&]() {
         // loop-carried scalars of step t: LDS offset of A part (t & 1) * 2, of B slots t % 3 and (t + 2) % 3, and the
@@ -541,6 +555,114 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
             ka += da; kb += db;
         };
+#if V3_HM_AHEAD
+        if constexpr (HM) {
+            // ---- the half-height form, fragments read ONE STEP AHEAD: one phase per K step on the wave's 64 x 64 tile
+            // (acc[0..3][]). The step's B fragments (both k-halves) and its first A pair are read from LDS at the END of the
+            // step before -- into the second of two register sets (the tile leaves ~110 registers free) -- so a step opens
+            // with MFMAs instead of two dependent LDS round trips behind its barrier; A pairs 1..3 stay pipelined under the
+            // MFMAs as in the full-height loop. For that the pieces run THREE steps ahead: at barrier t every wave has waited
+            // for its pieces of step t + 1 (vmcnt(6): only step t + 2's six may be in flight), during step t it issues step
+            // t + 3's: A into part (t + 3) & 3 (last read during step t - 1), B into slot t % 3 (read completely at the end of
+            // step t - 1: that is why BOTH B k-halves are read ahead).
+            struct Ahead { bf16x4 bl[2][4], bh[2][4]; TrPair p0; };
+            Ahead X, Y;
+            TrPair g1, g2, g3;                                      // A pairs 1..3 of the step at hand (named across steps: see the keeps)
+            g3 = TrPair{bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}};
+            unsigned oa4 = 0;                                       // A part of step t: (t & 3) * V3_APART
+            // eight transpose reads of a B k-half, issued only (the next barrier's lgkmcnt(0) retires them)
+            auto tr_issue4_keep = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x4 (&l)[4], bf16x4 (&h)[4],
+                                      const TrPair& keep, const TrPair& keep2) {
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+                asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+                             "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+                             "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+                             "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
+                             : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
+                             : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI), "v"(keep.l0), "v"(keep.h0), "v"(keep.l1), "v"(keep.h1),
+                               "v"(keep2.l0), "v"(keep2.h0), "v"(keep2.l1), "v"(keep2.h1)
+                             : "memory");
+            };
+            auto read_ahead = [&](Ahead& n, unsigned oa_n, unsigned ob_n, const TrPair& keep, const TrPair& keep2) {
+                const unsigned bb = (unsigned)(uintptr_t)(ldsb_t)(lds + 4 * V3_APART + ob_n);
+                const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)(lds + oa_n);
+                tr_issue4_keep(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], c0, std::integral_constant<int, 2048>(), n.bl[0], n.bh[0], keep, keep2);
+                tr_issue4_keep(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], std::integral_constant<int, 16384>(),
+                               std::integral_constant<int, 16384 + 2048>(), n.bl[1], n.bh[1], keep, keep2);
+                tr_issue2_keep(ba + a_tr[0], ba + a_tr[1], c0, std::integral_constant<int, 1024>(), n.p0, keep, keep2);
+            };
+            // the set's registers are DEFINED here for the compiler: behind the barrier whose lgkmcnt(0) retired the reads
+            auto landed = [&](Ahead& c) {
+                asm volatile("" : "+v"(c.bl[0][0]), "+v"(c.bh[0][0]), "+v"(c.bl[0][1]), "+v"(c.bh[0][1]), "+v"(c.bl[0][2]), "+v"(c.bh[0][2]),
+                                  "+v"(c.bl[0][3]), "+v"(c.bh[0][3]), "+v"(c.p0.l0), "+v"(c.p0.h0), "+v"(c.p0.l1), "+v"(c.p0.h1)::"memory");
+                asm volatile("" : "+v"(c.bl[1][0]), "+v"(c.bh[1][0]), "+v"(c.bl[1][1]), "+v"(c.bh[1][1]), "+v"(c.bl[1][2]), "+v"(c.bh[1][2]),
+                                  "+v"(c.bl[1][3]), "+v"(c.bh[1][3])::"memory");
+            };
+            auto step = [&](const int t, Ahead& c, Ahead& n) {
+                const bool n3 = t + 3 < nk;
+                const int so_a3 = ka + 3 * da, so_b3 = kb + 3 * db;
+                const unsigned oa3 = (oa4 + 3u * V3_APART) & (4u * V3_APART - 1u);
+                const unsigned oa1 = (oa4 + V3_APART) & (4u * V3_APART - 1u);
+                const unsigned ob1 = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+                if (t + 2 < nk) v2_wait_barrier<6>(); else v2_wait_barrier<0>();
+                landed(c);
+                auto dma_slot = [&](int k) {
+                    if (!n3) return;
+                    if (k == 0) dma_a_at(oa3, so_a3, c0, c0);
+                    if (k == 1) dma_a_at(oa3, so_a3, c0, c1);
+                    if (k == 2) dma_b_at(ob, so_b3, c0);             // slot t % 3: B of step t is in registers
+                    if (k == 3) dma_b_at(ob, so_b3, c1);
+                    if (k == 4) dma_b_at(ob, so_b3, c2);
+                    if (k == 5) dma_b_at(ob, so_b3, c3);
+                };
+                const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)(lds + oa4);
+                bf16x8 bf[2][4];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bf[s2][j] = __builtin_shufflevector(c.bl[s2][j], c.bh[s2][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                auto mfma8 = [&](const TrPair& p, auto s_c, auto f_c) {
+                    constexpr int S = decltype(s_c)::value, F = decltype(f_c)::value;
+                    const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bf[S][j], acc[F][j], 0, 0, 0);
+                    if constexpr (S == 0) { dma_slot(F); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[F + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bf[S][j], acc[F + 1][j], 0, 0, 0);
+                    dma_slot(S == 0 ? F + 1 : 4 + F / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // pair 1 (k-half 0, fragments 2, 3) flies under pair 0's MFMAs, and so on; a read never lands in a pair whose
+                // MFMAs are among the wave's last eight (kept: that pair and the one before)
+                tr_issue2_keep(ba + a_tr[2], ba + a_tr[3], c0, std::integral_constant<int, 1024>(), g1, g3, g3);   // (g3: the step before's last eight)
+                mfma8(c.p0, c0, c0);
+                tr_wait2(g1);
+                tr_issue2_keep(ba + a_tr[0], ba + a_tr[1], std::integral_constant<int, 8192>(), std::integral_constant<int, 8192 + 1024>(), g2, c.p0, g1);
+                mfma8(g1, c0, c2);
+                tr_wait2(g2);
+                tr_issue2_keep(ba + a_tr[2], ba + a_tr[3], std::integral_constant<int, 8192>(), std::integral_constant<int, 8192 + 1024>(), g3, g1, g2);
+                mfma8(g2, c1, c0);
+                tr_wait2(g3);
+                if (t + 1 < nk) read_ahead(n, oa1, ob1, g2, g3);     // next step's set: under this step's last eight MFMAs
+                mfma8(g3, c1, c2);
+                keep_frags(bf[0]); keep_frags(bf[1]);
+                oa4 = oa1;
+                ob = ob1;
+                ka += da; kb += db;
+            };
+            // the first step's set: its pieces (the first six of the fill) have landed for every wave behind this barrier
+            if (nk > 2) v2_wait_barrier<12>(); else if (nk > 1) v2_wait_barrier<6>(); else v2_wait_barrier<0>();
+            {
+                TrPair z{bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}};
+                read_ahead(X, 0u, 0u, z, z);
+            }
+            int t = 0;
+            for (; t + 1 < nk; t += 2) { step(t, X, Y); step(t + 1, Y, X); }
+            if (t < nk) step(t, X, Y);
+            return;
+        }
+#else
         if constexpr (HM) {
             // ---- the half-height form: one phase per K step on the wave's 64 x 64 tile (acc[0..3][]), the A parts a ring of four.
             // Step t: s_waitcnt vmcnt(6) (the six pieces of step t + 1 may stay in flight) -> barrier -> the phase-0 schedule of
@@ -608,6 +730,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             for (int t = 0; t < nk; ++t) kstep_hm(t);
             return;
         }
+#endif
         int t = 0;
         for (; t + 2 < nk; ++t) kstep(t, std::false_type());
         for (; t < nk; ++t) kstep(t, std::true_type());
