@@ -127,7 +127,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     }
     int tm, tn;
     {
-        constexpr int GM = 4, GN = 8;
+        // (HM: an A panel is half the size of a B panel and a round is 28 workgroups per XCD -- 8 x 4 groups: for the 7 x 16 tiles of
+        // the 784 x 4096 gradient every XCD holds ALL of x^T and four panels of g^T, 15 MB per GEMM instead of 20)
+        constexpr int GM = HM ? 8 : 4, GN = HM ? 4 : 8;
         const int per_band = GM * tiles_n;
         const int band = bid / per_band;
         const int in_band = bid - band * per_band;
