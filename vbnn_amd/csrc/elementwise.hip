@@ -632,7 +632,9 @@ __global__ __launch_bounds__(256) void k_prep_layer(const float* __restrict__ me
                 load4<float>(lvars + r * I + c, l, valid, vec_in);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (e < valid) { v[e] = expf(l[e]); s1 += (double)(v[e] + m[e] * m[e]); s2 += (double)l[e]; }
+                    // (vars + mu_sqe as the fp32 tensors of VBLinear.lua:82-86: the square and the sum rounded separately, whatever
+                    // the compiler would contract -- the update sweep forms the same terms in another order of elements)
+                    if (e < valid) { v[e] = expf(l[e]); s1 += (double)__fadd_rn(v[e], __fmul_rn(m[e], m[e])); s2 += (double)l[e]; }
                 store4<T>(mu_s + r * ld_w + c, m[0], m[1], m[2], m[3], valid, true);
                 store4<T>(var_s + r * ld_w + c, v[0], v[1], v[2], v[3], valid, true);
             }
@@ -805,17 +807,8 @@ __global__ __launch_bounds__(256) void k_vb_update(UpdLayer a) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.0;
     acc[12] = acc[14] = 1e300; acc[13] = acc[15] = -1e300;
-    for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
-        const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = threadIdx.x + 256 * k;
-            const int rr = idx >> 4, c4 = (idx & 15) * 4;
-            const int64_t r = r0 + rr, c = c0 + c4;
-            float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
-            const int valid = (r < O) ? (int)min((int64_t)4, I - c) : 0;
-            if (valid > 0) {
-                const int64_t base = r * I + c;
+    // four consecutive weights of row r (columns c .. c + valid - 1, flat index base): everything the sweep does with them
+    auto elem4 = [&](const int64_t base, const int64_t r, const int64_t c, const int valid, float (&m)[4], float (&v)[4]) {
                 float l[4], gm[4], gl[4], mm[4], vm[4], ml[4], vl[4];
                 load4<float>(a.means + base, m, valid, vec_in);
                 load4<float>(a.lvars + base, l, valid, vec_in);
@@ -847,7 +840,7 @@ __global__ __launch_bounds__(256) void k_vb_update(UpdLayer a) {
                         const float ul = a.step_lv * ml[e] / (sqrtf(vl[e]) + a.eps_lv);
                         l[e] -= ul;
                         v[e] = expf(l[e]);
-                        acc[0] += (double)(v[e] + m[e] * m[e]); acc[1] += (double)l[e];
+                        acc[0] += (double)__fadd_rn(v[e], __fmul_rn(m[e], m[e])); acc[1] += (double)l[e];      // as k_prep_layer
                         acc[2] += (double)um * um; acc[3] += (double)m[e] * m[e];
                         acc[4] += (double)ul * ul; acc[5] += (double)l[e] * l[e];
                         acc[10] += (double)v[e]; acc[11] += (double)m[e];
@@ -862,7 +855,30 @@ __global__ __launch_bounds__(256) void k_vb_update(UpdLayer a) {
                 store4<float>(a.v_lv + base, vl[0], vl[1], vl[2], vl[3], valid, vec_in);
                 store4<T>(mu_s + r * a.ld_w + c, m[0], m[1], m[2], m[3], valid, true);
                 store4<T>(var_s + r * a.ld_w + c, v[0], v[1], v[2], v[3], valid, true);
-            }
+    };
+    if (!muT_s && vec_in && (int64_t)gridDim.x * 1024 <= O * I) {
+        // FLAT form (no transposed shadows to build: the K-major configurations): the eight fp32 streams are walked as flat
+        // arrays, 4 KB per workgroup and stream at a time -- a wave-instruction is ONE contiguous KiB instead of four rows
+        // x 256 B of a 64 x 64 tile (16 KB apart in a 4096-wide layer: four DRAM pages per instruction and stream)
+        const int64_t total = O * I;
+        for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; base < total; base += (int64_t)gridDim.x * 1024) {
+            const int64_t r = base / I, c = base - r * I;          // I % 4 == 0 (vec_in): the four weights share a row
+            float m[4], v[4];
+            elem4(base, r, c, 4, m, v);
+        }
+        upd_block_reduce(acc, a.partial + (size_t)blockIdx.x * UPD_NSUM, sh);
+        return;
+    }
+    for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
+        const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            const int rr = idx >> 4, c4 = (idx & 15) * 4;
+            const int64_t r = r0 + rr, c = c0 + c4;
+            float m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
+            const int valid = (r < O) ? (int)min((int64_t)4, I - c) : 0;
+            if (valid > 0) elem4(r * I + c, r, c, valid, m, v);
             if (muT_s) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { tm[rr][c4 + e] = m[e]; tv[rr][c4 + e] = v[e]; }
@@ -1014,6 +1030,21 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ sr
     const int64_t ntiles = tiles_c * tiles_r;
     const bool vec_in = ((ld_src & 3) == 0) && (((uintptr_t)src & 15u) == 0);
     const bool vec_t = (ld_xT & 3) == 0;
+    if (!xT_s && vec_in && (I & 3) == 0) {
+        // no transposes to build (the K-major configurations): the rows are walked flat, a wave-instruction one contiguous
+        // KiB of the minibatch instead of four rows x 256 B of a 64 x 64 tile (as k_vb_update's flat form)
+        const int64_t total = N * I;
+        for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; base < total; base += (int64_t)gridDim.x * 1024) {
+            const int64_t r = base / I, c = base - r * I;
+            float a[4], b[4];
+            load4<float>(src + (rpd > 0 ? r % rpd : r) * ld_src + c, a, 4, true);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float ar = Elt<T>::from(Elt<T>::to(a[e])); b[e] = ar * ar; }
+            store4<T>(x_s + r * ld_x + c, a[0], a[1], a[2], a[3], 4, true);
+            if (x2_s) store4<T>(x2_s + r * ld_x + c, b[0], b[1], b[2], b[3], 4, true);
+        }
+        return;
+    }
     for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
         const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
 #pragma unroll
