@@ -1030,21 +1030,6 @@ __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ sr
     const int64_t ntiles = tiles_c * tiles_r;
     const bool vec_in = ((ld_src & 3) == 0) && (((uintptr_t)src & 15u) == 0);
     const bool vec_t = (ld_xT & 3) == 0;
-    if (!xT_s && vec_in && (I & 3) == 0) {
-        // no transposes to build (the K-major configurations): the rows are walked flat, a wave-instruction one contiguous
-        // KiB of the minibatch instead of four rows x 256 B of a 64 x 64 tile (as k_vb_update's flat form)
-        const int64_t total = N * I;
-        for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; base < total; base += (int64_t)gridDim.x * 1024) {
-            const int64_t r = base / I, c = base - r * I;
-            float a[4], b[4];
-            load4<float>(src + (rpd > 0 ? r % rpd : r) * ld_src + c, a, 4, true);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float ar = Elt<T>::from(Elt<T>::to(a[e])); b[e] = ar * ar; }
-            store4<T>(x_s + r * ld_x + c, a[0], a[1], a[2], a[3], 4, true);
-            if (x2_s) store4<T>(x2_s + r * ld_x + c, b[0], b[1], b[2], b[3], 4, true);
-        }
-        return;
-    }
     for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
         const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
 #pragma unroll
