@@ -13,7 +13,7 @@ times the whole training step (step + update) beside it. Inputs are resident in 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config wide|small|deep]
 N > 1: launched by the driver through torch.distributed.run (one rank per GPU, RCCL) -- or, from a bare shell, by
 bench.py itself: a parent that has not imported torch or touched HIP starts the same torch.distributed.run line as a
-CHILD process, relays its output and exits with its code. The timed region is `--repeats` (5) blocks of exactly K
+CHILD process, relays its output and exits with its code. The timed region is `--repeats` (7) blocks of exactly K
 steps, each bracketed by barrier + synchronize (wall clock, MAX over ranks) and by HIP events; `ms_per_step` is the
 median block. Prints ONE JSON line on rank 0.
 """
@@ -234,7 +234,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; ms_per_step is the median block")
+    ap.add_argument("--repeats", type=int, default=7, help="timed blocks of --steps steps; ms_per_step is the median block (seven: "
+                    "behind a short warm-up the first two blocks still run on the chip's clock ramp, and every block is reported)")
     ap.add_argument("--config", default="wide", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reporting-config", action="store_true", help="skip the 784-400-400-10 / batch 256 / fp32 row measured beside the headline")
@@ -504,7 +505,7 @@ def main():
                        "step": ("resetGradients, prepare, S x (sample, run), all-reduce" if args.prepare_each_step else
                                 "resetGradients, S x (sample, run), all-reduce; the parameter sweep (compute_prior + operand "
                                 "shadows) belongs to the excluded update, as VBLinear.lua:130 has it: prepare() ran once"),
-                       "timing": f"median of {len(wall)} blocks of {args.steps} steps, wall clock between barrier+synchronize, MAX over ranks",
+                       "timing": f"median of {len(wall)} blocks of {args.steps} steps (all in repeats_wall_ms; behind a short warm-up the first blocks run on the clock ramp), wall clock between barrier+synchronize, MAX over ranks",
                        "repeats_wall_ms": [round(v, 4) for v in wall], "repeats_event_ms": [round(v, 4) for v in evms],
                        "probed_block_ms": round(probed_ms, 4),
                        "backward_order": ("every updateGradInput, then the accGradParameters from the first layer up" if eng.dx_first

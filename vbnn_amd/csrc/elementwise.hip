@@ -618,6 +618,24 @@ __global__ __launch_bounds__(256) void k_prep_layer(const float* __restrict__ me
     // the shadows, and -- after the LDS transpose -- 4 consecutive rows of one column for the transposed shadows
     const bool vec_in = ((I & 3) == 0) && ((((uintptr_t)means | (uintptr_t)lvars) & 15u) == 0);
     const bool vec_t = muT_s && ((ld_wT & 3) == 0);
+    if (!muT_s && vec_in && (int64_t)gridDim.x * 1024 <= O * I) {
+        // FLAT form (no transposed shadows to build), as k_vb_update's: a wave-instruction is one contiguous KiB of means / lvars
+        const int64_t total = O * I;
+        for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; base < total; base += (int64_t)gridDim.x * 1024) {
+            const int64_t r = base / I, c = base - r * I;
+            float m[4], l[4], v[4];
+            load4<float>(means + base, m, 4, true);
+            load4<float>(lvars + base, l, 4, true);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = expf(l[e]); s1 += (double)__fadd_rn(v[e], __fmul_rn(m[e], m[e])); s2 += (double)l[e]; }
+            store4<T>(mu_s + r * ld_w + c, m[0], m[1], m[2], m[3], 4, true);
+            store4<T>(var_s + r * ld_w + c, v[0], v[1], v[2], v[3], 4, true);
+        }
+        const double r1 = block_sum(s1, sh);
+        const double r2 = block_sum(s2, sh);
+        if (threadIdx.x == 0) { partial[blockIdx.x * 2] = r1; partial[blockIdx.x * 2 + 1] = r2; }
+        return;
+    }
     for (int64_t tI = blockIdx.x; tI < ntiles; tI += gridDim.x) {
         const int64_t r0 = (tI / tiles_c) * 64, c0 = (tI % tiles_c) * 64;
 #pragma unroll
