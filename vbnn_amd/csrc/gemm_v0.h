@@ -34,7 +34,10 @@ __device__ __forceinline__ f32x4 v0_mfma16(const f32x4& a, const f32x4& b, f32x4
 #ifndef V0_LAB_PD
 #define V0_LAB_PD 2          // (lab: 2 <= 4 < 8 < 16 in time at every shape of the small MLP: the walk is issue-bound, not latency-bound)
 #endif
-constexpr int V0_W = 4;              // waves of a workgroup = K splits
+#ifndef V0_LAB_W
+#define V0_LAB_W 4          // (lab, r03: 8 waves = an eighth of the K walk each: K = 784 forward 6.39 against 6.53 us, every other shape +-0.1 -- the walk is not what a launch waits for)
+#endif
+constexpr int V0_W = V0_LAB_W;       // waves of a workgroup = K splits
 constexpr int V0_PD = V0_LAB_PD;     // k groups of loads in flight per wave
 // functors whose epilogue draws noise that depends on indices alone offer draw_fast / apply_fast_z (EpiFwd): detected here
 template <class E, class = void> struct v0_pre_noise : std::false_type { struct type {}; };
