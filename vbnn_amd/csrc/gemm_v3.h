@@ -29,12 +29,14 @@
 #include "gemm_v2.h"
 
 #ifndef V3_HM_AHEAD
-// 1: the half-height form reads a step's B fragments and its first A pair ONE STEP AHEAD into a second register set (pieces three
-// steps ahead), so a step opens with MFMAs instead of two LDS round trips behind its barrier. Parity-green and hazard-clean
-// (tests, tools/check_lds_war.py) and a WASH: 0.8297-0.8321 against 0.8290-0.8328 ms per wide step, three rounds on one box
-// (make LIBDIR=../lib/ab EXTRA=-DV3_HM_AHEAD=1). Like the half-phase stagger of waves 4-7 tried on the full-height loop the
-// same day (bitwise equal, 104.9 -> 105.0 us per 4096^3 pass), it says the start-of-phase LDS latency is not what these loops wait for.
-#define V3_HM_AHEAD 0
+// 1 (default): the half-height form reads a step's B fragments and its first A pair ONE STEP AHEAD into a second register set
+// (pieces three steps ahead), so a step opens with MFMAs instead of two LDS round trips behind its barrier. In-kernel stamps
+// (tools/split_lab, profiles/r03_stamps.txt): main loop 66.1-68.3 -> 64.2-64.5 us, the launch 76.6-78.3 -> 71.9-74.5 us (two
+// rounds on one box; without pieces 52.4-53.1 -> 49.4-50.5) -- 5 %, a quarter of what the exposed latencies add up to on
+// paper; inside the wide step the difference drowns in the box's noise (0.8297-0.8321 against 0.8290-0.8328 ms). 0: the plain
+// form (A/B: make LIBDIR=../lib/ab EXTRA=-DV3_HM_AHEAD=0). The half-phase stagger of waves 4-7 tried on the full-height
+// loop the same day (bitwise equal, 104.9 -> 105.0 us per 4096^3 pass) did nothing at all.
+#define V3_HM_AHEAD 1
 #endif
 constexpr int V3_BM = 256, V3_BN = 256;
 constexpr int V3_APART = 128 * 128;                  // bytes: 128 rows x 128 B
