@@ -112,6 +112,13 @@ int vbnn_buf_download(vbnn_ctx* ctx, void* dst_host, const void* src_dev, size_t
 int vbnn_fill_normal(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int64_t ld,
                      uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
                      float scale);
+/* The same normals in the form the bf16 forward draws them: the same Philox words, Box-Muller on them by the hardware's
+ * log2 / sqrt / sin / cos instead of the contract's bit-exact polynomial forms (csrc/common.h, vbnn_normal4_hw): equal to
+ * vbnn_fill_normal's to a few 1e-7 absolute, a quarter of the instructions. The fp32 path (held sample for sample against the
+ * oracle) draws the exact form; this entry exists so that a host or a test can see exactly what a bf16 forward used. */
+int vbnn_fill_normal_hw(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int64_t ld,
+                        uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
+                        float scale);
 
 /* VBLinear:compute_prior (VBLinear.lua:77-88). One fused sweep over means/lvars:
  *   stats[0] = sum(exp(lvars) + means^2)   (so var_hat = stats[0] / W, :86)

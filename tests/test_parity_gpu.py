@@ -58,6 +58,26 @@ def test_fill_normal_bit_exact(nnmod, oracle, rows, cols):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_hardware_form_of_the_normals_stays_within_2e6_of_the_contract(nnmod, oracle):
+    """What the bf16 forward draws (vbnn_normal4_hw: the contract's Philox words, Box-Muller by v_log / v_sqrt / v_sin / v_cos)
+    against the bit-exact contract on 2^22 normals: max |dz| < 2e-6 absolute (bf16 rounds what is made of them at 4e-3
+    relative), same mean / variance to 1e-6, and the largest |z| -- the u1 -> 0 tail, where log2 is steepest -- included."""
+    from vbnn_amd import _lib as L
+    rows, cols = 2048, 2048
+    a = torch.empty(rows, cols, dtype=torch.float32, device="cuda")
+    b = torch.empty(rows, cols, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(a, SEED, L.STREAM_ZETA, 1, 5, row0=4096)
+    nnmod.fill_normal(b, SEED, L.STREAM_ZETA, 1, 5, row0=4096, hw=True)
+    want = oracle.fill_normal(4, 64, SEED, L.STREAM_ZETA, 1, 5, 4096)
+    assert np.array_equal(host(a[:4, :64]).view(np.uint32), want.view(np.uint32))     # `a` IS the contract
+    d = (a.double() - b.double()).abs()
+    assert float(d.max()) < 2e-6, float(d.max())
+    assert abs(float(a.double().mean() - b.double().mean())) < 1e-6
+    assert abs(float(a.double().var() - b.double().var())) < 1e-6
+    i = int(a.abs().argmax())
+    assert abs(float(a.view(-1)[i] - b.view(-1)[i])) < 2e-6 and float(a.abs().max()) > 4.5
+
+
 # ------------------------------------------------------------------------------------------- prior / KL
 @pytest.mark.parametrize("O,I", [(5, 7), (48, 64), (400, 784)])
 def test_compute_prior_and_kl(nnmod, oracle, O, I):

@@ -8,6 +8,30 @@
 #include "../../include/vbnn_hip.h"
 #include "../../include/vbnn_philox.h"
 
+// ---- the bf16 path's form of the contract's normals (include/vbnn_philox.h): the SAME Philox4x32-10 words for the same
+// (seed, stream, layer, draw, row, quad), Box-Muller on them by the hardware's log2 / sqrt / sin / cos (v_log_f32, v_sqrt_f32,
+// v_sin_f32 / v_cos_f32 take their angle in revolutions: exactly Box-Muller's 2 pi u2) instead of the bit-exact polynomial
+// forms -- ~70 VALU slots per four normals against ~270. The values differ from the contract's by a few 1e-7 absolute
+// (tests: max |dz| over 2^22 normals < 2e-6; three orders below the bf16 rounding of everything a bf16 forward does with
+// them), so the fp32 path -- held sample for sample against the oracle -- keeps the exact form, and the bf16 path, held
+// against rounding-point emulation at bf16 tolerances, takes this one: the draw was 23 us of a 4096 x 4096 forward launch.
+#if defined(__HIPCC__)
+__device__ __forceinline__ vbnn_f32x4 vbnn_normal4_hw(uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, uint32_t row,
+                                                      uint32_t quad) {
+    const vbnn_u32x4 u = vbnn_philox4x32_10(quad, row, draw, (layer << 8) | stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+    vbnn_f32x4 z;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = (float)((u.v[2 * p] >> 8) + 1u) * 5.96046448e-8f;          // (0, 1], as vbnn_box_muller
+        const float t = (float)(u.v[2 * p + 1] >> 8) * 5.96046448e-8f;              // the angle in revolutions, [0, 1)
+        const float rr = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), ln = ln 2 . log2
+        z.v[2 * p] = rr * __builtin_amdgcn_cosf(t);
+        z.v[2 * p + 1] = rr * __builtin_amdgcn_sinf(t);
+    }
+    return z;
+}
+#endif
+
 // A loop the compiler MUST unroll: `#pragma unroll` is silently dropped when the unrolled body exceeds LLVM's
 // pragma-unroll-threshold (16 K instructions), and a rolled loop indexing a register array sends the WHOLE array to
 // scratch (seen: gemm_nt_v2<.., EpiDw>'s generic epilogue, 528 B of scratch and 64 stores on every path).

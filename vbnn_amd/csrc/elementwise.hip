@@ -13,13 +13,15 @@ static inline int grid_for(int64_t work_items, int per_block) {
 }
 
 // ---------------------------------------------------------------------------------- fill_normal
+template <bool HW>
 __global__ __launch_bounds__(256) void k_fill_normal(float* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
                                                      uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0, float scale) {
     const int64_t quads = (cols + 3) >> 2;
     const int64_t total = rows * quads;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int64_t r = t / quads, q = t - r * quads;
-        const vbnn_f32x4 z = vbnn_normal4(seed, stream, layer, draw, (uint32_t)(row0 + r), (uint32_t)q);
+        const vbnn_f32x4 z = HW ? vbnn_normal4_hw(seed, stream, layer, draw, (uint32_t)(row0 + r), (uint32_t)q)
+                                : vbnn_normal4(seed, stream, layer, draw, (uint32_t)(row0 + r), (uint32_t)q);
         float* p = out + r * ld + q * 4;
         const int valid = (int)min((int64_t)4, cols - q * 4);
         const bool vec = ((ld & 3) == 0) && (((uintptr_t)out & 15u) == 0);
@@ -33,7 +35,19 @@ extern "C" int vbnn_fill_normal(vbnn_ctx* ctx, float* out, int64_t rows, int64_t
     VBNN_REQUIRE(ctx && out, "null ctx/out");
     VBNN_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "shape");
     VBNN_REQUIRE(stream < 256 && layer < (1u << 24), "stream/layer id range");
-    hipLaunchKernelGGL(k_fill_normal, dim3(grid_for(rows * ((cols + 3) / 4), 256)), dim3(256), 0, ctx->stream, out, rows,
+    hipLaunchKernelGGL(k_fill_normal<false>, dim3(grid_for(rows * ((cols + 3) / 4), 256)), dim3(256), 0, ctx->stream, out, rows,
+                       cols, ld, seed, stream, layer, draw, row0, scale);
+    return vbnn_check_launch("k_fill_normal");
+    VBNN_API_END
+}
+// the same normals in the bf16 path's hardware-transcendental form (common.h, vbnn_normal4_hw): what a bf16 forward draws
+extern "C" int vbnn_fill_normal_hw(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
+                                   uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0, float scale) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && out, "null ctx/out");
+    VBNN_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "shape");
+    VBNN_REQUIRE(stream < 256 && layer < (1u << 24), "stream/layer id range");
+    hipLaunchKernelGGL(k_fill_normal<true>, dim3(grid_for(rows * ((cols + 3) / 4), 256)), dim3(256), 0, ctx->stream, out, rows,
                        cols, ld, seed, stream, layer, draw, row0, scale);
     return vbnn_check_launch("k_fill_normal");
     VBNN_API_END

@@ -80,11 +80,19 @@ struct EpiFwd {
     __device__ __forceinline__ int n_dim() const { return N; }
     // the two-pass kernel's fold addresses the noise by launch-wide (draw, row0): stacked draws stay with the other kernels
     __host__ __device__ __forceinline__ bool v3_ok() const { return rpd == 0; }
+    // the four normals of a quad: the contract's bit-exact form on the fp32 path, its hardware-transcendental form on the bf16
+    // path (common.h, vbnn_normal4_hw; -DVBNN_BF16_EXACT_NORMALS: the exact form there too, A/B)
+    static __device__ __forceinline__ vbnn_f32x4 normal4(uint64_t seed_, uint32_t layer_, uint32_t draw_, uint32_t row, uint32_t quad) {
+#ifndef VBNN_BF16_EXACT_NORMALS
+        if constexpr (sizeof(T) == 2) return vbnn_normal4_hw(seed_, VBNN_STREAM_ZETA, layer_, draw_, row, quad);
+#endif
+        return vbnn_normal4(seed_, VBNN_STREAM_ZETA, layer_, draw_, row, quad);
+    }
     // the four normals of output units 4 q .. 4 q + 3 of operand row n: (draw, minibatch row) of that row
     __device__ __forceinline__ vbnn_f32x4 zeta4(int n, uint32_t quad) const {
         uint32_t nn = (uint32_t)n, d = draw;
         if (rpd > 0) { const uint32_t k = nn / (uint32_t)rpd; d += k; nn -= k * (uint32_t)rpd; }
-        return vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, d, (uint32_t)(row0 + nn), quad);
+        return normal4(seed, layer, d, (uint32_t)(row0 + nn), quad);
     }
 
     template <bool STORE_T>
@@ -223,7 +231,7 @@ struct EpiFwd {
             const float f = (float)((um + ln.ml + un + ln.nl) & 7) * 0.25f - 0.875f;
             z.v[0] = f; z.v[1] = -f; z.v[2] = 0.5f * f; z.v[3] = -0.5f * f;
         } else {
-            z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+            z = normal4(seed, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
         }
         f32x4 out;
 #pragma unroll
@@ -249,7 +257,7 @@ struct EpiFwd {
             const float f = (float)((um + ln.ml + un + ln.nl) & 7) * 0.25f - 0.875f;
             z.v[0] = f; z.v[1] = -f; z.v[2] = 0.5f * f; z.v[3] = -0.5f * f;
         } else {
-            z = vbnn_normal4(seed, VBNN_STREAM_ZETA, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+            z = normal4(seed, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
         }
         f32x4 out;
         float rv[4];
