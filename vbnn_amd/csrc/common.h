@@ -199,7 +199,12 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, floa
 // faulted on a stale SGPR base. Plain stores it is.)
 template <class V, class T>
 __device__ __forceinline__ void vbnn_store_out(T* base, unsigned off, V v) {
+#ifdef VBNN_NT_STORES        // A/B (r03): the compiler's own nontemporal store -- 0.808-0.833 against 0.794-0.799 ms per wide step: the consumers of
+                             // these outputs (the next launch's operands and epilogue reads) find less of them in the caches. Off.
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(base + off));
+#else
     *reinterpret_cast<V*>(base + off) = v;
+#endif
 }
 
 // load 4 consecutive elements as floats (p 4-element aligned when `vec` is true); lanes past `valid` read 0
