@@ -207,6 +207,24 @@ __device__ __forceinline__ void vbnn_store_out(T* base, unsigned off, V v) {
 #endif
 }
 
+// The same for the parameter GRADIENTS (accGradParameters' outputs, 160 MB per wide step): nobody reads them inside the step --
+// the update sweep or the exchange does -- so they leave with the nontemporal hint and do not displace what the step's next
+// launches read (operand shadows, activations). Two A/B rounds on two boxes: 0.8046-0.8061 against 0.8075-0.8153 ms and
+// 0.816-0.828 against 0.828-0.831 ms per wide step (the next forward alone 0.1966 -> 0.1895 ms), the training step with the
+// update unchanged to slightly better (1.054-1.059 against 1.051-1.069 ms). (Nontemporal stores for EVERY epilogue output,
+// vbnn_store_out above, cost 15-30 us: those outputs ARE the next launch's operands.) -DVBNN_NT_GRADS=0: plain stores.
+#ifndef VBNN_NT_GRADS
+#define VBNN_NT_GRADS 1
+#endif
+template <class V, class T>
+__device__ __forceinline__ void vbnn_store_grad(T* base, unsigned off, V v) {
+#if VBNN_NT_GRADS
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(base + off));
+#else
+    *reinterpret_cast<V*>(base + off) = v;
+#endif
+}
+
 // load 4 consecutive elements as floats (p 4-element aligned when `vec` is true); lanes past `valid` read 0
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float (&v)[4], int valid, bool vec);

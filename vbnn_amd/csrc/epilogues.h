@@ -608,8 +608,8 @@ struct EpiDw {
             gm[j] = fmaf(k_mu, (float)pre.mu[j], lm);
             gl[j] = fmaf(k_lv, fmaf(var, inv_vh, -1.0f), ll);
         }
-        if (part != 2) vbnn_store_out(grad_mu + ub, ln.o, gm);
-        if (part != 1) vbnn_store_out(grad_lv + ub, ln.o, gl);
+        if (part != 2) vbnn_store_grad(grad_mu + ub, ln.o, gm);
+        if (part != 1) vbnn_store_grad(grad_lv + ub, ln.o, gl);
     }
 
     // ---- fold protocol: the two outputs depend on one accumulator each, so d/dlvars is FINISHED between the passes
@@ -673,6 +673,6 @@ struct EpiDw {
         f32x4 gm;
 #pragma unroll
         for (int j = 0; j < 4; ++j) gm[j] = fmaf(k_mu, (float)pre.mu[j], scale * a[j] * invS);
-        vbnn_store_out(grad_mu + ((int64_t)un * I + um), ln.o, gm);
+        vbnn_store_grad(grad_mu + ((int64_t)un * I + um), ln.o, gm);
     }
 };

@@ -877,10 +877,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
                                  : "v"(rd_a), "n"(4 * PITCH), "n"(8 * PITCH), "n"(12 * PITCH) : "memory");
                     float* const row0p = outp + ((int64_t)(fn0 + 16 * j) * old + fm0 + 64 * G);
-                    vbnn_store_out(row0p, olane, r0);
-                    vbnn_store_out(row0p + 4 * old, olane, r1);
-                    vbnn_store_out(row0p + 8 * old, olane, r2);
-                    vbnn_store_out(row0p + 12 * old, olane, r3);
+                    vbnn_store_grad(row0p, olane, r0);
+                    vbnn_store_grad(row0p + 4 * old, olane, r1);
+                    vbnn_store_grad(row0p + 8 * old, olane, r2);
+                    vbnn_store_grad(row0p + 12 * old, olane, r3);
                 }
             };
             fold_group(std::integral_constant<int, 0>());
