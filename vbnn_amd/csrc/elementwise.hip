@@ -785,6 +785,9 @@ extern "C" int vbnn_prepare(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_p
 // VBLinear:update for one layer as ONE sweep (vbnn_update): Adam on means and lvars from the total gradients, the new
 // parameters' GEMM shadows (+ transposes) and prior sums, and the sums behind the 14 logged series -- 32 B read +
 // 24 B (+ 4..8 B of shadows) written per weight, HBM-bound. Tiling of k_prep_layer.
+#ifndef VBNN_NT_UPDATE
+#define VBNN_NT_UPDATE 1
+#endif
 constexpr int UPD_NSUM = 16;      // per-block partials: 12 sums, then min / max of the new variances and of the new means
 struct UpdLayer {
     float* means; float* lvars; int64_t O, I;
@@ -839,17 +842,31 @@ __global__ __launch_bounds__(256) void k_vb_update(UpdLayer a) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.0;
     acc[12] = acc[14] = 1e300; acc[13] = acc[15] = -1e300;
-    // four consecutive weights of row r (columns c .. c + valid - 1, flat index base): everything the sweep does with them
+    // four consecutive weights of row r (columns c .. c + valid - 1, flat index base): everything the sweep does with them.
+    // (VBNN_NT_UPDATE: parameters, gradients and Adam moments are this sweep's alone -- nontemporal both ways -- so that what it
+    // leaves in the caches is the operand shadows the next forward reads.)
+    auto ld4 = [&](const float* p, float (&o)[4], int valid) {
+#if VBNN_NT_UPDATE
+        if (vec_in && valid == 4) { const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3]; return; }
+#endif
+        load4<float>(p, o, valid, vec_in);
+    };
+    auto st4 = [&](float* p, const float (&o)[4], int valid) {
+#if VBNN_NT_UPDATE
+        if (vec_in && valid == 4) { __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(p)); return; }
+#endif
+        store4<float>(p, o[0], o[1], o[2], o[3], valid, vec_in);
+    };
     auto elem4 = [&](const int64_t base, const int64_t r, const int64_t c, const int valid, float (&m)[4], float (&v)[4]) {
                 float l[4], gm[4], gl[4], mm[4], vm[4], ml[4], vl[4];
-                load4<float>(a.means + base, m, valid, vec_in);
-                load4<float>(a.lvars + base, l, valid, vec_in);
-                load4<float>(a.g_mu + base, gm, valid, vec_in);
-                load4<float>(a.g_lv + base, gl, valid, vec_in);
-                load4<float>(a.m_mu + base, mm, valid, vec_in);
-                load4<float>(a.v_mu + base, vm, valid, vec_in);
-                load4<float>(a.m_lv + base, ml, valid, vec_in);
-                load4<float>(a.v_lv + base, vl, valid, vec_in);
+                ld4(a.means + base, m, valid);
+                ld4(a.lvars + base, l, valid);
+                ld4(a.g_mu + base, gm, valid);
+                ld4(a.g_lv + base, gl, valid);
+                ld4(a.m_mu + base, mm, valid);
+                ld4(a.v_mu + base, vm, valid);
+                ld4(a.m_lv + base, ml, valid);
+                ld4(a.v_lv + base, vl, valid);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (e < valid) {
@@ -879,12 +896,12 @@ __global__ __launch_bounds__(256) void k_vb_update(UpdLayer a) {
                         acc[12] = fmin(acc[12], (double)v[e]); acc[13] = fmax(acc[13], (double)v[e]);
                         acc[14] = fmin(acc[14], (double)m[e]); acc[15] = fmax(acc[15], (double)m[e]);
                     }
-                store4<float>(a.means + base, m[0], m[1], m[2], m[3], valid, vec_in);
-                store4<float>(a.lvars + base, l[0], l[1], l[2], l[3], valid, vec_in);
-                store4<float>(a.m_mu + base, mm[0], mm[1], mm[2], mm[3], valid, vec_in);
-                store4<float>(a.v_mu + base, vm[0], vm[1], vm[2], vm[3], valid, vec_in);
-                store4<float>(a.m_lv + base, ml[0], ml[1], ml[2], ml[3], valid, vec_in);
-                store4<float>(a.v_lv + base, vl[0], vl[1], vl[2], vl[3], valid, vec_in);
+                st4(a.means + base, m, valid);
+                st4(a.lvars + base, l, valid);
+                st4(a.m_mu + base, mm, valid);
+                st4(a.v_mu + base, vm, valid);
+                st4(a.m_lv + base, ml, valid);
+                st4(a.v_lv + base, vl, valid);
                 store4<T>(mu_s + r * a.ld_w + c, m[0], m[1], m[2], m[3], valid, true);
                 store4<T>(var_s + r * a.ld_w + c, v[0], v[1], v[2], v[3], valid, true);
     };
