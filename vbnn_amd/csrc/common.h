@@ -225,6 +225,28 @@ __device__ __forceinline__ void vbnn_store_grad(T* base, unsigned off, V v) {
 #endif
 }
 
+// ... and for outputs / operands whose next (or last) use lies a whole layer away: the noise factor r of a layer that is
+// not the last (stored by its forward, read once by the gradInput epilogue of the layer above, ~half a step later) --
+// -DVBNN_NT_R=0: plain.
+#ifndef VBNN_NT_R
+#define VBNN_NT_R 1
+#endif
+template <class V, class T>
+__device__ __forceinline__ void vbnn_store_stream(T* base, unsigned off, V v, bool stream) {
+#if VBNN_NT_R
+    if (stream) { __builtin_nontemporal_store(v, reinterpret_cast<V*>(base + off)); return; }
+#endif
+    *reinterpret_cast<V*>(base + off) = v;
+}
+template <class V>
+__device__ __forceinline__ V vbnn_load_last_use(const V* p) {
+#if VBNN_NT_R
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // load 4 consecutive elements as floats (p 4-element aligned when `vec` is true); lanes past `valid` read 0
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float (&v)[4], int valid, bool vec);

@@ -225,6 +225,7 @@ struct EpiFwd {
     __host__ __device__ __forceinline__ T* fold_st_ptr() const { return r_t; }
     __host__ __device__ __forceinline__ int64_t fold_st_ld() const { return ld_r; }
     __host__ __device__ __forceinline__ const float* fold_bias_ptr() const { return bias; }   // per-m addend of the fold, or NULL
+    __device__ __forceinline__ bool fold_st_stream() const { return h2 != nullptr; }          // r of a layer with a VB layer above it: read half a step later
     __device__ __forceinline__ f32x4 fold_s(int um, int un, const Lane& ln, f32x4 v, const f32x4& b4, float (&rv)[4]) const {
         vbnn_f32x4 z;
         if (noise == 2) {                         // A/B only (vbnn_debug_set key 7): what the draw itself costs
@@ -392,7 +393,7 @@ struct EpiDx {
     __device__ __forceinline__ Pre load_fast(int um, int un, const Lane& ln) const {
         Pre p;
         p.x = *reinterpret_cast<const typename V4<T>::type*>(x + ((int64_t)un * ld_x + um) + ln.ox);
-        if (r_prev_t) p.r = *reinterpret_cast<const typename V4<T>::type*>(r_prev_t + ((int64_t)un * ld_r_prev + um) + ln.orp);
+        if (r_prev_t) p.r = vbnn_load_last_use(reinterpret_cast<const typename V4<T>::type*>(r_prev_t + ((int64_t)un * ld_r_prev + um) + ln.orp));   // r's only reader
         else p.r = typename V4<T>::type{};
         return p;
     }

@@ -906,6 +906,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             const unsigned rd_a = stg + (flane >> 3) * PITCH + (flane & 7) * 16;   // row (lane >> 3) (+ 8), m chunk lane & 7
             ST* const outp = epi.fold_st_ptr();
             const int64_t old = epi.fold_st_ld();
+            const bool st_stream = epi.fold_st_stream();
             const unsigned olane = (unsigned)((flane >> 3) * (int)old + (flane & 7) * 8);
             auto fold_group = [&](auto g_c) {
                 constexpr int G = decltype(g_c)::value;
@@ -927,8 +928,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(r0), "=&v"(r1) : "v"(rd_a), "n"(8 * PITCH) : "memory");
                     ST* const row0p = outp + ((int64_t)(fn0 + 16 * j) * old + fm0 + 64 * G);
-                    vbnn_store_out(row0p, olane, r0);
-                    vbnn_store_out(row0p + 8 * old, olane, r1);
+                    vbnn_store_stream(row0p, olane, r0, st_stream);
+                    vbnn_store_stream(row0p + 8 * old, olane, r1, st_stream);
                 }
             };
             fold_group(std::integral_constant<int, 0>());
