@@ -169,7 +169,7 @@ def reporting_config_row(torch, L, FusedMLP, fill_normal, with_cpu):
     peak over the step, the CPU baseline on the same host cores -- and the reference's shipped operating point, batch 1 with
     S = 30 draws (config.lua:11,32), the draws stacked as rows. Launch-bound: reported, not the metric."""
     cfg = CONFIGS["small"]
-    out = {"workload": cfg["name"], "dtype": "f32", "launch": "one stream launch per kernel (6 per step)"}
+    out = {"workload": cfg["name"], "dtype": "f32", "launch": "one stream launch per kernel (5 per step: forward x 2, the one-launch head, the layer-2 backward pair, accGradParameters of layer 1)"}
     for key, N, S, stack in (("batch256", cfg["batch"], 1, False), ("batch1_S30_stacked", 1, 30, True)):
         opt = dict(var_init=1e-3, B=1e6, S=S, mode="lrt", dtype="f32", seed=3, input_size=cfg["input_size"], hidden=cfg["hidden"],
                    n_classes=cfg["n_classes"], fuse_kl=True)
@@ -204,6 +204,105 @@ def reporting_config_row(torch, L, FusedMLP, fill_normal, with_cpu):
         del eng
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(dict(cfg), budget_s=4.0)
+    return out
+
+
+def side_config_row(name, torch, dist, L, FusedMLP, fill_normal, steps, warmup, world, rank, use_dist, blocks=3):
+    """Another BASELINE.json configuration measured in the SAME run, by the same protocol (warm-up, `blocks` blocks of `steps`
+    steps between barrier + synchronize, MAX over ranks, the median block): configs[4], the 8 x 4096 VBLinear stack with its
+    regression head, so that the driver's line carries it. Its own engine, its own exchange when N > 1."""
+    cfg = CONFIGS[name]
+    N = cfg["batch"]
+    opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"], hidden=cfg["hidden"],
+               n_classes=cfg["n_classes"], fuse_kl=True, criterion=cfg.get("criterion", "nll"))
+    eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
+    x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
+    fill_normal(x, 3, L.STREAM_DATA, 0, 0, row0=rank * N)
+    t = eng.synthetic_targets(x, rank * N)
+
+    def step():
+        eng.resetGradients(); eng.sample(); eng.run(x, t); eng.finish()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    eng.prepare()
+    for _ in range(warmup):
+        step()
+    wall = []
+    for _ in range(blocks):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        wall.append(el / steps * 1e3)
+    eng.check_exchange()
+    loss, _ = eng.loss_and_accuracy()
+    ms = sorted(wall)[len(wall) // 2]
+    fps = algorithmic_flops_per_sample([cfg["input_size"]] + cfg["hidden"], cfg["n_classes"])
+    peak = PEAK_TFLOPS[cfg["dtype"]]
+    out = {"workload": cfg["name"], "dtype": cfg["dtype"], "n_gpus": world, "global_batch": N * world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(ms, 4), "samples_per_s": round(N * world / (ms * 1e-3), 1), "blocks_ms": [round(b, 4) for b in wall],
+           "flop_per_sample": fps, "step_tflops_per_gpu": round(fps * N / (ms * 1e-3) / 1e12, 2),
+           "step_frac_of_mfma_peak": round(fps * N / (ms * 1e-3) / 1e12 / peak, 4), "loss": round(loss, 5),
+           "gradient_bytes_exchanged": int(eng.grads.numel() * 4) if use_dist else 0}
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def time_other_backend(eng, torch, reps=5):
+    """The buckets of the step through the exchange backend the step did NOT use, back to back on the idle GPUs: vbnn_p2p (the
+    direct reduce-scatter + all-gather over peer-mapped arenas) when the step ran on RCCL, RCCL when it ran on vbnn_p2p -- so
+    that ONE multi-GPU run prices both. Collective: every rank calls it. Never fatal: an error is reported."""
+    from vbnn_amd import comm
+    base = eng.grads.data_ptr()
+    spans = [((b.data_ptr() - base) // 4, b.numel()) for b in eng.buckets()]
+    out = {"buckets": []}
+    ex = None
+    try:
+        if eng.exchange_kind == "p2p":
+            import torch.distributed as dist
+            if dist.get_backend(eng.pg) != "nccl":
+                raise RuntimeError("RCCL wants one device per rank: not timed in a gloo rehearsal (ranks share devices)")
+            ex = comm.RcclExchange(eng.ctx, eng.rank, eng.world, eng.pg)
+            scratch = torch.zeros(eng.grads.numel(), dtype=torch.float32, device=eng.device)
+        else:
+            ex = comm.P2PExchange(eng.ctx, eng.rank, eng.world, eng.grads.numel(), eng.pg)
+            scratch = ex.arena
+        out["backend"] = ex.backend
+        for off, n in spans:
+            buf = scratch[off:off + n]
+            for _ in range(2):
+                ex.allreduce(buf); ex.finish()
+            torch.cuda.synchronize(eng.device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ex.allreduce(buf)
+            ex.finish()
+            torch.cuda.synchronize(eng.device)
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            alg = n * 4 / (ms * 1e-3) / 1e9
+            out["buckets"].append({"bytes": n * 4, "ms": round(ms, 4), "alg_GBps": round(alg, 1),
+                                   "bus_GBps": round(alg * 2 * (eng.world - 1) / max(eng.world, 1), 1)})
+        if hasattr(ex, "gave_up"):
+            out["p2p_barrier_gave_up_epoch"] = int(ex.gave_up())
+    except Exception as e:                      # noqa: BLE001 -- the headline must survive a backend this node cannot run
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    finally:
+        try:
+            if ex is not None:
+                ex.close()
+        except Exception:                       # noqa: BLE001
+            pass
     return out
 
 
@@ -247,7 +346,9 @@ def main():
     ap.add_argument("--host-input", action="store_true", help="the minibatch starts in (pinned) HOST memory every step: the PCIe-inclusive "
                     "rate, reported beside the metric in config.pcie_inclusive -- never `value`")
     ap.add_argument("--prepare-each-step", action="store_true", help="round 1's protocol: the parameter sweep inside every step")
-    ap.add_argument("--with-update", action="store_true", help="also time step + optimiser update (reported beside the metric)")
+    ap.add_argument("--with-update", action="store_true", help="(default since r04: on) also time step + optimiser update, reported beside the metric as train_step")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the train_step entry (step + FusedMLP.update)")
+    ap.add_argument("--no-deep-config", action="store_true", help="skip the deep_config entry (BASELINE configs[4] measured beside the headline)")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
     ap.add_argument("--backward-order", default="auto", choices=["auto", "dx-first", "layerwise"], help="A/B: every updateGradInput first "
                     "then the accGradParameters (auto: when the layers differ in size and there is no exchange), or layer by layer")
@@ -394,8 +495,27 @@ def main():
         for _ in range(3):
             step()
     wall, evms = timed_blocks(step, max(1, args.repeats))
+    # (a p2p barrier that gave up: the sums are not sums and the timing means nothing -- say so and fail, on every rank)
+    try:
+        eng.check_exchange()
+    except RuntimeError as e:
+        if rank == 0:
+            print(json.dumps({"metric": "VBLinear fwd+bwd samples/sec", "value": None, "n_gpus": world, "exchange_failed": str(e)}), flush=True)
+        sys.exit(3)
     loss, correct = eng.loss_and_accuracy()
     ms = sorted(wall)[len(wall) // 2]
+    # the SAME step (same launch order, same two-launch accGradParameters) with the collective calls left out: what the
+    # exchange costs beyond the compute it overlaps with = ms - this
+    noex = None
+    if use_dist:
+        eng.skip_exchange = True
+        for _ in range(3):
+            step()
+        nw, _ = timed_blocks(step, min(3, max(1, args.repeats)))
+        eng.skip_exchange = False
+        step(); barrier()                                 # the arena holds exchanged sums again
+        noex = {"ms_per_step": round(sorted(nw)[len(nw) // 2], 4), "repeats_wall_ms": [round(v, 4) for v in nw]}
+        noex["exposed_exchange_ms"] = round(ms - noex["ms_per_step"], 4)
 
     # HIP events around every launch of the widest layer's three dual GEMMs, on the stream they are launched on, in one
     # more block of --steps steps of the same step (rank 0; kept out of the blocks above: an event record is a marker
@@ -455,13 +575,20 @@ def main():
                 "note": "minibatch copied from pinned host memory at the head of every step (no overlap with the previous step)"}
 
     train = None
-    if args.with_update:
+    if (args.with_update or not args.no_train_step) and args.mode == "lrt" and not use_graph:
         for _ in range(3):
             train_step()
-        tw, te = timed_blocks(train_step, max(1, args.repeats))
-        train = {"ms_per_train_step": round(sorted(tw)[len(tw) // 2], 4), "repeats_wall_ms": [round(v, 4) for v in tw],
-                 "note": "step + FusedMLP.update (fused Adam on means / lvars that also writes the operand shadows and prior "
-                         "statistics, SGD on biases and the final Linear)"}
+        tw, te = timed_blocks(train_step, max(1, args.repeats) if args.with_update else min(3, max(1, args.repeats)))
+        tms = sorted(tw)[len(tw) // 2]
+        fps_t = algorithmic_flops_per_sample([cfg["input_size"]] + cfg["hidden"], cfg["n_classes"]) * args.S
+        train = {"ms_per_train_step": round(tms, 4), "samples_per_s": round(N * world * args.S / (tms * 1e-3), 1),
+                 "repeats_wall_ms": [round(v, 4) for v in tw],
+                 "step_frac_of_mfma_peak": round(fps_t * N / (tms * 1e-3) / 1e12 / PEAK_TFLOPS[cfg["dtype"]], 4),
+                 "kl_gradient": ("exact: added by the update sweep from the fp32 means / lvars (vbnn_update_desc.kl_add, VBLinear.lua:91,96)"
+                                 if eng.kl_in_update else "fused into the accGradParameters epilogue"),
+                 "note": "the whole training step of main.lua:28-40: the metric's step + mlp:update / VBLinear:update (VBLinear.lua:124-166) "
+                         "as ONE sweep per layer (Adam on means / lvars, SGD on biases and the final Linear, the next minibatch's operand "
+                         "shadows and prior statistics); the update's flops are not counted in the fraction (same numerator as the metric)"}
 
     comm = None
     if use_dist:
@@ -469,6 +596,16 @@ def main():
         dist.all_gather_object(ident, (rank, local_rank, device_identity(torch, local_rank), os.getpid()))
         comm = {"backend": eng.comm_backend(), "payload": eng.exchange_dtype, "ranks_seen": [list(i) for i in ident],
                 "distinct_devices": len({i[2] for i in ident}), "allreduce": eng.time_buckets(5)}
+        if noex is not None:
+            comm["step_without_exchange"] = noex
+        if world > 1 and os.environ.get("VBNN_BENCH_OTHER_BACKEND", "1") != "0":
+            comm["other_backend"] = time_other_backend(eng, torch)
+        st = 0
+        if hasattr(eng.exchange(), "gave_up"):
+            st = int(eng.exchange().gave_up())
+        comm["p2p_barrier_gave_up_epoch"] = st if eng.exchange_kind == "p2p" else None
+        comm["scaling_note"] = ("no scaling number exists until this line has been produced on N > 1 DEVICES: " +
+                                (f"{len({i[2] for i in ident})} distinct device(s) took part in this run"))
         ex = eng.exchange()
         if hasattr(ex, "gather_u64"):
             # the same census over the EXCHANGE's own communicator (vbnn_comm_allgather_u64: RCCL's all-gather on the stream
@@ -530,6 +667,7 @@ def main():
                                                        f"{fps * N / (peak * 1e12) * 1e3:.4f} ms"}
         if train:
             out["config"]["train"] = train
+            out["train_step"] = train
         if pcie:
             out["config"]["pcie_inclusive"] = pcie
         if comm:
@@ -538,6 +676,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         if world == 1 and args.config == "wide" and not use_graph and args.cu_budget == 0 and not args.no_reporting_config:
             out["reporting_config"] = reporting_config_row(torch, L, FusedMLP, fill_normal, not args.no_cpu_baseline)
+    # BASELINE.json configs[4] beside the headline, every rank (its step has its own exchange when N > 1)
+    deep = None
+    if args.config == "wide" and not args.no_deep_config and not use_graph and args.cu_budget == 0 and args.mode == "lrt" and args.S == 1:
+        try:
+            del eng
+            torch.cuda.empty_cache()
+            deep = side_config_row("deep", torch, dist, L, FusedMLP, fill_normal, min(args.steps, 20), min(args.warmup, 5), world, rank, use_dist)
+        except Exception as e:                  # noqa: BLE001 -- never at the price of the headline
+            deep = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0:
+        if deep is not None:
+            out["deep_config"] = deep
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
 #endif
 
-#define VBNN_ABI_VERSION 4
+#define VBNN_ABI_VERSION 5
 #define VBNN_KPAD 64            /* packed leading dimensions are multiples of this */
 
 enum { VBNN_OK = 0, VBNN_ERR_INVALID = 1, VBNN_ERR_HIP = 2, VBNN_ERR_NOMEM = 3, VBNN_ERR_UNSUPPORTED = 4 };
@@ -80,6 +80,10 @@ int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K);
  * ld_x >= the row length (ones column included) rounded up to a multiple of 256, zero filled past the data; with a
  * smaller ld_x the call still works, on the slower launch. */
 int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row);
+/* The same two questions for the launches of ONE context: a context made by vbnn_ctx_create_cu_budget tiles for its budget, every
+ * other context (and the two calls above) for the whole device -- the plan is a property of the context, not of the process. */
+int vbnn_ctx_kmajor_supported(vbnn_ctx* ctx, int64_t M, int64_t N, int64_t K);
+int vbnn_ctx_kmajor_supported_dw(vbnn_ctx* ctx, int64_t I, int64_t O, int64_t N, int bias_row);
 
 /* context = (device, stream). hip_stream is a hipStream_t; NULL = the device's default stream
  * (which is also what PyTorch-ROCm's default stream is, so the two stay ordered). */
@@ -88,7 +92,7 @@ int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);
  * (hipExtStreamCreateWithCUMask; the enabled units are spread evenly over the XCDs): the CU budget of the compute stream in
  * a data-parallel run, where RCCL's channels hold some units for the whole step -- a 256-tile GEMM launched on all 256
  * units then finishes the displaced tiles as a straggling second round, while a launch planned for the units it really
- * has (vbnn_kmajor_supported* and the shape heuristics read the budget) tiles for them. n_cus <= 0 or >= the device's
+ * has (vbnn_ctx_kmajor_supported* and the shape heuristics of THIS context's calls read the budget) tiles for them. n_cus <= 0 or >= the device's
  * count: no mask, just an own stream. vbnn_ctx_stream returns the hipStream_t for hosts that enqueue their own work
  * (PyTorch: torch.cuda.ExternalStream). */
 int vbnn_ctx_create_cu_budget(int device, int n_cus, vbnn_ctx** out);
@@ -413,8 +417,16 @@ int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t*
  * (world x VBNN_P2P_HANDLE_BYTES), and from then on vbnn_p2p_allreduce(offset, n) sums arena[offset, offset + n) over the ranks
  * in place: ordered behind the context's stream, run on a high-priority stream of its own, the sum formed in rank order (bitwise
  * the same arena on every rank). vbnn_p2p_finish orders the context's stream behind it. Every rank issues the same sequence.
- * A barrier whose peers never arrive gives up after about two seconds instead of hanging the device: vbnn_p2p_status (blocking)
- * reports it. At most 8 ranks (one node); peers on other devices need peer access (xGMI / PCIe P2P). */
+ * A barrier whose peers never arrive gives up after a bounded WALL time -- 20 s by default, VBNN_P2P_TIMEOUT_S in the environment
+ * at create, or vbnn_p2p_set_timeout -- instead of hanging the device, and raises the exchange's status word: from then on every
+ * data kernel of the exchange is a no-op (the arena keeps this rank's OWN gradients; no partial sum is ever written over them)
+ * and later barriers signal without polling; the rank also marks itself dead in every PEER's flag page, so each peer's next barrier
+ * fails at once and its data kernels stop too -- within one barrier no rank believes a sum that a stopped rank took no part in.
+ * vbnn_p2p_status (blocking on the exchange stream) reports the epoch of the barrier
+ * that failed: the host checks it before it lets an update read the arena (engine.py: FusedMLP.update / check_exchange) and,
+ * having re-synchronised the ranks by its own means, may re-arm the exchange with vbnn_p2p_clear_status. The host runs one
+ * barrier of its own between vbnn_p2p_connect and the first exchange (comm.P2PExchange). At most 8 ranks (one node); peers on
+ * other devices need peer access (xGMI / PCIe P2P). */
 #define VBNN_P2P_HANDLE_BYTES 128
 typedef struct vbnn_p2p vbnn_p2p;
 int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_floats, vbnn_p2p** out, void** arena_out, void* handle_out);
@@ -422,6 +434,8 @@ int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles);
 int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n);
 int vbnn_p2p_finish(vbnn_p2p* p);
 int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up);
+int vbnn_p2p_set_timeout(vbnn_p2p* p, double seconds);
+int vbnn_p2p_clear_status(vbnn_p2p* p);
 int vbnn_p2p_destroy(vbnn_p2p* p);
 
 /* ---- a whole step as ONE graph launch (launch-bound configurations: BASELINE configs[1], the reference's own batch-1

@@ -34,6 +34,9 @@ function FusedMLP.new(opt)
     self.esize = (self.dtype == C.VBNN_BF16) and 2 or 4
     self.seed, self.B, self.S = opt.seed or 3, opt.B, opt.S or 1
     self.world, self.rank = opt.world or 1, opt.rank or 0
+    -- opt.kl_in_update (default: true for bf16, as engine.py): the gradient arena holds the LIKELIHOOD parts and update() adds the
+    -- exact fp32 KL gradient (vbnn_update_desc.kl_add); false = the KL part fused into the accGradParameters epilogue (A/B)
+    if opt.kl_in_update == nil then self.kl_in_update = (self.dtype == C.VBNN_BF16) else self.kl_in_update = opt.kl_in_update end
     self.n_classes = opt.n_classes
     assert(self.n_classes <= 16, 'FusedMLP.lua drives the fused classifier head (mlp.lua:29-32); see engine.py for wider ones')
     local sizes = { opt.input_size }
@@ -215,7 +218,9 @@ function FusedMLP:run(inputs, ld, targets, N)
         d.N, d.I, d.O, d.scale, d.accumulate = N, v.I, v.O, 1, accumulate
         d.seed, d.layer, d.draw, d.lvars = self.seed, v.layer_id, self.draw, f32(v.lvars)
         d.grad_mu, d.grad_lv, d.means, d.stats = v.grad_mu, v.grad_lv, f32(v.means), ffi.cast('double*', v.stats)
-        d.B, d.S, d.kl_scale = self.B, self.S, 1 / self.world
+        -- the KL gradient: exact, from the fp32 parameters in the update sweep (kl_in_update: the default where the epilogue would
+        -- read the bf16 shadows -- (bf16(s2) / var_hat - 1) cancels; VBLinear.lua:96-97 uses the fp32 vars) or fused here (A/B)
+        d.B, d.S, d.kl_scale = self.B, self.S, self.kl_in_update and 0 or 1 / self.world
         d.gradBias = v.bias_from_dw and v.gradBias or nil
         d.x, d.x2, d.g, d.gv, d.ld_x, d.ld_g = v.x_in, v.x2_s and v.x2_s.p or nil, v.g_s.p, v.gv_s.p, v.ld_in, v.g_s.ld
         if self.dtype == C.VBNN_BF16 then d.mu_s, d.var_s, d.ld_w = v.mu_s.p, v.var_s.p, v.mu_s.ld end   -- KL terms from the shadows
@@ -321,6 +326,7 @@ function FusedMLP:update(opt, log14)
         end
         e.bias, e.grad_bias, e.lr_bias, e.B = f32(v.bias), v.gradBias, lr, self.B
         e.log14 = log14 and (ffi.cast('double*', log14) + 14 * (k - 1)) or nil
+        e.kl_add = self.kl_in_update and 1 or 0
     end
     local w3 = ffi.new('vbnn_pack_desc[1]')
     w3[0].src, w3[0].rows, w3[0].cols, w3[0].ld_src = f32(self.weight3), self.n_classes, H, H

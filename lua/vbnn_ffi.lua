@@ -17,6 +17,8 @@ const char* vbnn_last_error(void);
 int vbnn_debug_set(int key, int value);
 int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K);
 int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bias_row);
+int vbnn_ctx_kmajor_supported(vbnn_ctx* ctx, int64_t M, int64_t N, int64_t K);
+int vbnn_ctx_kmajor_supported_dw(vbnn_ctx* ctx, int64_t I, int64_t O, int64_t N, int bias_row);
 int vbnn_ctx_create(int device, void* hip_stream, vbnn_ctx** out);
 int vbnn_ctx_create_cu_budget(int device, int n_cus, vbnn_ctx** out);
 int vbnn_ctx_stream(vbnn_ctx* ctx, void** hip_stream_out, int* n_cus_out);
@@ -157,6 +159,8 @@ int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles);
 int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n);
 int vbnn_p2p_finish(vbnn_p2p* p);
 int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up);
+int vbnn_p2p_set_timeout(vbnn_p2p* p, double seconds);
+int vbnn_p2p_clear_status(vbnn_p2p* p);
 int vbnn_p2p_destroy(vbnn_p2p* p);
 int vbnn_sample(vbnn_ctx* ctx, uint32_t* draw_dev, uint32_t by);
 typedef struct vbnn_graph vbnn_graph;

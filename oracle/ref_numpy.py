@@ -123,13 +123,14 @@ class ReferenceCpuMLP:
 
 
 # ---- the fused LRT step with explicit rounding points -------------------------------------------------
-def emulate_lrt_step(layers, w3, b3, x, t, zetas, rnd=lambda a: a, S=1.0, B=1e6, inv_n=None, kl_shadows=False, criterion="nll"):
+def emulate_lrt_step(layers, w3, b3, x, t, zetas, rnd=lambda a: a, S=1.0, B=1e6, inv_n=None, kl_shadows=False, criterion="nll", kl_scale=1.0):
     """One LRT draw of the whole MLP in float64 with the engine's rounding points made explicit:
     `rnd` is applied wherever the HIP path stores a GEMM operand (x, x.x, mu, sigma^2, relu(y), its
     square, g, g.r and the final Linear's operands). rnd = identity gives the exact fp32-free reference
     (cross-checks the C oracle); rnd = bf16_round gives what the bf16 MFMA path computes up to fp32
     accumulation order. layers: list of dicts(means, lvars, bias); zetas: per-layer N x O normals.
     kl_shadows: the fused total gradients read mu and sigma^2 from the ROUNDED operand shadows (vbnn_dw_args.mu_s / var_s).
+    kl_scale: vbnn_dw_args.kl_scale -- 0 for an engine whose arena holds the likelihood parts alone (opt.kl_in_update).
     Returns loss, per-layer dicts(gradWeight, gradSum, gradBias, grad_mu, grad_lv), gw3, gb3."""
     f8 = np.float64
     N = x.shape[0]
@@ -176,8 +177,8 @@ def emulate_lrt_step(layers, w3, b3, x, t, zetas, rnd=lambda a: a, S=1.0, B=1e6,
         mu_e = rnd(lay["means"]).astype(f8) if kl_shadows else lay["means"].astype(f8)
         var_e = rnd(var32).astype(f8) if kl_shadows else var32.astype(f8)
         res[k] = dict(gradWeight=gw, gradSum=2 * gs2 * stdv, gradBias=g.sum(axis=0),
-                      grad_mu=gw / S + mu_e / (B * vh),
-                      grad_lv=gs2 * var_e / S + (var_e / vh - 1.0) / (2 * B))
+                      grad_mu=gw / S + kl_scale * mu_e / (B * vh),
+                      grad_lv=gs2 * var_e / S + kl_scale * (var_e / vh - 1.0) / (2 * B))
         if k > 0:
             mu, var = rnd(lay["means"]).astype(f8), rnd(var32).astype(f8)
             gx = g @ mu + 2 * xs[k] * (gv @ var)

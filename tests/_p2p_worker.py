@@ -14,7 +14,62 @@ from vbnn_amd.comm import P2PExchange            # noqa: E402
 from vbnn_amd.nn import Context                  # noqa: E402
 
 
+def delayed_rank():
+    """A rank that arrives late: with the barrier's bound set to 0.5 s, rank 1 issues its all-reduce 3 s after rank 0.
+    Rank 0's first barrier gives up: its data kernels become no-ops (its arena is bitwise what it was), check() raises
+    BEFORE anything consumes the arena, and rank 1 -- whose barriers all find rank 0's epochs already signalled -- learns of
+    the failure from the dead word rank 0 left in its flag page: its arena is untouched as well. After a host barrier and
+    clear_status on both ranks the same exchange sums again."""
+    import time
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == 2
+    torch.cuda.set_device(0)
+    ctx = Context.get()
+    n = 1_000_003
+    ex = P2PExchange(ctx, rank, world, n)
+    ex.set_timeout(0.5)
+    g = torch.Generator(device="cuda").manual_seed(77 + rank)
+    ex.arena.copy_(torch.randn(n, generator=g, device="cuda"))
+    torch.cuda.synchronize()
+    mine = ex.arena.cpu()
+    dist.barrier()
+    if rank == 1:
+        time.sleep(3.0)
+    ex.allreduce(ex.arena[:n])
+    ex.finish()
+    raised = False
+    try:
+        ex.check()
+    except RuntimeError as e:
+        raised = "gave up" in str(e)
+    untouched = torch.equal((ex.arena * 1.0).cpu().view(torch.int32), mine.view(torch.int32))
+    print(f"rank {rank}: check raised {raised}, arena untouched {untouched} (epoch {ex.gave_up()})", flush=True)
+    ok = raised and untouched
+    # re-arm: every exchange stream has drained (gave_up synchronised), a host barrier, clear on every rank, a host barrier
+    dist.barrier()
+    ex.clear_status()
+    ex.set_timeout(20.0)
+    dist.barrier()
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    ex.allreduce(ex.arena[:n])
+    ex.finish()
+    ex.check()
+    got = (ex.arena * 1.0).cpu()
+    same = torch.equal(got.view(torch.int32), (everyone[0] + everyone[1]).view(torch.int32))
+    print(f"rank {rank}: after clear_status the sum is bitwise {'equal' if same else 'DIFFERENT'}", flush=True)
+    flag = torch.tensor([1 if (ok and same) else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    ex.close()
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) == 1 else 1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "delayed":
+        return delayed_rank()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)

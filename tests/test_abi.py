@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes table covers exactly the header
     assert sorted(L.exported_symbols()) == names
     L.lib()
-    assert L.lib().vbnn_abi_version() == 4
+    assert L.lib().vbnn_abi_version() == 5
 
 
 def test_no_gpu_is_an_error_not_a_fallback():

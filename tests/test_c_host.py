@@ -12,6 +12,8 @@ import sys
 import numpy as np
 import pytest
 
+from tests import _children
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tools", "c_host.c")
 
@@ -22,7 +24,7 @@ def build(tmp_path):
     libdir = os.path.dirname(L.LIB_PATH)
     cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
            "-L", libdir, "-lvbnn_hip", "-lm", f"-Wl,-rpath,{libdir}"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    res = _children.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-3000:]
     return exe
 
@@ -35,7 +37,7 @@ def test_c_host_builds_against_the_header_alone_and_needs_the_gpu(tmp_path):
     torch = pytest.importorskip("torch")
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: the GPU test runs it")
-    res = subprocess.run([exe, "--out", str(tmp_path / "a.bin")], capture_output=True, text=True, timeout=120)
+    res = _children.run([exe, "--out", str(tmp_path / "a.bin")], capture_output=True, text=True, timeout=120)
     assert res.returncode == 2 and "vbnn_ctx_create" in res.stderr, (res.returncode, res.stderr[-500:])   # loud, no fallback
 
 
@@ -121,7 +123,7 @@ def test_c_host_gradient_arena_is_bitwise_the_python_engines(tmp_path, dtype, I0
     cmd += ["--comm"] if comm else []
     cmd += ["--graph"] if graph else []
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VBNN_RCCL_PATH="/opt/rocm/lib/librccl.so.1")
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = _children.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
     print(res.stdout.strip())
     assert not graph or "replays of one captured graph" in res.stdout

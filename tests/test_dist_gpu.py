@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+from tests import _children
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -37,7 +39,7 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, dtype, hid
         env["VBNN_EXCHANGE"] = os.environ["VBNN_EXCHANGE_FOR_WORKER"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), out, dtype, hidden, str(I0), str(N), xdt, str(S)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    res = _children.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     if os.environ.get("VBNN_EXCHANGE_FOR_WORKER") == "p2p":
         assert res.stdout.count("exchange: vbnn_p2p/ipc") == 2, res.stdout[-1500:]
@@ -81,7 +83,7 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "3", "--warmup", "1",
            "--repeats", "2", "--no-cpu-baseline"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    res = _children.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -91,8 +93,38 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
     assert sorted(r[0] for r in seen) == [0, 1] and len({r[3] for r in seen}) == 2          # two ranks, two processes
     assert len(out["comm"]["allreduce"]) == 2 and all(a["ms"] > 0 for a in out["comm"]["allreduce"])
     assert len(out["config"]["repeats_wall_ms"]) == 2
+    # the ONE line a multi-GPU run has to answer everything in: the step without its collective calls and
+    # the exposed exchange time, every bucket through the OTHER backend as well (here: the step on torch.distributed / gloo,
+    # vbnn_p2p timed beside it over IPC-mapped arenas), no p2p barrier given up, the overlapped GEMMs' own times, and the
+    # training step
+    noex = out["comm"]["step_without_exchange"]
+    assert noex["ms_per_step"] > 0 and abs(noex["exposed_exchange_ms"] - (out["ms_per_step"] - noex["ms_per_step"])) < 1e-3
+    other = out["comm"]["other_backend"]
+    assert other.get("backend") == "vbnn_p2p/ipc" and "error" not in other, other
+    assert len(other["buckets"]) == 2 and all(b["ms"] > 0 and b["bus_GBps"] > 0 for b in other["buckets"])
+    assert other["p2p_barrier_gave_up_epoch"] == 0
+    assert "distinct device(s)" in out["comm"]["scaling_note"] and out["comm"]["distinct_devices"] == 1
+    assert out["roofline"]["timed_region_kernels_ms"]
+    assert out["train_step"]["ms_per_train_step"] > out["ms_per_step"] * 0.5
+
+
+def test_bench_rehearsal_with_the_p2p_exchange_reports_its_status():
+    """The same line with VBNN_EXCHANGE=p2p: the step's buckets go through vbnn_p2p_allreduce, the line carries the exchange's
+    status word (0: no barrier gave up) -- a non-zero status would have been rc 3 and no value."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VBNN_DIST_BACKEND="gloo", VBNN_EXCHANGE="p2p")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "3", "--warmup", "1",
+           "--repeats", "2", "--no-cpu-baseline"]
+    res = _children.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert out["comm"]["backend"] == "vbnn_p2p/ipc" and out["comm"]["p2p_barrier_gave_up_epoch"] == 0
+    assert "error" in out["comm"]["other_backend"]                  # RCCL is not timed with ranks sharing a device, and says so
+    assert out["comm"]["step_without_exchange"]["ms_per_step"] > 0
     # a rank count the launcher did not provide is an error, not a silent single-rank run
-    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small"],
+    bad = _children.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
 
@@ -106,10 +138,24 @@ def test_p2p_exchange_sums_peer_mapped_arenas_bitwise(world):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_p2p_worker.py")]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    res = _children.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     print("\n".join(l for l in res.stdout.splitlines() if "rank" in l))
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count("bitwise equal") == 3 * world
+
+
+def test_p2p_exchange_with_a_late_rank_fails_loudly_and_leaves_the_arenas_alone():
+    """A rank later than the barrier's bound (set to 0.5 s here; 20 s by default): the early rank's barrier gives up, BOTH ranks'
+    data kernels become no-ops (the failure reaches the late rank through its flag page), check() raises on both before
+    anything reads the arena, and after clear_status on both the exchange sums bitwise again (tests/_p2p_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_p2p_worker.py"), "delayed"]
+    res = _children.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    print("\n".join(l for l in res.stdout.splitlines() if "rank" in l))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert res.stdout.count("check raised True, arena untouched True") == 2, res.stdout[-1500:]
+    assert res.stdout.count("after clear_status the sum is bitwise equal") == 2, res.stdout[-1500:]
 
 
 def test_two_ranks_through_the_p2p_exchange_match_the_single_process_step(tmp_path):

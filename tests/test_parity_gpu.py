@@ -434,7 +434,8 @@ def _check_bf16_step_against_emulation(oracle, hidden, I0, N, fuse_kl, loss_tol=
     layers = [dict(means=om.means, lvars=om.lvars, bias=om.bias) for om in onet.vb]
     zetas = [oracle.fill_normal(N, om.O, SEED, 2, k, 1, 0).astype(np.float64) for k, om in enumerate(onet.vb)]
     wloss, res, gw3, gb3 = emulate_lrt_step(layers, onet.last.weight, onet.last.bias, x, t, zetas, bf16_round,
-                                            S=1.0, B=opt["B"], kl_shadows=eng.kl_from_shadows)
+                                            S=1.0, B=opt["B"], kl_shadows=eng.kl_from_shadows,
+                                            kl_scale=0.0 if eng.kl_in_update else 1.0)
     assert abs(loss - wloss) <= loss_tol * abs(wloss), (loss, wloss)
 
     def close(got, want, what):
@@ -556,8 +557,9 @@ def test_full_size_layer2_backward_launches_against_float64(oracle, nnmod):
     vh = float(np.sum(var32 + means ** 2) / means.size)
     B = opt["B"]
     assert eng.kl_from_shadows                                # the epilogue reads the bf16 shadows (vbnn_dw_args.mu_s / var_s)
-    want_mu = gw + mu / (B * vh)
-    want_lv = gs2 * var + (var / vh - 1.0) / (2 * B)
+    klk = 0.0 if eng.kl_in_update else 1.0                     # (default: the arena holds the likelihood parts, update() adds the KL)
+    want_mu = gw + klk * mu / (B * vh)
+    want_lv = gs2 * var + klk * (var / vh - 1.0) / (2 * B)
     var32 = var
     tol_mu = 4e-6 * (np.abs(g).astype(f8).T @ np.abs(x).astype(f8)) + 1e-12
     tol_lv = 4e-6 * (np.abs(gv).astype(f8).T @ x2) * var32 * 1.001 + 1e-5 * np.abs(want_lv) + 1e-12
@@ -819,6 +821,140 @@ def test_engine_test_path_matches_oracle(oracle, nnmod, mode):
                 werr += e / 3; wacc += a / 3
         assert abs(err - werr) <= 3e-5 * abs(werr) + 1e-6, (quick, err, werr)
         assert abs(acc - wacc) <= 100.0 * 1.01 / N
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_one_engine_alternates_sampled_and_map_passes_at_one_batch_size(oracle, nnmod, dtype):
+    """the kept argument blocks bake in the LRT / MAP operand set, and their cache key did not say which.
+    ONE engine, one batch size: a sampled training run, then clamp_to_map() + a forward-only run -- which must be the plain
+    Linear on the means (no noise: two MAP runs are bitwise equal and equal the oracle's clamped pass) --, then a sampled
+    run again, which must draw THIS draw's noise (the oracle's third draw) and back-propagate through it."""
+    N, I0 = 37, 70
+    x = oracle.fill_normal(N, I0, SEED, 4, 0, 0)
+    t = (np.arange(N) * 7 % 10).astype(np.int32)
+    opt, eng, onet = _engine_pair(oracle, "lrt", dtype, [50, 34], I0, True, S=1)
+    tol = 3e-5 if dtype == "f32" else 3e-2
+    # 1. sampled, with backward
+    eng.resetGradients(); eng.prepare(); eng.sample(); onet.resetGradients(); onet.sample()
+    eng.run(dev(x), dev(t)); w1, _ = onet.run(x, t)
+    l1, _ = eng.loss_and_accuracy()
+    assert abs(l1 - w1) <= tol * abs(w1) + 1e-6, (l1, w1)
+    # 2. MAP, forward only, same N (the reference's quicktest, mlp.lua:88-92)
+    outs = []
+    for _ in range(2):
+        eng.resetGradients(); eng.clamp_to_map()
+        eng.run(dev(x), dev(t), backward=False)
+        lm, _ = eng.loss_and_accuracy()
+        outs.append((lm, host(eng.out).copy()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32)), "a MAP pass drew noise"
+    for om in onet.vb:
+        om.clamp_to_map()
+    wm, _ = onet.run(x, t)
+    assert abs(outs[0][0] - wm) <= tol * abs(wm) + 1e-6, (outs[0][0], wm)
+    assert abs(outs[0][0] - l1) > 1e-6 * abs(l1), "the MAP loss equals the sampled loss: the cached LRT block ran"
+    # 3. sampled again: the second draw's noise, and a backward that uses this run's r
+    eng.resetGradients(); eng.sample(); onet.resetGradients(); onet.sample()
+    eng.run(dev(x), dev(t)); w3, _ = onet.run(x, t)
+    l3, _ = eng.loss_and_accuracy()
+    assert abs(l3 - w3) <= tol * abs(w3) + 1e-6, (l3, w3)
+    assert abs(l3 - l1) > 1e-7 * abs(l1), "the second draw repeated the first draw's noise"
+    if dtype == "f32":
+        mle, mlc = onet.vb[0].compute_mugrads(opt)
+        want = mle + mlc
+        np.testing.assert_allclose(host(eng.vb[0].gradWeight), want, rtol=0, atol=3e-5 * np.abs(want).max() + 1e-10)
+        vle, vlc = onet.vb[0].compute_vargrads(opt)
+        want = vle + vlc
+        np.testing.assert_allclose(host(eng.vb[0].gradSum), want, rtol=0, atol=3e-5 * np.abs(want).max() + 1e-10)
+
+
+def test_engine_on_its_own_stream_orders_itself_behind_the_callers_stream(oracle, nnmod):
+    """with stream= the library launches on the engine's stream while the caller's copies and torch's fills
+    go to torch's current stream. The engine orders itself (FusedMLP._on_stream): constructed OUTSIDE any stream context,
+    fed a minibatch that a slow copy chain on the caller's stream is still producing when run() is issued, it computes
+    bitwise what an engine on the default stream computes."""
+    from vbnn_amd.engine import FusedMLP
+    N, I0 = 256, 784
+    opt = opt_for("lrt", "bf16", input_size=I0, hidden=[512, 256], S=1, fuse_kl=True)
+    x0 = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x0, SEED, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    ref = FusedMLP(opt)
+    ref.resetGradients(); ref.prepare(); ref.sample(); ref.run(x0, t)
+    want_loss, _ = ref.loss_and_accuracy()
+    want = host(ref.grads).copy()
+    s = torch.cuda.Stream()
+    eng = FusedMLP(opt, stream=s)                          # NOT under torch.cuda.stream(s): allocation + init are the engine's job
+    big = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
+    for rep in range(2):
+        xin = torch.zeros_like(x0)
+        for _ in range(8):                                  # ~2 GB of fills on the caller's stream, then the minibatch lands
+            big.add_(1.0)
+        xin.copy_(x0)
+        eng.resetGradients()
+        if rep == 0:
+            eng.prepare()
+        eng.sample(); eng.run(xin, t)                       # issued while the copy chain above is still in flight
+        got_loss, _ = eng.loss_and_accuracy()
+        if rep == 0:
+            assert got_loss == want_loss, (got_loss, want_loss)
+            assert np.array_equal(host(eng.grads).view(np.uint32), want.view(np.uint32))
+    assert np.isfinite(host(eng.grads)).all()
+
+
+def test_update_refuses_an_exchange_that_cannot_vouch_for_its_sums(oracle, nnmod):
+    """FusedMLP.update() asks the exchange BEFORE a parameter is touched (check_exchange): a p2p barrier
+    that gave up makes it raise, with means / lvars / Adam state as they were. (The exchange object here is a stand-in that
+    reports a given-up barrier; the real give-up path is tests/test_dist_gpu.py's delayed-rank case.)"""
+    from vbnn_amd.engine import FusedMLP
+    opt = opt_for("lrt", "f32", input_size=70, hidden=[50, 34], S=1, fuse_kl=True, **OPT_STATES)
+    eng = FusedMLP(opt)
+    x = torch.empty(37, 70, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = (torch.arange(37, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t)
+    before = [host(v.means).copy() for v in eng.vb] + [host(eng.weight3).copy()]
+
+    class GaveUp:
+        backend = "stand-in"
+
+        def finish(self):
+            pass
+
+        def check(self):
+            raise RuntimeError("vbnn_p2p: barrier 7 of rank 0 gave up waiting for a peer rank")
+    eng._exchange = GaveUp()
+    with pytest.raises(RuntimeError, match="gave up"):
+        eng.update(opt)
+    with pytest.raises(RuntimeError, match="gave up"):
+        eng.loss_and_accuracy()
+    after = [host(v.means) for v in eng.vb] + [host(eng.weight3)]
+    for a, b in zip(before, after):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "update() touched parameters before it checked the exchange"
+
+
+def test_cu_budget_is_a_property_of_the_context_not_of_the_process(nnmod):
+    """a budgeted context plans for its budget, a full-device context in the same process for the device --
+    whatever order they were made or destroyed in."""
+    import ctypes as C
+    from vbnn_amd import _lib as L
+    lib = L.lib()
+    full = nnmod.Context.get()
+    n = C.c_int()
+    L.check(lib.vbnn_ctx_stream(full.h, None, C.byref(n)))
+    total = n.value
+    assert total >= 64
+    a = nnmod.Context.with_cu_budget(0, total // 2)
+    b = nnmod.Context.with_cu_budget(0, total // 2)
+    assert a.cu_budget == total // 2
+    L.check(lib.vbnn_ctx_stream(full.h, None, C.byref(n)))
+    assert n.value == total, "a full-device context plans for the budget of another context"
+    # 4096^3 fills 256 CUs with 256 two-pass tiles; on half the CUs the shape heuristic answers differently from the device's
+    full_says = lib.vbnn_ctx_kmajor_supported(full.h, 4096, 4096, 4096)
+    assert full_says == lib.vbnn_kmajor_supported(4096, 4096, 4096) == 1
+    L.check(lib.vbnn_ctx_destroy(a.h))
+    L.check(lib.vbnn_ctx_stream(b.h, None, C.byref(n)))
+    assert n.value == total // 2, "destroying one budgeted context reset the survivor's plan"
+    L.check(lib.vbnn_ctx_destroy(b.h))
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -1223,7 +1359,8 @@ def test_kl_gradient_added_in_the_update_is_the_fp32_form(oracle, nnmod, dtype):
     nnmod.fill_normal(x, SEED, 4, 0, 0)
     t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
     out = {}
-    for name, extra in (("in_update", dict(kl_in_update=True)), ("fp32_epilogue", dict(kl_from_shadows=False)), ("shadows", {})):
+    for name, extra in (("in_update", dict(kl_in_update=True)), ("fp32_epilogue", dict(kl_from_shadows=False)),
+                        ("shadows", dict(kl_in_update=False))):       # (the A/B form: in-update is the bf16 default since r04)
         opt = opt_for("lrt", dtype, input_size=I0, hidden=hidden, S=1, fuse_kl=True, B=B, **OPT_STATES, **extra)   # small B: the KL part matters
         eng = FusedMLP(opt)
         for v in eng.vb:                                    # posterior variances away from the prior's: a KL gradient that is not ~0
@@ -1296,7 +1433,8 @@ def test_update_leaves_what_prepare_would_and_logs_the_14_series(oracle, nnmod):
                 mu0, lv0, gmu, glv, vh = before[k]
                 mu1, lv1 = host(v.means).astype(np.float64), host(v.lvars).astype(np.float64)
                 mlc, vlc = mu0 / (B * vh), (np.exp(lv0) / vh - 1.0) / (2 * B)
-                mle, vle = gmu - mlc, glv - vlc
+                # (the arena holds the totals -- or, with kl_in_update, the bf16 default, the likelihood parts themselves)
+                mle, vle = (gmu, glv) if eng.kl_in_update else (gmu - mlc, glv - vlc)
                 nl, nm = np.linalg.norm(lv1), np.linalg.norm(mu1)
                 var1 = np.exp(lv1)
                 want = [np.linalg.norm(vlc) / nl, np.linalg.norm(vle) / nl, np.linalg.norm(mlc) / nm, np.linalg.norm(mle) / nm,
@@ -1488,7 +1626,7 @@ def test_engine_regression_head_bf16_against_rounding_emulation(oracle, nnmod):
     layers = [dict(means=om.means, lvars=om.lvars, bias=om.bias) for om in onet.vb]
     zetas = [oracle.fill_normal(N, om.O, SEED, 2, k, 1, 0).astype(np.float64) for k, om in enumerate(onet.vb)]
     wloss, res, gw3, gb3 = emulate_lrt_step(layers, onet.last.weight, onet.last.bias, x, host(t), zetas, bf16_round, S=1.0, B=opt["B"],
-                                            kl_shadows=eng.kl_from_shadows, criterion="mse")
+                                            kl_shadows=eng.kl_from_shadows, criterion="mse", kl_scale=0.0 if eng.kl_in_update else 1.0)
     assert abs(loss - wloss) <= 1e-4 * abs(wloss), (loss, wloss)
     for k, v in enumerate(eng.vb):
         for got, want, what in ((v.gradWeight, res[k]["grad_mu"], "d/dmeans"), (v.gradSum, res[k]["grad_lv"], "d/dlvars"), (v.gradBias, res[k]["gradBias"], "gradBias")):

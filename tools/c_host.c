@@ -13,7 +13,7 @@
  * vbnn_amd/engine.py:FusedMLP on the same configuration.
  *
  *   c_host --dtype f32|bf16 --input 784 --hidden 400,400 --classes 10 --batch 256 [--S 1] [--steps 2] [--update]
- *          [--comm] [--graph] [--seed 3] --out arena.bin
+ *          [--comm] [--graph] [--kl-shadows] [--seed 3] --out arena.bin
  *   --graph: the context gets a stream of its own (vbnn_ctx_create_cu_budget), the draw counter lives on the device
  *   (vbnn_fwd_args.draw_dev, vbnn_sample), step 2 is CAPTURED (vbnn_capture_begin / _end) and steps 2.. are replays of it.
  *   arena.bin: int64 n_grads, double loss, int32 correct, int32 flags, then n_grads floats (the arena after the last
@@ -80,6 +80,7 @@ typedef struct {
 
 typedef struct {
     int dtype, esize, n_layers, n_classes, world, rank, dx_first;
+    int kl_in_update;         /* 1 (default for bf16): the arena holds the likelihood parts, vbnn_update adds the exact fp32 KL gradient (kl_add) */
     int direct;               /* fp32: operands as their producers left them (no packing launch, no squares, no transposes) */
     uint64_t seed;
     float B, S;
@@ -108,6 +109,7 @@ static void fm_new(fused_mlp* m, int dtype, const int64_t* sizes, int n_layers, 
     m->dtype = dtype; m->esize = dtype == VBNN_BF16 ? 2 : 4;
     m->n_layers = n_layers; m->n_classes = n_classes; m->seed = seed; m->B = B; m->S = S; m->var_init = var_init;
     m->world = 1; m->rank = 0;
+    m->kl_in_update = dtype == VBNN_BF16;                          /* engine.py: opt.kl_in_update's default (main: --kl-shadows turns it off) */
     memcpy(m->sizes, sizes, (size_t)(n_layers + 1) * sizeof(int64_t));
     /* gradient arena: [d/dlvars | d/dmeans | d/dbias] per VB layer, then the final Linear (vbnn_amd/partition.py) */
     int64_t total = 0;
@@ -258,7 +260,9 @@ static void dw_block(fused_mlp* m, int li, int64_t N, int accumulate, vbnn_dw_ar
     d->N = N; d->I = v->I; d->O = v->O; d->scale = 1.0f; d->accumulate = accumulate;
     d->seed = m->seed; d->layer = v->layer_id; d->draw = m->draw; d->lvars = v->lvars;
     d->grad_mu = v->grad_mu; d->grad_lv = v->grad_lv; d->means = v->means; d->stats = v->stats;
-    d->B = m->B; d->S = m->S; d->kl_scale = 1.0f / (float)m->world;
+    /* the KL gradient: exact, from the fp32 parameters in the update sweep (default where the epilogue would read the bf16 shadows:
+       (bf16(s2) / var_hat - 1) cancels, VBLinear.lua:96-97 uses the fp32 vars) -- or fused here (--kl-shadows, the A/B form) */
+    d->B = m->B; d->S = m->S; d->kl_scale = m->kl_in_update ? 0.0f : 1.0f / (float)m->world;
     d->gradBias = v->bias_from_dw ? v->gradBias : NULL;
     d->x = v->x_in; d->x2 = m->direct ? NULL : v->x2_s.p; d->g = v->g_s.p; d->gv = v->gv_s.p; d->ld_x = v->ld_in; d->ld_g = v->g_s.ld;
     if (m->dtype == VBNN_BF16) { d->mu_s = v->mu_s.p; d->var_s = v->var_s.p; d->ld_w = v->mu_s.ld; }   /* KL terms from the shadows */
@@ -408,6 +412,7 @@ static void fm_update(fused_mlp* m, float lr, float lr_mu, float lr_lv) {
         e->lv.lr = lr_lv; e->lv.beta1 = 0.9f; e->lv.beta2 = 0.999f; e->lv.eps = 1e-8f; e->lv.lambda = 1.0f; e->lv.t = v->t;
         e->bias = v->bias; e->grad_bias = v->gradBias; e->lr_bias = lr; e->B = m->B;
         e->log14 = NULL;
+        e->kl_add = m->kl_in_update ? 1.0f : 0.0f;
     }
     vbnn_pack_desc w3;
     memset(&w3, 0, sizeof w3);
@@ -469,6 +474,7 @@ int main(int argc, char** argv) {
     }
     fused_mlp net;
     fm_new(&net, dtype, sizes, n_layers, n_classes, seed, 1e-3, 1e6f, (float)S, with_comm);
+    if (arg_flag(argc, argv, "--kl-shadows")) net.kl_in_update = 0;    /* A/B: the KL gradient fused into the accGradParameters epilogue, from the bf16 shadows */
     if (with_graph) net.draw_dev = (uint32_t*)dev_alloc(4);
 
     /* the synthetic minibatch of the parity tests: x ~ N(0,1) from the Philox contract (stream DATA), targets by row */

@@ -89,6 +89,8 @@ _SIGS = {
     "vbnn_debug_set": ([_i, _i], _i),
     "vbnn_kmajor_supported": ([_i64, _i64, _i64], _i),
     "vbnn_kmajor_supported_dw": ([_i64, _i64, _i64, _i], _i),
+    "vbnn_ctx_kmajor_supported": ([_vp, _i64, _i64, _i64], _i),
+    "vbnn_ctx_kmajor_supported_dw": ([_vp, _i64, _i64, _i64, _i], _i),
     "vbnn_ctx_create": ([_i, _vp, C.POINTER(_vp)], _i),
     "vbnn_ctx_create_cu_budget": ([_i, _i, C.POINTER(_vp)], _i),
     "vbnn_ctx_stream": ([_vp, C.POINTER(_vp), C.POINTER(_i)], _i),
@@ -133,6 +135,8 @@ _SIGS = {
     "vbnn_p2p_allreduce": ([_vp, C.c_size_t, _i64], _i),
     "vbnn_p2p_finish": ([_vp], _i),
     "vbnn_p2p_status": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_uint)], _i),
+    "vbnn_p2p_set_timeout": ([_vp, C.c_double], _i),
+    "vbnn_p2p_clear_status": ([_vp], _i),
     "vbnn_p2p_destroy": ([_vp], _i),
     "vbnn_sample": ([_vp, _vp, _u32], _i),
     "vbnn_capture_begin": ([_vp], _i),

@@ -104,6 +104,9 @@ class P2PExchange:
             dist.all_gather_object(box, bytes(mine), group=process_group)
             allh = (C.c_ubyte * (128 * world)).from_buffer_copy(b"".join(box))
             L.check(lib.vbnn_p2p_connect(h, allh))
+            # one HOST barrier before the first exchange: every rank has mapped every arena and flag page, and the device-side
+            # barriers' bounded poll only ever has to cover the skew of a running step, not another rank's start-up
+            dist.barrier(group=process_group)
         else:
             L.check(lib.vbnn_p2p_connect(h, None))
         self._keep = _DevArray(self._ptr, arena_floats)
@@ -125,6 +128,22 @@ class P2PExchange:
         g = C.c_uint()
         L.check(L.lib().vbnn_p2p_status(self.h, None, None, C.byref(g)))
         return g.value
+
+    def check(self):
+        """Raise if a barrier of this rank gave up (the exchange's data kernels are no-ops from that point on: the arena
+        holds this rank's own gradients, not the sums). Blocks on the exchange stream: call it where the sums are about to
+        be consumed -- before an update, at the end of a timed block -- not inside the step."""
+        epoch = self.gave_up()
+        if epoch:
+            raise RuntimeError(f"vbnn_p2p: barrier {epoch} of rank {self.rank} gave up waiting for a peer rank -- the gradient "
+                               "arena holds this rank's own gradients, not the sums (vbnn_p2p_clear_status re-arms the exchange "
+                               "once the ranks are in step again)")
+
+    def set_timeout(self, seconds):
+        L.check(L.lib().vbnn_p2p_set_timeout(self.h, float(seconds)))
+
+    def clear_status(self):
+        L.check(L.lib().vbnn_p2p_clear_status(self.h))
 
     def close(self):
         if self.h:

@@ -12,11 +12,14 @@ void vbnn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// compute units the shape heuristics plan for: the device's, or the CU budget of the process's compute stream
-// (vbnn_ctx_create_cu_budget: one data-parallel rank per process, so the budget is process-wide like the device itself)
-static int g_cu_budget_plan = 0;
+// compute units the shape heuristics plan for: the budget of the CONTEXT whose call is running on this thread
+// (vbnn_cu_scope, entered by every entry point that selects a kernel by shape), otherwise the device's. No process-wide
+// state: a full-device context beside a budgeted one plans for the whole device.
+static thread_local int t_cu_plan = 0;
+vbnn_cu_scope::vbnn_cu_scope(const vbnn_ctx* c) : prev(t_cu_plan) { t_cu_plan = c ? c->cu_budget : 0; }
+vbnn_cu_scope::~vbnn_cu_scope() { t_cu_plan = prev; }
 int vbnn_cu_count() {
-    if (g_cu_budget_plan > 0) return g_cu_budget_plan;
+    if (t_cu_plan > 0) return t_cu_plan;
     static int cus = 0;
     if (cus <= 0) {
         int dev = 0;
@@ -80,8 +83,7 @@ extern "C" int vbnn_ctx_create_cu_budget(int device, int n_cus, vbnn_ctx** out) 
         std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
         for (int i = 0; i < n_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
         e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
-        c->cu_budget = n_cus;
-        g_cu_budget_plan = n_cus;                                 // tile the launches for the units they will really have
+        if (e == hipSuccess) c->cu_budget = n_cus;               // this context's launches are tiled for the units they really have
     } else {
         e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     }
@@ -97,7 +99,8 @@ extern "C" int vbnn_ctx_stream(vbnn_ctx* ctx, void** hip_stream_out, int* n_cus_
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx, "null ctx");
     if (hip_stream_out) *hip_stream_out = (void*)ctx->stream;
-    if (n_cus_out) *n_cus_out = ctx->cu_budget > 0 ? ctx->cu_budget : vbnn_cu_count();
+    vbnn_cu_scope plan(ctx);
+    if (n_cus_out) *n_cus_out = vbnn_cu_count();
     return VBNN_OK;
     VBNN_API_END
 }
@@ -111,7 +114,6 @@ extern "C" int vbnn_ctx_destroy(vbnn_ctx* ctx) {
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->park) (void)hipFree(ctx->park);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->cu_budget > 0 && g_cu_budget_plan == ctx->cu_budget) g_cu_budget_plan = 0;     // the process plans for the whole device again
     delete ctx;
     return VBNN_OK;
     VBNN_API_END

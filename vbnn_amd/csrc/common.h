@@ -71,9 +71,17 @@ struct vbnn_per_device_flag {
     bool done[VBNN_MAX_DEVICES] = {};
     bool& operator[](int device) { return done[(device >= 0 && device < VBNN_MAX_DEVICES) ? device : 0]; }
 };
-// compute units of the device the shape heuristics plan for (all GPUs of a node are one model): read once from the
-// current device instead of assuming MI355X's 256
+// compute units the shape heuristics plan for: the CU budget of the context whose API call is running on this thread
+// (vbnn_cu_scope, a thread-local: entered by the entry points that pick a kernel by shape), else the device's (all GPUs of a
+// node are one model; read once from the current device instead of assuming MI355X's 256)
 int vbnn_cu_count();
+struct vbnn_cu_scope {
+    int prev;
+    explicit vbnn_cu_scope(const vbnn_ctx* c);
+    ~vbnn_cu_scope();
+    vbnn_cu_scope(const vbnn_cu_scope&) = delete;
+    vbnn_cu_scope& operator=(const vbnn_cu_scope&) = delete;
+};
 
 #define VBNN_CHECK_HIP(expr)                                                             \
     do {                                                                                 \

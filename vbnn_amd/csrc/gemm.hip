@@ -39,6 +39,10 @@ static bool kmajor_selected(int64_t M, int64_t N, int64_t K) {
     return g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_shape_ok(M, N, K);
 }
 extern "C" int vbnn_kmajor_supported(int64_t M, int64_t N, int64_t K) { return kmajor_selected(M, N, K) ? 1 : 0; }
+extern "C" int vbnn_ctx_kmajor_supported(vbnn_ctx* ctx, int64_t M, int64_t N, int64_t K) {
+    vbnn_cu_scope plan(ctx);                                 // the answer for THIS context's launches (its CU budget, if any)
+    return kmajor_selected(M, N, K) ? 1 : 0;
+}
 // accGradParameters only: the pair-split launch of gemm_v2 also has a K-major form (outputs too few for gemm_v3)
 static bool kmajor_dw_v2_selected(int64_t M, int64_t N, int64_t K) {
     if (K * (M + 64) >= (1ll << 30) || K * (N + 64) >= (1ll << 30)) return false;
@@ -55,6 +59,10 @@ extern "C" int vbnn_kmajor_supported_dw(int64_t I, int64_t O, int64_t N, int bia
     if (!bias_row && kmajor_selected(I, O, N)) return 1;
     if (I % 4 == 0 && kmajor_dw_v3_split_selected(I + (bias_row ? 1 : 0), O, N)) return 2;
     return kmajor_dw_v2_selected(I + (bias_row ? 1 : 0), O, N) ? 1 : 0;
+}
+extern "C" int vbnn_ctx_kmajor_supported_dw(vbnn_ctx* ctx, int64_t I, int64_t O, int64_t N, int bias_row) {
+    vbnn_cu_scope plan(ctx);
+    return vbnn_kmajor_supported_dw(I, O, N, bias_row);
 }
 
 // the K-major launch (A and / or B stored [K][rows]); false = this shape / configuration does not take it
@@ -247,6 +255,7 @@ static int acc_grad_t(vbnn_ctx* ctx, const vbnn_dw_args* a) {
 
 extern "C" int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a) {
     VBNN_API_BEGIN
+    vbnn_cu_scope plan(ctx);                                 // shape heuristics: this context's compute units
     VBNN_REQUIRE(ctx && a, "null ctx/args");
     VBNN_REQUIRE(a->w && a->x, "w and x are required");
     VBNN_REQUIRE(!a->x2 || a->w2, "x2 needs w2 (LRT pair)");
@@ -286,6 +295,7 @@ static int check_dx_args(vbnn_ctx* ctx, const vbnn_dx_args* a) {
 
 extern "C" int vbnn_grad_input(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* a) {
     VBNN_API_BEGIN
+    vbnn_cu_scope plan(ctx);                                 // shape heuristics: this context's compute units
     const int chk = check_dx_args(ctx, a);
     if (chk != VBNN_OK) return chk;
     if (dtype == VBNN_F32) return grad_input_t<float>(ctx, a);
@@ -314,6 +324,7 @@ static int check_dw_args(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a) {
 
 extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_args* a) {
     VBNN_API_BEGIN
+    vbnn_cu_scope plan(ctx);                                 // shape heuristics: this context's compute units
     const int chk = check_dw_args(ctx, dtype, a);
     if (chk != VBNN_OK) return chk;
     if (dtype == VBNN_F32) return acc_grad_t<float>(ctx, a);
@@ -327,6 +338,7 @@ extern "C" int vbnn_acc_grad_parameters(vbnn_ctx* ctx, int dtype, const vbnn_dw_
 // the launch-bound geometry, otherwise exactly the two calls in the order given
 extern "C" int vbnn_backward_pair(vbnn_ctx* ctx, int dtype, const vbnn_dx_args* dx, const vbnn_dw_args* dw) {
     VBNN_API_BEGIN
+    vbnn_cu_scope plan(ctx);                                 // shape heuristics: this context's compute units
     int chk = check_dx_args(ctx, dx);
     if (chk != VBNN_OK) return chk;
     chk = check_dw_args(ctx, dtype, dw);

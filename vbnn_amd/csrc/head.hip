@@ -843,6 +843,7 @@ extern "C" int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64
                                   int64_t ld_gpT) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(ctx && h && w3 && g_logits, "null argument");
+    vbnn_cu_scope plan(ctx);
     VBNN_REQUIRE(N > 0 && H > 0 && C > 0 && C <= HEAD_CMAX, "shape (C <= 16)");
     VBNN_REQUIRE(ld_h % VBNN_KPAD == 0 && ld_h >= H && ld_w >= H, "h and w3 must be packed operands");
     VBNN_REQUIRE(!gv_prev || (g_prev && r_prev), "gv_prev needs g_prev and r_prev");

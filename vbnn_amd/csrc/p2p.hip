@@ -30,26 +30,58 @@
 #include "common.h"
 
 constexpr int P2P_MAX_WORLD = 8;
-constexpr unsigned P2P_SPIN_LIMIT = 1u << 21;              // x s_sleep(32) = 2048 cycles each: about two seconds
+// A barrier's poll is bounded in WALL time (s_memrealtime: the 100 MHz constant counter), default 20 s, VBNN_P2P_TIMEOUT_S in the
+// environment or vbnn_p2p_set_timeout: long enough for ordinary skew between ranks (a first-launch code-object load, a
+// rank-0-only evaluation, a stalled data loader), short enough that a dead peer does not hold the device for minutes.
+constexpr double P2P_TICKS_PER_S = 1.0e8;
+constexpr double P2P_DEFAULT_TIMEOUT_S = 20.0;
 
 struct P2PFlags { unsigned* page[P2P_MAX_WORLD]; };
 struct P2PArenas { float* a[P2P_MAX_WORLD]; };
 
-__global__ __launch_bounds__(64) void k_p2p_barrier(P2PFlags peers, unsigned* mine, int rank, int world, unsigned epoch, unsigned* status) {
+// flag page of a rank (uncached, 4 KiB): words [0, 8) = the epoch each peer has signalled, word 8 = this rank's status (the
+// epoch of a barrier that failed, else 0), words [16, 24) = "peer q's exchange is dead" (written by q when ITS barrier fails)
+constexpr int P2P_STATUS_WORD = P2P_MAX_WORLD, P2P_DEAD_WORD0 = 16;
+
+__global__ __launch_bounds__(64) void k_p2p_barrier(P2PFlags peers, unsigned* mine, int rank, int world, unsigned epoch, unsigned* status,
+                                                    unsigned long long timeout_ticks) {
     const int p = threadIdx.x;
     if (p >= world) return;
+    // (a rank whose exchange is dead still SIGNALS, so that no peer waits out its timeout on it; it does not poll again --
+    // the exchange stays dead until the host clears the status on every rank)
     __hip_atomic_store(peers.page[p] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     bool ok = false;
-    for (unsigned spin = 0; spin < P2P_SPIN_LIMIT; ++spin) {
+    for (;;) {
         const unsigned seen = __hip_atomic_load(mine + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // a peer whose own barrier failed says so in THIS rank's page: its data kernels have stopped, so what it holds are not
+        // sums -- this rank's exchange is dead too, from this barrier on (the failure reaches every rank within one barrier)
+        const unsigned dead = __hip_atomic_load(mine + P2P_DEAD_WORD0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (dead != 0u) break;
         if ((int)(seen - epoch) >= 0) { ok = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) break;       // gave up: never hang the device
         __builtin_amdgcn_s_sleep(32);
     }
-    if (!ok) __hip_atomic_store(status, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // gave up: never hang the device
+    const bool any_fail = __ballot(!ok) != 0ull;              // (over the `world` active lanes)
+    if (any_fail) {
+        if (p == 0) __hip_atomic_store(status, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p != rank) __hip_atomic_store(peers.page[p] + P2P_DEAD_WORD0 + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The data kernels do NOTHING once a barrier of this rank has given up: a reduce-scatter on buckets a peer has not
+// finished would put wrong sums into the gradient arena IN PLACE, where the next update reads them. With the status raised the
+// arena keeps this rank's own (unsummed) gradients, every later phase of the exchange is a no-op, and the host finds the
+// status at its next check (P2PExchange.check: before update(), at the end of a bench block, in loss_and_accuracy).
+__device__ __forceinline__ bool p2p_dead(const unsigned* status) {
+    return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
 }
 
 // out[i] = sum over ranks p = 0 .. world - 1 of arena_p[base + i], i in [0, n): into this rank's own arena
-__global__ __launch_bounds__(256) void k_p2p_reduce_scatter(P2PArenas peers, int rank, int world, size_t base, int64_t n, int vec) {
+__global__ __launch_bounds__(256) void k_p2p_reduce_scatter(P2PArenas peers, int rank, int world, size_t base, int64_t n, int vec,
+                                                            const unsigned* status) {
+    if (p2p_dead(status)) return;
     float* out = peers.a[rank] + base;
     const int64_t stride = (int64_t)gridDim.x * 256;
     if (vec) {
@@ -74,9 +106,10 @@ __global__ __launch_bounds__(256) void k_p2p_reduce_scatter(P2PArenas peers, int
 }
 
 // mine[base_q + i] = arena_q[base_q + i] for every peer chunk q != rank (blockIdx.y = q)
-__global__ __launch_bounds__(256) void k_p2p_all_gather(P2PArenas peers, int rank, size_t off, int64_t n, int64_t cs, int vec) {
+__global__ __launch_bounds__(256) void k_p2p_all_gather(P2PArenas peers, int rank, size_t off, int64_t n, int64_t cs, int vec,
+                                                        const unsigned* status) {
     const int q = blockIdx.y;
-    if (q == rank) return;
+    if (q == rank || p2p_dead(status)) return;
     const int64_t c0 = (int64_t)q * cs;
     const int64_t cn = min(cs, n - c0);
     if (cn <= 0) return;
@@ -106,7 +139,24 @@ struct vbnn_p2p {
     hipEvent_t ready, done;
     int64_t pending;
     unsigned epoch;
+    unsigned long long timeout_ticks;
+    bool have_stream, have_ready, have_done;
 };
+
+static void p2p_release(vbnn_p2p* p) {           // everything create / connect may have made, in any state of completion
+    for (int q = 0; q < p->world; ++q) {
+        if (q == p->rank) continue;
+        if (p->arenas.a[q]) (void)hipIpcCloseMemHandle(p->arenas.a[q]);
+        if (p->pages.page[q]) (void)hipIpcCloseMemHandle(p->pages.page[q]);
+        p->arenas.a[q] = nullptr; p->pages.page[q] = nullptr;
+    }
+    if (p->have_ready) (void)hipEventDestroy(p->ready);
+    if (p->have_done) (void)hipEventDestroy(p->done);
+    if (p->have_stream) (void)hipStreamDestroy(p->stream);
+    if (p->arena) (void)hipFree(p->arena);
+    if (p->flags) (void)hipFree(p->flags);
+    delete p;
+}
 
 static_assert(VBNN_P2P_HANDLE_BYTES == 2 * sizeof(hipIpcMemHandle_t), "the handle the host passes round: arena + flag page");
 
@@ -118,6 +168,13 @@ extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_
     VBNN_CHECK_HIP(hipSetDevice(ctx->device));
     vbnn_p2p* p = new vbnn_p2p();
     p->ctx = ctx; p->rank = rank; p->world = world; p->arena_floats = arena_floats; p->pending = 0; p->epoch = 0; p->connected = world == 1;
+    p->arena = nullptr; p->flags = nullptr; p->have_stream = p->have_ready = p->have_done = false;
+    for (int q = 0; q < P2P_MAX_WORLD; ++q) { p->arenas.a[q] = nullptr; p->pages.page[q] = nullptr; }
+    {
+        double secs = P2P_DEFAULT_TIMEOUT_S;
+        if (const char* e = getenv("VBNN_P2P_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) secs = v; }
+        p->timeout_ticks = (unsigned long long)(secs * P2P_TICKS_PER_S);
+    }
     hipError_t e = hipMalloc((void**)&p->arena, arena_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemset(p->arena, 0, arena_floats * sizeof(float));
     // the flag page is polled by running kernels of OTHER devices: uncached (fine-grained) memory
@@ -125,13 +182,10 @@ extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_
     if (e == hipSuccess) e = hipMemset(p->flags, 0, 4096);
     if (e != hipSuccess) {
         vbnn_set_error("p2p arena / flag page: %s", hipGetErrorString(e));
-        if (p->arena) (void)hipFree(p->arena);
-        if (p->flags) (void)hipFree(p->flags);
-        delete p;
+        p2p_release(p);
         return VBNN_ERR_NOMEM;
     }
-    p->status = p->flags + P2P_MAX_WORLD;
-    for (int q = 0; q < P2P_MAX_WORLD; ++q) { p->arenas.a[q] = nullptr; p->pages.page[q] = nullptr; }
+    p->status = p->flags + P2P_STATUS_WORD;
     p->arenas.a[rank] = p->arena; p->pages.page[rank] = p->flags;
     hipIpcMemHandle_t h[2];
     memset(h, 0, sizeof h);
@@ -141,13 +195,12 @@ extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_
     }
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, greatest);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+    if (e == hipSuccess) { e = hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, greatest); p->have_stream = e == hipSuccess; }
+    if (e == hipSuccess) { e = hipEventCreateWithFlags(&p->ready, hipEventDisableTiming); p->have_ready = e == hipSuccess; }
+    if (e == hipSuccess) { e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming); p->have_done = e == hipSuccess; }
     if (e != hipSuccess) {
         vbnn_set_error("p2p export / stream: %s", hipGetErrorString(e));
-        (void)hipFree(p->arena); (void)hipFree(p->flags);
-        delete p;
+        p2p_release(p);                                           // (the stream and the events made so far as well)
         return VBNN_ERR_HIP;
     }
     memcpy(handle_out, h, sizeof h);
@@ -165,12 +218,20 @@ extern "C" int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles) {
     const hipIpcMemHandle_t* h = static_cast<const hipIpcMemHandle_t*>(all_handles);
     for (int q = 0; q < p->world; ++q) {
         if (q == p->rank) continue;
-        void* a = nullptr; void* f = nullptr;
-        hipError_t e = hipIpcOpenMemHandle(&a, h[2 * q], hipIpcMemLazyEnablePeerAccess);
-        if (e == hipSuccess) e = hipIpcOpenMemHandle(&f, h[2 * q + 1], hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) { vbnn_set_error("hipIpcOpenMemHandle(rank %d's arena / flags): %s", q, hipGetErrorString(e)); return VBNN_ERR_HIP; }
-        p->arenas.a[q] = static_cast<float*>(a);
-        p->pages.page[q] = static_cast<unsigned*>(f);
+        // every mapping is RECORDED as soon as it is open, so that vbnn_p2p_destroy closes whatever a failed connect left
+        // (a second connect after a failure skips what is already mapped)
+        if (!p->arenas.a[q]) {
+            void* a = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&a, h[2 * q], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { vbnn_set_error("hipIpcOpenMemHandle(rank %d's arena): %s", q, hipGetErrorString(e)); return VBNN_ERR_HIP; }
+            p->arenas.a[q] = static_cast<float*>(a);
+        }
+        if (!p->pages.page[q]) {
+            void* f = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&f, h[2 * q + 1], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { vbnn_set_error("hipIpcOpenMemHandle(rank %d's flag page): %s", q, hipGetErrorString(e)); return VBNN_ERR_HIP; }
+            p->pages.page[q] = static_cast<unsigned*>(f);
+        }
     }
     p->connected = true;
     return VBNN_OK;
@@ -179,7 +240,7 @@ extern "C" int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles) {
 
 static int p2p_barrier(vbnn_p2p* p) {
     p->epoch += 1;
-    hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, p->stream, p->pages, p->flags, p->rank, p->world, p->epoch, p->status);
+    hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, p->stream, p->pages, p->flags, p->rank, p->world, p->epoch, p->status, p->timeout_ticks);
     return vbnn_check_launch("k_p2p_barrier");
 }
 
@@ -200,13 +261,13 @@ extern "C" int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n) 
     if (st != VBNN_OK) return st;
     if (cn > 0) {
         const unsigned nb = (unsigned)(((cn + 3) / 4 + 255) / 256 < 1024 ? ((cn + 3) / 4 + 255) / 256 : 1024);
-        hipLaunchKernelGGL(k_p2p_reduce_scatter, dim3(nb ? nb : 1), dim3(256), 0, p->stream, p->arenas, p->rank, W, offset_floats + (size_t)c0, cn, vec);
+        hipLaunchKernelGGL(k_p2p_reduce_scatter, dim3(nb ? nb : 1), dim3(256), 0, p->stream, p->arenas, p->rank, W, offset_floats + (size_t)c0, cn, vec, p->status);
     }
     st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
     {
         const unsigned nb = (unsigned)(((cs + 3) / 4 + 255) / 256 < 256 ? ((cs + 3) / 4 + 255) / 256 : 256);
-        hipLaunchKernelGGL(k_p2p_all_gather, dim3(nb ? nb : 1, W), dim3(256), 0, p->stream, p->arenas, p->rank, offset_floats, n, cs, vec);
+        hipLaunchKernelGGL(k_p2p_all_gather, dim3(nb ? nb : 1, W), dim3(256), 0, p->stream, p->arenas, p->rank, offset_floats, n, cs, vec, p->status);
     }
     st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
@@ -241,22 +302,35 @@ extern "C" int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gav
     VBNN_API_END
 }
 
+// the bound of a barrier's poll, in seconds (default 20, or VBNN_P2P_TIMEOUT_S at vbnn_p2p_create); takes effect for the barriers
+// enqueued after the call
+extern "C" int vbnn_p2p_set_timeout(vbnn_p2p* p, double seconds) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p && seconds > 0.0 && seconds < 3600.0, "timeout in (0, 3600) seconds");
+    p->timeout_ticks = (unsigned long long)(seconds * P2P_TICKS_PER_S);
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+// after a failure the host has re-synchronised the ranks by its own means (a host barrier AFTER every rank's exchange stream
+// has drained, and BEFORE any rank's next exchange) and refilled the arena: every rank calls this, then the exchange may be used again
+extern "C" int vbnn_p2p_clear_status(vbnn_p2p* p) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p, "null p2p");
+    VBNN_CHECK_HIP(hipStreamSynchronize(p->stream));
+    const unsigned zero[P2P_MAX_WORLD] = {};
+    VBNN_CHECK_HIP(hipMemcpy(p->status, zero, sizeof(unsigned), hipMemcpyHostToDevice));
+    VBNN_CHECK_HIP(hipMemcpy(p->flags + P2P_DEAD_WORD0, zero, sizeof zero, hipMemcpyHostToDevice));     // the peers' "dead" words too
+    return VBNN_OK;
+    VBNN_API_END
+}
+
 extern "C" int vbnn_p2p_destroy(vbnn_p2p* p) {
     VBNN_API_BEGIN
     if (!p) return VBNN_OK;
     (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->stream);
-    for (int q = 0; q < p->world; ++q) {
-        if (q == p->rank) continue;
-        if (p->arenas.a[q]) (void)hipIpcCloseMemHandle(p->arenas.a[q]);
-        if (p->pages.page[q]) (void)hipIpcCloseMemHandle(p->pages.page[q]);
-    }
-    (void)hipEventDestroy(p->ready);
-    (void)hipEventDestroy(p->done);
-    (void)hipStreamDestroy(p->stream);
-    (void)hipFree(p->arena);
-    (void)hipFree(p->flags);
-    delete p;
+    if (p->have_stream) (void)hipStreamSynchronize(p->stream);
+    p2p_release(p);
     return VBNN_OK;
     VBNN_API_END
 }

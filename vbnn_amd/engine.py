@@ -10,7 +10,9 @@ dL/dv hand-off in the epilogue, accGradParameters GEMMs with the gradSum / KL-gr
 Everything here is argument plumbing around include/vbnn_hip.h; torch is device memory, the
 stream and torch.distributed.
 """
+import contextlib
 import ctypes as C
+import functools
 import math
 
 import torch
@@ -22,6 +24,19 @@ from .nn import Context, _DT, _Packed, _p, fill_normal
 
 class _VB:
     pass
+
+
+_NULL_CM = contextlib.nullcontext()
+
+
+def _ordered(fn):
+    """Engine entry points that launch or allocate: the body runs with the engine's stream as torch's current stream, that
+    stream ordered behind whatever the caller queued on ITS current stream before the call (FusedMLP._on_stream)."""
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        with self._on_stream():
+            return fn(self, *args, **kwargs)
+    return wrapped
 
 
 class _View:
@@ -45,7 +60,9 @@ class _StepGraph:
         self.kernel_nodes, self.nodes = k.value, n.value
 
     def launch(self):
-        L.check(L.lib().vbnn_graph_launch(self.h))
+        # the replay reads the captured input buffers: it goes behind the copies the caller queued on its own stream
+        with self.eng._on_stream():
+            L.check(L.lib().vbnn_graph_launch(self.h))
         self.eng.draw += self.draws                      # the host's mirror of the device counter
         self.eng._first = False
 
@@ -70,6 +87,32 @@ class FusedMLP:
             self.ctx = Context.with_cu_budget(self.device.index or 0, cu_budget)
         else:
             self.ctx = Context.get(self.device) if stream is None else Context(self.device.index or 0, stream=stream)
+        with self._on_stream():                # every allocation / fill below is queued on the engine's own stream
+            self._build(opt, world_size, rank, process_group, force_reduce)
+
+    def _on_stream(self):
+        """With a stream of the engine's own (stream= / cu_budget) the library launches there while torch's fills, copies
+        and allocations go to torch's CURRENT stream: make the ordering the engine's job. The engine stream
+        first waits for the caller's current stream (a minibatch copied there is complete before a kernel reads it), then
+        is torch's current stream for the body (the engine's own zero fills / repeats queue in launch order). Results are
+        ordered for the caller by join() or any device synchronisation (loss_and_accuracy does one)."""
+        ts = self.ctx.torch_stream
+        if ts is None:
+            return _NULL_CM
+        cur = torch.cuda.current_stream(self.device)
+        if cur != ts:
+            ts.wait_stream(cur)
+        return torch.cuda.stream(ts)
+
+    def join(self):
+        """The caller's current stream waits for everything this engine has queued (no host block)."""
+        ts = self.ctx.torch_stream
+        if ts is not None:
+            cur = torch.cuda.current_stream(self.device)
+            if cur != ts:
+                cur.wait_stream(ts)
+
+    def _build(self, opt, world_size, rank, process_group, force_reduce):
         self.dtype = opt.get("dtype", "bf16")
         self.code, self.tdt = _DT[self.dtype]
         self.mode = opt.get("mode", "lrt")
@@ -91,7 +134,10 @@ class FusedMLP:
         # opt.kl_in_update: the gradient arena holds the LIKELIHOOD parts only (vbnn_dw_args.kl_scale = 0) and update() adds the
         # KL gradient from the fp32 means / lvars (vbnn_update_desc.kl_add) -- exact, where the epilogue's shadow form carries
         # bf16(sigma^2) / var_hat - 1; in a data-parallel run the exchanged sum is then a pure sum of likelihoods.
-        self.kl_in_update = bool(opt.get("kl_in_update", False))
+        # DEFAULT (r04): on wherever the fused epilogue would otherwise take the KL terms from the bf16 shadows -- the exact form is
+        # what every host gets unless it asks for the A/B form (kl_in_update = False); fp32 epilogues read the fp32 parameters
+        # and are exact either way, so they keep the total gradients in the arena.
+        self.kl_in_update = bool(opt.get("kl_in_update", self.kl_from_shadows and self.fuse_kl and self.mode == "lrt"))
         assert not self.kl_in_update or (self.fuse_kl and self.mode == "lrt"), "kl_in_update: the fused LRT engine"
         # optional second HIP stream (+ its own context, hence its own reduction scratch) for the accGradParameters
         # GEMMs. Measured on MI355X (wide config): 1.32 ms with, 1.29 ms without -- two 512-block GEMMs sharing the
@@ -199,11 +245,12 @@ class FusedMLP:
 
     # mlp.lua:47-55 (He rule for every weight, bias zero) + the bench's non-degenerate means
     # (means ~ N(0, sqrt(2/I)); the shipped mu_init = 0 gives an all-zero net).
+    @_ordered
     def init_parameters(self):
         for v in self.vb:
-            fill_normal(v.means, self.seed, L.STREAM_HEINIT, v.layer_id, 0, scale=math.sqrt(2.0 / v.I))
+            fill_normal(v.means, self.seed, L.STREAM_HEINIT, v.layer_id, 0, scale=math.sqrt(2.0 / v.I), ctx=self.ctx)
             v.bias.zero_()
-        fill_normal(self.weight3, self.seed, L.STREAM_HEINIT, len(self.vb), 0, scale=math.sqrt(2.0 / self.sizes[-1]))
+        fill_normal(self.weight3, self.seed, L.STREAM_HEINIT, len(self.vb), 0, scale=math.sqrt(2.0 / self.sizes[-1]), ctx=self.ctx)
         self.bias3.zero_()
 
     # ---- buffers that depend on the local batch size
@@ -235,14 +282,14 @@ class FusedMLP:
                 continue
             # (the K-major launches take the epilogue's fast protocol, which reads mu / sigma^2 from the operand shadows
             # only: vbnn_dw_args.mu_s / var_s are REQUIRED for them, include/vbnn_hip.h)
-            km = lib.vbnn_kmajor_supported_dw(v.I, v.O, N, 1 if v.bias_from_dw else 0) if (
+            km = lib.vbnn_ctx_kmajor_supported_dw(self.ctx.h, v.I, v.O, N, 1 if v.bias_from_dw else 0) if (
                 km_ok and self.mode == "lrt" and self.fuse_kl and int(self.S) == 1 and self.kl_from_shadows) else 0
             v.dw_km = km > 0
             v.x_pad256 = km == 2         # the split launch of gemm_v3 reads x / x.x in whole 256-column tiles
             # the two-launch form of accGradParameters (early d/dlvars message) needs either the transposed operands or the
             # plain K-major launch of the two-pass kernel; the few-tile K-major launches compute both GEMMs in one grid
-            v.early_ok = (not v.dw_km) or bool(not v.bias_from_dw and lib.vbnn_kmajor_supported(v.I, v.O, N))
-            v.dx_km = bool(km_ok and li > 0 and lib.vbnn_kmajor_supported(v.I, N, v.O))
+            v.early_ok = (not v.dw_km) or bool(not v.bias_from_dw and lib.vbnn_ctx_kmajor_supported(self.ctx.h, v.I, v.O, N))
+            v.dx_km = bool(km_ok and li > 0 and lib.vbnn_ctx_kmajor_supported(self.ctx.h, v.I, N, v.O))
             use_muT = (li > 0) and not v.dx_km
             if use_muT and not getattr(v, "use_muT", True):
                 need_prepare = True                            # the shadows' transposes were being skipped: refresh them
@@ -273,7 +320,7 @@ class FusedMLP:
             # well, and accGradParameters reads x K-major with g K-contiguous. Measured in the step (r02): the GEMM 220 ->
             # 216 us, the head's backward 32 -> 40 us for the extra stores: a net loss, so it stays off.
             v.mixed_g = bool(v.dw_km and v is self.vb[-1] and self.n_classes <= 16 and self.criterion == "nll" and
-                             self.opt.get("mixed_g", False) and lib.vbnn_kmajor_supported(v.I, v.O, N) and not v.bias_from_dw)
+                             self.opt.get("mixed_g", False) and lib.vbnn_ctx_kmajor_supported(self.ctx.h, v.I, v.O, N) and not v.bias_from_dw)
             if v.dw_km:
                 v.xT_s = v.x2T_s = v.gT_s = v.gvT_s = None
                 if v.mixed_g:
@@ -305,6 +352,7 @@ class FusedMLP:
 
     # ---- once per minibatch, after the parameters changed: VBLinear:compute_prior (VBLinear.lua:77-88)
     # fused with the packing of the GEMM shadows.
+    @_ordered
     def prepare(self):
         lib = L.lib()
         if self.mode == "lrt":                                # one call: a sweep per layer + ONE finish kernel
@@ -351,6 +399,7 @@ class FusedMLP:
         return _Bracket()
 
     # ---- VBLinear:clamp_to_map on every VB layer (mlp.lua:88-91): the forward uses the means as weights.
+    @_ordered
     def clamp_to_map(self):
         self._map = True
         if self.mode == "wn":                 # the weight shadows currently hold a sampled draw: repack the means
@@ -381,6 +430,7 @@ class FusedMLP:
         return err / draws, acc / draws
 
     # ---- mlp.lua:69-74
+    @_ordered
     def sample(self, by=1):
         self.draw += by
         self._map = False
@@ -438,7 +488,7 @@ class FusedMLP:
     # raw minibatch's address -- is patched in.
     def _fwd_args(self, li, N, row0):
         direct_x = li == 0 and self._x_in is not None
-        key = ("fwd", li, N, row0, self._rpd, direct_x)
+        key = ("fwd", li, N, row0, self._rpd, direct_x, self._lrt())     # (the block bakes in the LRT / MAP operand set)
         a = self._argcache.get(key)
         if a is None:
             a = self._argcache[key] = self._build_fwd_args(li, N, row0)
@@ -467,7 +517,7 @@ class FusedMLP:
 
     def _dw_args(self, li, N, accumulate):
         direct_x = li == 0 and self._x_in is not None
-        key = ("dw", li, N, accumulate, float(self._draws or self.S), direct_x)
+        key = ("dw", li, N, accumulate, float(self._draws or self.S), direct_x, self._lrt())
         d = self._argcache.get(key)
         if d is None:
             d = self._argcache[key] = self._build_dw_args(li, N, accumulate)
@@ -504,7 +554,7 @@ class FusedMLP:
         return d
 
     def _dx_args(self, li, N):
-        key = ("dx", li, N)
+        key = ("dx", li, N, self._lrt())
         a = self._argcache.get(key)
         if a is None:
             a = self._argcache[key] = self._build_dx_args(li, N)
@@ -523,6 +573,7 @@ class FusedMLP:
                         w=v.mu_s.ptr, w2=v.var_s.ptr if lrt else None, ld_w=v.mu_s.ld)
 
     # ---- mlp.lua:76-84, fused
+    @_ordered
     def run(self, inputs, targets, row0=None, backward=True, last_draw=None):
         """last_draw (data-parallel only): whether this run's gradients are the minibatch's final ones, i.e. whether the
         buckets' all-reduces are issued. Default: the opt.S-th sequential run since resetGradients() (always, inside
@@ -741,8 +792,10 @@ class FusedMLP:
     # all-reduced (80 instead of 160 MB per step of the wide configuration), and finish() widens the sums
     # back into the fp32 arena. A different gradient (every rank's contribution rounded, RCCL sums in bf16): an option for
     # hosts whose step is exchange-bound, never the default, and the bench line says which one ran.
+    skip_exchange = False      # bench.py: the step with its collective calls left out (what the exchange costs beyond the overlap)
+
     def _reduce(self, bucket):
-        if not self.reduce or not self._exchange_now:
+        if not self.reduce or not self._exchange_now or self.skip_exchange:
             return
         if self.exchange_dtype != "bf16":
             self.exchange().allreduce(bucket)
@@ -764,6 +817,7 @@ class FusedMLP:
     def comm_backend(self):
         return self.exchange().backend if self.reduce else "none"
 
+    @_ordered
     def finish(self):
         """Order the compute stream behind the outstanding all-reduces (end of the step)."""
         if self._exchange is not None:
@@ -771,6 +825,13 @@ class FusedMLP:
         for bucket, stage in self._staged:            # (bf16 exchange) the sums, widened back behind the exchange
             L.check(L.lib().vbnn_cast_grads(self.ctx.h, 0, _p(stage), _p(bucket), bucket.numel()))
         self._staged = []
+
+    def check_exchange(self):
+        """Raise if the exchange cannot vouch for the sums in the arena (the p2p exchange: a barrier that gave up -- ADVICE r03).
+        Blocks on the exchange stream; update() and loss_and_accuracy() call it, a loop that does neither (a benchmark, a
+        custom host) calls it before it believes a gradient or a timing."""
+        if self._exchange is not None and hasattr(self._exchange, "check"):
+            self._exchange.check()
 
     def _early(self, v, lrt=True):
         return v.msg_early is not None and lrt and self.fuse_kl and getattr(v, "early_ok", True)
@@ -786,6 +847,7 @@ class FusedMLP:
                 out.append(self.bucket_tail if li == nl - 1 else v.bucket)
         return out
 
+    @_ordered
     def time_buckets(self, reps=5):
         """Each bucket's all-reduce alone on an otherwise idle GPU: milliseconds (host clock around reps exchanges,
         device-synchronised), algorithm GB/s and bus GB/s (x 2 (world - 1) / world). Collective: every rank calls it."""
@@ -828,11 +890,13 @@ class FusedMLP:
     # and prior statistics of the next minibatch (the reference's update calls compute_prior too, :130). Nothing is
     # downloaded. Needs fuse_kl (otherwise use vbnn_amd/mlp.py's module-level update). `log` = True also produces the
     # 14 series of VBLinear.lua:149-164 per layer (self.update_log, a device tensor [layers][14]).
+    @_ordered
     def update(self, opt=None, log=False):
         if not self.fuse_kl:
             raise RuntimeError("FusedMLP.update needs opt.fuse_kl = True (total gradients from the dW epilogue)")
         opt = opt or self.opt
         self.finish()
+        self.check_exchange()                  # BEFORE a parameter is touched: an incomplete exchange must not reach them
         lib, h = L.lib(), self.ctx.h
         lr = float(opt["state"]["learningRate"])
         st = self.__dict__.setdefault("_opt_state", {})
@@ -884,14 +948,12 @@ class FusedMLP:
     def loss_and_accuracy(self):
         self.finish()
         torch.cuda.synchronize(self.device)
-        if self._exchange is not None and hasattr(self._exchange, "gave_up"):
-            epoch = self._exchange.gave_up()             # (p2p exchange) a barrier whose peers never arrived: the sums are not sums
-            if epoch:
-                raise RuntimeError(f"vbnn_p2p: barrier {epoch} gave up waiting for a peer rank -- the gradient arena is incomplete")
+        self.check_exchange()
         loss = float(self._acc[0].item())
         correct = int(self._corr[0].item())
         return loss, correct
 
+    @_ordered
     def calc_lc(self, opt=None):                                         # mlp.lua:109-115, fresh statistics
         lc = 0.0
         B = float((opt or self.opt).get("B", self.B))

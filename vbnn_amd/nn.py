@@ -382,10 +382,11 @@ class Linear(Module):
         self._acc_bias(g, scale)
 
 
-def fill_normal(t, seed, stream, layer, draw, row0=0, scale=1.0, hw=False):
+def fill_normal(t, seed, stream, layer, draw, row0=0, scale=1.0, hw=False, ctx=None):
     """t[r][c] <- scale * N(0,1) from the Philox contract (include/vbnn_philox.h); hw=True: the form the bf16 forward
-    draws (the same Philox words, Box-Muller by the hardware's log2 / sqrt / sin / cos: vbnn_fill_normal_hw)."""
-    ctx = Context.get(t.device)
+    draws (the same Philox words, Box-Muller by the hardware's log2 / sqrt / sin / cos: vbnn_fill_normal_hw).
+    ctx: the library context (hence the stream) to launch on; default the device's shared context."""
+    ctx = ctx or Context.get(t.device)
     rows, cols = (t.shape if t.dim() == 2 else (1, t.numel()))
     ld = t.stride(0) if t.dim() == 2 else cols
     fn = L.lib().vbnn_fill_normal_hw if hw else L.lib().vbnn_fill_normal

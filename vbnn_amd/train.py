@@ -45,12 +45,10 @@ def default_opt(**over):
 
 class Main:
     def __init__(self, opt, device=None, net=None):
-        self.opt = opt
-        if net is None and opt.get("mode", "lrt") == "lrt" and opt.get("fuse_kl", True) and "kl_in_update" not in opt:
-            # training: the KL gradient from the fp32 parameters, added by the update sweep (VBLinear.lua:91,96 exactly) -- the
-            # epilogue's bf16-shadow form is off by ~1e-3 of the KL gradient (tests/test_parity_gpu.py), systematic in sign
-            opt = dict(opt, kl_in_update=True)
+        # (the KL gradient: FusedMLP's own default -- exact, from the fp32 parameters in the update sweep wherever the fused
+        # epilogue would read bf16 shadows; the saved opt records the form that actually ran)
         self.net = net or FusedMLP(opt, device=device)
+        self.opt = dict(opt, kl_in_update=bool(getattr(self.net, "kl_in_update", False)))
         self.device = self.net.device
         self.rng = np.random.RandomState(int(opt.get("seed", 3)))                         # torch.manualSeed(3), config.lua:40
         self.indices = None
