@@ -32,7 +32,7 @@
 
 // 1 (default): the fp32 shapes of the 32 x 32 geometry run on the latency kernel (gemm_v0.h); 0: on this file's tile.
 // Test / A-B hook: vbnn_debug_set(VBNN_DEBUG_V0, ..).
-static int g_v0 = 1;
+inline int g_v0 = 1;
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x4 type; };

@@ -67,10 +67,10 @@ __device__ unsigned long long* g_v2_diag = nullptr;
 // DMA schedule: 0 = burst after the barrier; 2 = interleaved with the MFMAs; 4 = 2 with the SIMD partners' DMA slots
 // skewed (measured: no better than 2); -1 = auto: 2 for the 8-wave 256 x 128 tile (+8 % over 0), 0 for the 4-wave
 // 128 x 128 tile (one wave per SIMD has no partner to cover an interleaved DMA issue: 0 is 8 % faster there).
-static int g_v2_sched = -1;
-static int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
-static int g_v2_split = -1;       // split-K of the 256 x 128 tiling: -1 / 0 off, 1 whenever possible (key 3)
-static int g_v2_psplit = -1;      // pair split of the 256 x 128 tiling: -1 by shape, 0 never, 1 whenever the functor allows (key 5)
+inline int g_v2_sched = -1;
+inline int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
+inline int g_v2_split = -1;       // split-K of the 256 x 128 tiling: -1 / 0 off, 1 whenever possible (key 3)
+inline int g_v2_psplit = -1;      // pair split of the 256 x 128 tiling: -1 by shape, 0 never, 1 whenever the functor allows (key 5)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

@@ -43,7 +43,7 @@ constexpr int V3_APART = 128 * 128;                  // bytes: 128 rows x 128 B
 constexpr int V3_BTILE = 256 * 128;
 constexpr int V3_LDS = 4 * V3_APART + 3 * V3_BTILE;  // 163840: all of the CU's LDS
 
-static int g_v3_min_k = 704;        // shortest K the shape selection gives to this kernel (vbnn_debug_set key 4)
+inline int g_v3_min_k = 704;        // shortest K the shape selection gives to this kernel (vbnn_debug_set key 4)
 
 // Diagnostic stamps (tools/split_lab.hip builds with -DV3_STAMP; the library never does): wave 0 of every workgroup
 // stores the 100 MHz real-time counter at a few points of the kernel into g_v3_stamp[blockIdx.x * 8 + k].
@@ -1192,8 +1192,8 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
 }
 
 // ---- the SPLIT launch (K-major operands only: accGradParameters reading x and g as the other GEMMs hold them)
-static int g_v3_split = -1;         // -1 by shape, 0 never, 1 whenever possible (vbnn_debug_set key 8)
-static int g_v3_hm = 1;             // the half-height pair-split form (HM): 0 never, 1 where its grid fills the CUs in one round,
+inline int g_v3_split = -1;         // -1 by shape, 0 never, 1 whenever possible (vbnn_debug_set key 8)
+inline int g_v3_hm = 1;             // the half-height pair-split form (HM): 0 never, 1 where its grid fills the CUs in one round,
                                     // 2 whenever the split launch is taken (vbnn_debug_set key 8, values 2 / 3 / 4)
 // shape part: M rows of output (the ones row included) on N columns, K deep. Wanted when the pair split alone would leave
 // half the CUs idle and both K halves are long enough to amortise the pipeline fill and the hand-off.
