@@ -179,6 +179,14 @@ typedef struct vbnn_fwd_args {
      * constant base. General kernel only: with it set the pipelined bf16 kernels are not selected (the launch-bound
      * configurations are the ones worth capturing; the others take the counter as the launch argument above). */
     const uint32_t* draw_dev;
+    /* optional (NULL: off; ABI 5): the logits of the classifier head that follows the LAST VB layer (mlp.lua:29: the final
+     * nn.Linear, C <= 16 outputs) formed by THIS launch, from its output tiles while they are still in registers: every
+     * 256 x 256 tile adds nothing to memory traffic but 2 x 256 rows x 16 fp32 partial logits, written to the fixed slot
+     * head_slots[2 tile + half][n][16] (n_slots = vbnn_forward_head_slots(...) slots of N x 16 floats; classes >= head_C are
+     * undefined), and the head (vbnn_head_forward_slots / vbnn_head_args.logit_slots) adds the slots in order instead of
+     * re-reading h: bitwise reproducible, no atomics. head_w3: the final weight PACKED (head_C x head_ld_w, dtype), as
+     * vbnn_prepare / vbnn_update leave it. Only where vbnn_forward_head_slots says so (> 0); elsewhere the call fails. */
+    const void* head_w3; int64_t head_ld_w; int64_t head_C; float* head_slots;
 } vbnn_fwd_args;
 
 /* updateOutput. WN/MAP: y = x w^T + b  (inherited nn.Linear:updateOutput, VBLinear.lua:7).
@@ -187,6 +195,10 @@ typedef struct vbnn_fwd_args {
  * ld_x % 4 == 0, columns [I, ld_x) finite; the K walk is masked at the row end, no zero padding is needed -- so an fp32
  * host needs no vbnn_pack_input at all. */
 int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a);
+/* How many slots the forward of an I -> O layer on N rows writes when given vbnn_fwd_args.head_slots for a C-class head, under
+ * this context's kernel selection: 0 = that launch cannot carry the head's logits (use vbnn_head_forward on h), otherwise
+ * allocate n x N x 16 floats. (bf16 layers whose forward runs on the two-pass 256 x 256 kernel: 2 slots per 256 output units.) */
+int vbnn_forward_head_slots(vbnn_ctx* ctx, int dtype, int64_t N, int64_t I, int64_t O, int64_t C);
 
 typedef struct vbnn_dx_args {
     /* A = transposed weights-side I x ld_wT, B = gradient-side N x ld_g */
@@ -491,6 +503,12 @@ int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, con
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
                       float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
                       int32_t* correct_dev, int64_t rows_per_draw);
+/* The same forward from partial logits a vbnn_forward launch left in `slots` (vbnn_fwd_args.head_slots: n_slots x N x 16
+ * floats): logits[n][c] = bias[c] + slots[0][n][c] + slots[1][n][c] + ... in that order, then exactly vbnn_head_forward's
+ * log-softmax, loss, hit count and g_logits. h is not read. */
+int vbnn_head_forward_slots(vbnn_ctx* ctx, const float* slots, int64_t n_slots, const float* bias, const int32_t* target,
+                            int64_t N, int64_t C, float inv_n, float* logits, float* out, float* g_logits, int accumulate,
+                            double* loss_sum_dev, int32_t* correct_dev, int64_t rows_per_draw);
 /* Backward of the same head in one pass over h: gradWeight (C x H) / gradBias (C) of the final Linear (accumulate
  * as in vbnn_acc_grad_parameters; NULL to skip), its gradInput pushed through the ReLU straight into the last VB
  * layer's packed gradient operands (same meaning as the hand-off fields of vbnn_dx_args), and optionally
@@ -526,6 +544,9 @@ typedef struct vbnn_head_args {
     const void* r_prev; int64_t ld_r_prev;
     void* g_prev; void* gv_prev; int64_t ld_gp;
     void* gT_prev; void* gvT_prev; int64_t ld_gpT;
+    /* optional (ABI 5): the forward half from partial logits left by the last VB layer's forward (vbnn_fwd_args.head_slots):
+     * as vbnn_head_forward_slots, then vbnn_head_backward. NULL / 0: the logits are computed from h. */
+    const float* logit_slots; int64_t n_slots;
 } vbnn_head_args;
 int vbnn_head_forward_backward(vbnn_ctx* ctx, int dtype, const vbnn_head_args* a);
 

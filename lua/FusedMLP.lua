@@ -140,6 +140,10 @@ function FusedMLP:_alloc_batch(N)
     end
     self.h_s = packed(N, self.sizes[#self.sizes], self.esize)
     self.logits, self.out, self.g_logits = vb.alloc(N * self.n_classes * 4), vb.alloc(N * self.n_classes * 4), vb.alloc(N * self.n_classes * 4)
+    -- the head's logits from the last VB layer's forward tiles, where that launch can carry them (vbnn_fwd_args.head_slots)
+    local vl = self.vb[#self.vb]
+    self.n_head_slots = self.draw_dev and 0 or C.vbnn_forward_head_slots(vb.ctx, self.dtype, N, vl.I, vl.O, self.n_classes)
+    self.head_slots = self.n_head_slots > 0 and vb.alloc(self.n_head_slots * N * 16 * 4) or nil
     if need_prepare then self:prepare() end
 end
 
@@ -195,6 +199,9 @@ function FusedMLP:run(inputs, ld, targets, N)
         fa.h2 = (nxt and nxt.x2_s) and nxt.x2_s.p or nil
         fa.ld_h = nxt and nxt.x_s.ld or self.h_s.ld
         if nxt and nxt.has_t then fa.hT, fa.h2T, fa.ld_hT = nxt.xT_s.p, nxt.x2T_s.p, nxt.xT_s.ld end
+        if not nxt and self.n_head_slots > 0 then
+            fa.head_w3, fa.head_ld_w, fa.head_C, fa.head_slots = self.w3_s.p, self.w3_s.ld, self.n_classes, ffi.cast('float*', self.head_slots)
+        end
         check(C.vbnn_forward(vb.ctx, self.dtype, fa))
     end
     -- final Linear + LogSoftMax + ClassNLL (mlp.lua:29-32), forward and backward
@@ -209,6 +216,7 @@ function FusedMLP:run(inputs, ld, targets, N)
     ha.relu_mask, ha.r_prev_packed, ha.r_prev, ha.ld_r_prev = 1, 1, vl.r, vl.O
     ha.g_prev, ha.gv_prev, ha.ld_gp = vl.g_s.p, vl.gv_s.p, vl.g_s.ld
     if vl.has_t then ha.gT_prev, ha.gvT_prev, ha.ld_gpT = vl.gT_s.p, vl.gvT_s.p, vl.gT_s.ld end
+    if self.n_head_slots > 0 then ha.logit_slots, ha.n_slots = ffi.cast('const float*', self.head_slots), self.n_head_slots end
     check(C.vbnn_head_forward_backward(vb.ctx, self.dtype, ha))
     -- backward. The argument blocks of layer li (no library call in these two):
     local function dw_block(li)

@@ -60,8 +60,10 @@ typedef struct vbnn_fwd_args {
     void* hT; void* h2T; int64_t ld_hT;
     int64_t rows_per_draw;
     const uint32_t* draw_dev;
+    const void* head_w3; int64_t head_ld_w; int64_t head_C; float* head_slots;
 } vbnn_fwd_args;
 int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a);
+int vbnn_forward_head_slots(vbnn_ctx* ctx, int dtype, int64_t N, int64_t I, int64_t O, int64_t C);
 typedef struct vbnn_dx_args {
     const void* wT;
     const void* w2T;
@@ -178,6 +180,9 @@ int vbnn_mse_forward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* t
                      float inv_nd, float* g, int64_t ld_g, int accumulate, double* loss_sum_dev);
 int vbnn_mse_backward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* target, int64_t ld_t, int64_t N, int64_t D,
                       float inv_nd, float* g, int64_t ld_g);
+int vbnn_head_forward_slots(vbnn_ctx* ctx, const float* slots, int64_t n_slots, const float* bias, const int32_t* target,
+                            int64_t N, int64_t C, float inv_n, float* logits, float* out, float* g_logits, int accumulate,
+                            double* loss_sum_dev, int32_t* correct_dev, int64_t rows_per_draw);
 int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
                       float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
@@ -203,6 +208,7 @@ typedef struct vbnn_head_args {
     const void* r_prev; int64_t ld_r_prev;
     void* g_prev; void* gv_prev; int64_t ld_gp;
     void* gT_prev; void* gvT_prev; int64_t ld_gpT;
+    const float* logit_slots; int64_t n_slots;
 } vbnn_head_args;
 int vbnn_head_forward_backward(vbnn_ctx* ctx, int dtype, const vbnn_head_args* a);
 int vbnn_nll_forward(vbnn_ctx* ctx, const float* out, int64_t ld, const int32_t* target, int64_t N, int64_t C,

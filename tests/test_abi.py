@@ -219,7 +219,7 @@ def test_lua_fused_mlp_structure():
     eng = open(os.path.join(ROOT, "vbnn_amd", "engine.py")).read()
     run = eng[eng.index("    def run(self, inputs, targets"):eng.index("            main, side, ctx2 =")]
     # (the head: the one-call form is what the Lua host issues; engine.py's two-call branch -- test path, opt.head_step = False -- is cut)
-    run = run[:run.index("                L.check(lib.vbnn_head_forward(ctx")] + run[run.index("        # ---------------- backward: VB layers"):]
+    run = run[:run.index("                if self._use_head_slots():\n                    L.check(lib.vbnn_head_forward_slots(")] + run[run.index("        # ---------------- backward: VB layers"):]
     py_order = []
     for m in re.finditer(r"lib\.(vbnn_[a-z0-9_]+)\(|self\.(_reduce)\(", run):
         name = m.group(1) or "vbnn_allreduce_grads"

@@ -823,6 +823,52 @@ def test_engine_test_path_matches_oracle(oracle, nnmod, mode):
         assert abs(acc - wacc) <= 100.0 * 1.01 / N
 
 
+def test_head_logits_from_the_forward_tiles_equal_the_heads_own_pass_over_h(oracle, nnmod):
+    """vbnn_fwd_args.head_slots (r04): the last VB layer's forward forms the final Linear's logits from its output tiles while
+    they are in registers -- [2 x 16 tiles of m][N][16] fp32 partials in fixed slots, added in order by the head. Against (1) a
+    float64 product of the stored h and the packed final weight (per-element fp32 accumulation bound), (2) an engine whose head
+    reads h itself (opt.head_from_h: the same numbers in another summation order), (3) itself, bitwise, on a second run; and the
+    whole step's gradients agree with the head_from_h engine's to fp32 rounding. MAP passes (single GEMM) carry the logits too."""
+    from vbnn_amd.engine import FusedMLP
+    I0, N, hidden = 256, 4096, [1024, 4096]
+    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+    nnmod.fill_normal(x, SEED, 4, 0, 0)
+    t = (torch.arange(N, device="cuda", dtype=torch.int64) * 7 % 10).to(torch.int32)
+    res = {}
+    for name, extra in (("slots", {}), ("from_h", dict(head_from_h=True))):
+        opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True, **extra)
+        eng = FusedMLP(opt)
+        eng.bias3.copy_(torch.linspace(-0.5, 0.5, 10, device="cuda"))
+        runs = []
+        for rep in range(2):
+            eng.draw = 0
+            eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t)
+            loss, hits = eng.loss_and_accuracy()
+            runs.append((loss, hits, host(eng.logits).copy(), host(eng.grads).copy()))
+        assert (eng.n_head_slots > 0) == (name == "slots"), (name, eng.n_head_slots)
+        assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][2].view(np.uint32), runs[1][2].view(np.uint32))
+        assert np.array_equal(runs[0][3].view(np.uint32), runs[1][3].view(np.uint32)), f"{name}: gradients differ between two runs"
+        h = host(eng.h_s.t[:, :hidden[-1]].float()).astype(np.float64)
+        w3 = host(eng.w3_s.t[:, :hidden[-1]].float()).astype(np.float64)
+        want = h @ w3.T + host(eng.bias3).astype(np.float64)
+        bound = 4e-6 * (np.abs(h) @ np.abs(w3).T) + 1e-6
+        err = np.abs(runs[0][2] - want)
+        assert (err <= bound).all(), f"{name}: {int((err > bound).sum())} logits off, max {err.max():.3e}"
+        # MAP pass, forward only (mlp.lua:88-92): the single-GEMM launch carries the logits as well
+        eng.resetGradients(); eng.clamp_to_map(); eng.run(x, t, backward=False)
+        lm, _ = eng.loss_and_accuracy()
+        hm = host(eng.h_s.t[:, :hidden[-1]].float()).astype(np.float64)
+        wantm = hm @ w3.T + host(eng.bias3).astype(np.float64)
+        errm = np.abs(host(eng.logits) - wantm)
+        assert (errm <= 4e-6 * (np.abs(hm) @ np.abs(w3).T) + 1e-6).all(), f"{name} MAP: max {errm.max():.3e}"
+        res[name] = runs[0] + (lm,)
+    a, b = res["slots"], res["from_h"]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 2, (a[0], b[0], a[1], b[1])
+    assert abs(a[4] - b[4]) <= 1e-6 * abs(b[4])
+    rel = np.linalg.norm(a[3] - b[3]) / np.linalg.norm(b[3])
+    assert rel <= 1e-4, f"gradient arenas of the two head forms: relative Frobenius {rel:.3e}"
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_one_engine_alternates_sampled_and_map_passes_at_one_batch_size(oracle, nnmod, dtype):
     """the kept argument blocks bake in the LRT / MAP operand set, and their cache key did not say which.

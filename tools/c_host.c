@@ -80,6 +80,7 @@ typedef struct {
 
 typedef struct {
     int dtype, esize, n_layers, n_classes, world, rank, dx_first;
+    int n_head_slots; float* head_slots;   /* vbnn_forward_head_slots x N x 16 floats, or 0 / NULL */
     int kl_in_update;         /* 1 (default for bf16): the arena holds the likelihood parts, vbnn_update adds the exact fp32 KL gradient (kl_add) */
     int direct;               /* fp32: operands as their producers left them (no packing launch, no squares, no transposes) */
     uint64_t seed;
@@ -224,6 +225,12 @@ static void fm_alloc_batch(fused_mlp* m, int64_t N) {
     m->logits = (float*)dev_alloc((size_t)N * m->n_classes * 4);
     m->out = (float*)dev_alloc((size_t)N * m->n_classes * 4);
     m->g_logits = (float*)dev_alloc((size_t)N * m->n_classes * 4);
+    /* the head's logits from the last VB layer's forward tiles, where that launch can carry them (vbnn_fwd_args.head_slots) */
+    {
+        layer_t* vl = &m->vb[m->n_layers - 1];
+        m->n_head_slots = m->draw_dev ? 0 : vbnn_forward_head_slots(g_ctx, m->dtype, N, vl->I, vl->O, m->n_classes);
+        m->head_slots = m->n_head_slots > 0 ? (float*)dev_alloc((size_t)m->n_head_slots * N * 16 * 4) : NULL;
+    }
     if (need_prepare) fm_prepare(m);
 }
 
@@ -310,6 +317,7 @@ static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t*
         fa.h2 = (nxt && !m->direct) ? nxt->x2_s.p : NULL;
         fa.ld_h = nxt ? nxt->x_s.ld : m->h_s.ld;
         if (nxt && nxt->has_t) { fa.hT = nxt->xT_s.p; fa.h2T = nxt->x2T_s.p; fa.ld_hT = nxt->xT_s.ld; }
+        if (!nxt && m->n_head_slots > 0) { fa.head_w3 = m->w3_s.p; fa.head_ld_w = m->w3_s.ld; fa.head_C = m->n_classes; fa.head_slots = m->head_slots; }
         CHECK(vbnn_forward(g_ctx, m->dtype, &fa));
     }
     /* final Linear + LogSoftMax + ClassNLL (mlp.lua:29-32), forward and backward */
@@ -324,6 +332,7 @@ static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t*
     ha.relu_mask = 1; ha.r_prev_packed = 1; ha.r_prev = vl->r; ha.ld_r_prev = vl->O;
     ha.g_prev = vl->g_s.p; ha.gv_prev = vl->gv_s.p; ha.ld_gp = vl->g_s.ld;
     if (vl->has_t) { ha.gT_prev = vl->gT_s.p; ha.gvT_prev = vl->gvT_s.p; ha.ld_gpT = vl->gT_s.ld; }
+    if (m->n_head_slots > 0) { ha.logit_slots = m->head_slots; ha.n_slots = m->n_head_slots; }
     CHECK(vbnn_head_forward_backward(g_ctx, m->dtype, &ha));
     vbnn_dw_args dd;
     vbnn_dx_args xa;

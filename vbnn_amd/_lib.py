@@ -31,7 +31,7 @@ class FwdArgs(C.Structure):
                 ("seed", _u64), ("layer", _u32), ("draw", _u32), ("row0", _i64),
                 ("y", _vp), ("ld_y", _i64), ("r", _vp), ("ld_r", _i64), ("r_packed", _i), ("relu", _i),
                 ("h", _vp), ("h2", _vp), ("ld_h", _i64), ("hT", _vp), ("h2T", _vp), ("ld_hT", _i64), ("rows_per_draw", _i64),
-                ("draw_dev", _vp)]
+                ("draw_dev", _vp), ("head_w3", _vp), ("head_ld_w", _i64), ("head_C", _i64), ("head_slots", _vp)]
 
 
 class DxArgs(C.Structure):
@@ -80,7 +80,7 @@ class HeadArgs(C.Structure):          # vbnn_head_args
                 ("logits", _vp), ("out", _vp), ("g_logits", _vp), ("loss_sum_dev", _vp), ("correct_dev", _vp),
                 ("gradWeight", _vp), ("gradBias", _vp), ("gradBias_prev", _vp), ("relu_mask", _i), ("r_prev_packed", _i),
                 ("r_prev", _vp), ("ld_r_prev", _i64), ("g_prev", _vp), ("gv_prev", _vp), ("ld_gp", _i64),
-                ("gT_prev", _vp), ("gvT_prev", _vp), ("ld_gpT", _i64)]
+                ("gT_prev", _vp), ("gvT_prev", _vp), ("ld_gpT", _i64), ("logit_slots", _vp), ("n_slots", _i64)]
 
 
 _SIGS = {
@@ -108,6 +108,8 @@ _SIGS = {
     "vbnn_wn_sample": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _u64, _u32, _u32], _i),
     "vbnn_pack": ([_vp, _i, _i, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64], _i),
     "vbnn_forward": ([_vp, _i, C.POINTER(FwdArgs)], _i),
+    "vbnn_forward_head_slots": ([_vp, _i, _i64, _i64, _i64, _i64], _i),
+    "vbnn_head_forward_slots": ([_vp, _vp, _i64, _vp, _vp, _i64, _i64, _f, _vp, _vp, _vp, _i, _vp, _vp, _i64], _i),
     "vbnn_grad_input": ([_vp, _i, C.POINTER(DxArgs)], _i),
     "vbnn_acc_grad_parameters": ([_vp, _i, C.POINTER(DwArgs)], _i),
     "vbnn_backward_pair": ([_vp, _i, C.POINTER(DxArgs), C.POINTER(DwArgs)], _i),

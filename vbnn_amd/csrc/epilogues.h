@@ -65,6 +65,13 @@ struct EpiFwd {
     T* h; T* h2; int64_t ld_h;
     T* hT; T* h2T; int64_t ld_hT;
     int O, N;
+    // optional (gemm_v3.h only, the LAST VB layer below the fused classifier head, mlp.lua:29): the final nn.Linear's logits are
+    // formed HERE, from the output tile as it stands in the accumulators -- each wave's 128 m x 64 n of relu(y), rounded to the
+    // operand type exactly as `h` is stored, times the matching 128 columns of the packed final weight (C <= 16 rows): one
+    // [16 classes] x [64 n] partial per wave into head_slots[2 tile_m + wave row][N][16] (fp32, a FIXED slot: no atomics, the
+    // head sums the slots in order). The head's forward then never re-reads h (33 MB at 4096 x 4096).
+    const T* head_w3 = nullptr; int64_t head_ld_w = 0; int head_C = 0; float* head_slots = nullptr;
+    static constexpr bool HEAD = sizeof(T) == 2;
 
     static constexpr bool SPLITTABLE = false;     // every output needs both GEMMs of the pair
     static constexpr bool EDGE_FAST = false;      // ragged wave tiles take the guarded form
@@ -327,6 +334,7 @@ struct EpiDx {
 
     static constexpr bool SPLITTABLE = false;
     static constexpr bool EDGE_FAST = false;
+    static constexpr bool HEAD = false;
     __device__ __forceinline__ void bind_draw() {}                 // (no noise in gradInput: r comes from the forward)
     __host__ __device__ __forceinline__ bool has_draw_dev() const { return false; }
     __device__ __forceinline__ void edge_row(int, float) const {}
@@ -464,6 +472,7 @@ struct EpiDw {
     // what depends on that; 0 = both accumulators, as ever.
     int part = 0;
     static constexpr bool SPLITTABLE = true;
+    static constexpr bool HEAD = false;
     __device__ __forceinline__ void set_part(int p) { part = p; }
     __device__ __forceinline__ void bind_draw() { if (draw_dev) draw += *draw_dev; }
     __host__ __device__ __forceinline__ bool has_draw_dev() const { return draw_dev != nullptr; }

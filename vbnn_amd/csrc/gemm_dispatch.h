@@ -38,6 +38,17 @@ static inline bool kmajor_dw_v3_split_selected(int64_t M, int64_t N, int64_t K) 
            K * gemm_v3_split_lda(M) < (1ll << 30) && K * (N + 64) < (1ll << 30);
 }
 
+// does the forward of an I -> O layer on N rows (M = O, N = N, K = I, K-contiguous operands) run on gemm_v3 right now -- the kernel
+// that can carry the classifier head's logits (EpiFwd::head_slots)? Shape and debug keys only, as kmajor_selected; the functor's
+// fast-path conditions are checked at launch, where a forward that was given head_slots and does not take that kernel fails loudly.
+static inline bool head_slots_selected(int64_t N, int64_t I, int64_t O, int64_t C) {
+    if (C < 1 || C > 16 || O % V3_BM || N % V3_BN) return false;
+    const int64_t ld = (I + V2_BK - 1) / V2_BK * V2_BK;
+    if (O * ld >= (1ll << 30) || N * ld >= (1ll << 30)) return false;
+    if (g_force_kernel == 3) return true;
+    return g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_shape_ok(O, N, I);
+}
+
 // the K-major launch (A and / or B stored [K][rows]); false = this shape / configuration does not take it
 template <typename T, bool DUAL, bool AK, bool BK, class Epi>
 static bool try_kmajor(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda, const void* B, const void* B2, int64_t ldb,
@@ -78,6 +89,12 @@ static int launch_gemm(vbnn_ctx* ctx, const void* A, const void* A2, int64_t lda
          (g_force_kernel == 0 && g_v2_tile == 0 && gemm_v3_eligible(M, N, K, lda, ldb, false, false, epi))))
         return launch_gemm_v3<T, DUAL, false, false, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb, (int)M,
                                                           (int)N, (int)K, epi);
+    if constexpr (Epi::HEAD) {
+        if (epi.head_slots) {
+            vbnn_set_error("head_slots given, but this forward does not run on the two-pass 256 x 256 kernel (functor fast path or operands)");
+            return VBNN_ERR_INVALID;
+        }
+    }
     if (v2_ok && g_force_kernel != 1 && (g_force_kernel == 2 || gemm_v2_eligible<T>(M, N, K, lda, ldb)))
         return launch_gemm_v2<T, DUAL, Epi>(ctx, (const T*)A, (const T*)A2, lda, (const T*)B, (const T*)B2, ldb,
                                             (int)M, (int)N, (int)K, epi);

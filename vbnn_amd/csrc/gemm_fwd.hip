@@ -16,12 +16,35 @@ static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
     e.h = (T*)a->h; e.h2 = (T*)a->h2; e.ld_h = a->ld_h;
     e.hT = (T*)a->hT; e.h2T = (T*)a->h2T; e.ld_hT = a->ld_hT;
     e.O = (int)a->O; e.N = (int)a->N;
+    if (a->head_slots) {
+        // the classifier head's logits from the forward's own tiles (vbnn_fwd_args.head_slots): the two-pass 256 x 256 kernel only
+        if constexpr (sizeof(T) == 2) {
+            if (!head_slots_selected(a->N, a->I, a->O, a->head_C) || a->rows_per_draw != 0 || a->draw_dev || !a->head_w3 || a->hT ||
+                a->head_ld_w < a->O || a->head_ld_w % 4 != 0 || !aligned16(a->head_w3) || !aligned16(a->head_slots)) {
+                vbnn_set_error("head_slots: this forward does not take the fused form (ask vbnn_forward_head_slots; no stacked draws, "
+                               "no device draw counter, no transposed output, packed 16-byte-aligned head_w3)");
+                return VBNN_ERR_INVALID;
+            }
+            e.head_w3 = (const T*)a->head_w3; e.head_ld_w = a->head_ld_w; e.head_C = (int)a->head_C; e.head_slots = a->head_slots;
+        } else {
+            vbnn_set_error("head_slots: bf16 only");
+            return VBNN_ERR_INVALID;
+        }
+    }
     if (a->w2) {
         V1Form f;
         if (!a->x2) f.sq = 1;                                    // fp32: x.x is formed while staging x (vbnn_fwd_args.x2 == NULL)
         return launch_gemm<T, true>(ctx, a->w, a->w2, a->ld_w, a->x, a->x2, a->ld_x, a->O, a->N, a->I, e, f);
     }
     return launch_gemm<T, false>(ctx, a->w, nullptr, a->ld_w, a->x, nullptr, a->ld_x, a->O, a->N, a->I, e);
+}
+
+// slots the forward of an I -> O layer on N rows would write with vbnn_fwd_args.head_slots (0: that launch does not carry the
+// head's logits -- use vbnn_head_forward on h)
+extern "C" int vbnn_forward_head_slots(vbnn_ctx* ctx, int dtype, int64_t N, int64_t I, int64_t O, int64_t C) {
+    vbnn_cu_scope plan(ctx);
+    if (dtype != VBNN_BF16 || !head_slots_selected(N, I, O, C)) return 0;
+    return (int)(2 * (O / V3_BM));
 }
 
 extern "C" int vbnn_forward(vbnn_ctx* ctx, int dtype, const vbnn_fwd_args* a) {

@@ -1006,6 +1006,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         V3_ST(3);
     }
 
+    // ---- the classifier head's logits from this tile (EpiFwd::head_slots; see epilogues.h). The accumulators ARE y (the fold
+    // put b + sqrt(v) z under pass 2): lane (q4, c16) holds m = 16 i + 4 q4 + 0..3 of row n = 16 j + c16 in acc[i][j]. An MFMA
+    // contracts over its k slots whatever they stand for, so slot (q4, e) of the B operand is taken to mean m = 16 i0 + 4 q4 + e
+    // (e < 4) and 16 i1 + 4 q4 + e - 4 (e >= 4) for a PAIR of m-blocks (i0, i1): the B fragment is then the two accumulator
+    // quads as they stand (ReLU, rounded to bf16 -- the values `h` gets), no LDS trip, and the A fragment is the final weight's
+    // row `class = c16` at the same m: two 8-byte loads per pair. 16 MFMAs per wave.
+    if constexpr (!SPLIT && Epi::HEAD) {
+        if (epi.head_slots) {
+            const int hq4 = lane >> 4, hc16 = lane & 15;
+            const bf16_t* wrow = epi.head_w3 + (int64_t)min(hc16, epi.head_C - 1) * epi.head_ld_w + (m0 + wr * 128) + 4 * hq4;
+            bf16x8 wf[4];
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(wrow + 32 * pr);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(wrow + 32 * pr + 16);
+                wf[pr] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            const bool relu = epi.relu != 0;
+            float* const sl = epi.head_slots + ((int64_t)(tm * 2 + wr) * epi.N + (n0 + wc * 64)) * 16 + hc16 * 16 + 4 * hq4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const f32x4 a0 = acc[2 * pr][j], a1 = acc[2 * pr + 1][j];
+                    bf16x8 hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hb[e] = (bf16_t)(relu ? fmaxf(a0[e], 0.f) : a0[e]);
+                        hb[4 + e] = (bf16_t)(relu ? fmaxf(a1[e], 0.f) : a1[e]);
+                    }
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[pr], hb, d, 0, 0, 0);
+                }
+                // classes 4 q4 .. + 3 of row 16 j + c16: 16 rows x 64 contiguous bytes per wave-instruction
+                *reinterpret_cast<f32x4*>(sl + j * 256) = d;
+            }
+        }
+    }
+
     ET* tp1 = epi.t1_ptr();
     ET* tp2 = epi.t2_ptr();
     const bool any_t = (tp1 != nullptr) || (tp2 != nullptr);

@@ -90,6 +90,77 @@ __device__ __forceinline__ float head_sum_partials(const float* src, int64_t str
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// The rows of one 16-row block from their logits (without the bias): lane (q = lane >> 4, c16 = lane & 15) of ONE wave holds classes
+// 4q .. 4q + 3 of row n0 + c16 in `s`. Bias, log-softmax, arg-max (first maximum wins: Tensor:max), d(loss)/d(logits), and the
+// block's loss / hit partials (write-through: the last arriver's payload).
+__device__ __forceinline__ void head_rows_from_logits(f32x4 s, int lane, int64_t n0, int64_t N, int C, const float* __restrict__ bias,
+                                                      const int32_t* __restrict__ target, int64_t rpd, float inv_n, float* out, float* g_logits,
+                                                      float* logits, double* part_loss, int32_t* part_corr) {
+    const int q = lane >> 4, c16 = lane & 15;
+    const int64_t n = n0 + c16;
+    const bool row_ok = n < N;
+    float lg[4];
+    float mx = -INFINITY; int arg = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * q + j;
+        lg[j] = (c < C) ? s[j] + (bias ? bias[c] : 0.f) : -INFINITY;
+        if (lg[j] > mx) { mx = lg[j]; arg = c; }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {           // combine the four lanes (q = 0..3) of a row
+        const float om = __shfl_xor(mx, off, 64);
+        const int oa = __shfl_xor(arg, off, 64);
+        if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }     // first maximum wins (Tensor:max)
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (4 * q + j < C) se += expf(lg[j] - mx);
+    se += __shfl_xor(se, 16, 64);
+    se += __shfl_xor(se, 32, 64);
+    const float lse = mx + logf(se);
+    const int t = row_ok ? min(max(target[rpd > 0 ? n % rpd : n], 0), C - 1) : 0;     // stacked draws share the minibatch's targets
+    double loss_acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * q + j;
+        if (row_ok && c < C) {
+            const float o = lg[j] - lse;
+            if (logits) logits[n * C + c] = lg[j];
+            if (out) out[n * C + c] = o;
+            g_logits[n * C + c] = (expf(o) - (c == t ? 1.0f : 0.0f)) * inv_n;
+            if (c == t) loss_acc -= (double)o * (double)inv_n;
+        }
+    }
+    int corr = (row_ok && q == 0 && arg == t) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { loss_acc += __shfl_xor(loss_acc, off, 64); corr += __shfl_xor(corr, off, 64); }
+    if (lane == 0) { vbnn_store_wt(&part_loss[blockIdx.x], loss_acc); vbnn_store_wt(&part_corr[blockIdx.x], (int32_t)corr); }
+}
+
+// the last workgroup to arrive adds the per-workgroup loss / hit partials in a fixed order (NT threads per workgroup)
+template <int NT>
+__device__ __forceinline__ void head_sum_loss_partials(unsigned* counter, const double* part_loss, const int32_t* part_corr, double* loss_sum,
+                                                       int32_t* correct, int accumulate, double* red_l, int* red_c, int* last) {
+    if (!vbnn_last_arriver(counter, gridDim.x, last)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double ls = 0.0;
+    int cs = 0;
+    for (int b = (int)threadIdx.x; b < (int)gridDim.x; b += NT) { ls += vbnn_load_wt(&part_loss[b]); cs += vbnn_load_wt(&part_corr[b]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ls += __shfl_xor(ls, off, 64); cs += __shfl_xor(cs, off, 64); }
+    if (lane == 0) { red_l[wave] = ls; red_c[wave] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double lt = 0.0;
+        int ct = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { lt += red_l[w]; ct += red_c[w]; }
+        if (loss_sum) loss_sum[0] = (accumulate ? loss_sum[0] : 0.0) + lt;
+        if (correct) correct[0] = (accumulate ? correct[0] : 0) + ct;
+    }
+}
+
 // MFMA orientation: M = class (A operand = w3 rows, rows >= C clamped and ignored), N = minibatch row.
 // Accumulator layout: lane (q = l >> 4, c = l & 15) holds classes 4q .. 4q+3 of row n0 + c.
 template <typename T>
@@ -155,64 +226,46 @@ __global__ __launch_bounds__(64 * HEAD_FW) void k_head_forward(const T* __restri
         f32x4 s = part[0][lane];
 #pragma unroll
         for (int w = 1; w < HEAD_FW; ++w) s += part[w][lane];
-        const int64_t n = n0 + c16;
-        const bool row_ok = n < N;
-        float lg[4];
-        float mx = -INFINITY; int arg = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 4 * q + j;
-            lg[j] = (c < C) ? s[j] + (bias ? bias[c] : 0.f) : -INFINITY;
-            if (lg[j] > mx) { mx = lg[j]; arg = c; }
-        }
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {           // combine the four lanes (q = 0..3) of a row
-            const float om = __shfl_xor(mx, off, 64);
-            const int oa = __shfl_xor(arg, off, 64);
-            if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }     // first maximum wins (Tensor:max)
-        }
-        float se = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (4 * q + j < C) se += expf(lg[j] - mx);
-        se += __shfl_xor(se, 16, 64);
-        se += __shfl_xor(se, 32, 64);
-        const float lse = mx + logf(se);
-        const int t = row_ok ? min(max(target[rpd > 0 ? n % rpd : n], 0), C - 1) : 0;     // stacked draws share the minibatch's targets
-        double loss_acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 4 * q + j;
-            if (row_ok && c < C) {
-                const float o = lg[j] - lse;
-                if (logits) logits[n * C + c] = lg[j];
-                if (out) out[n * C + c] = o;
-                g_logits[n * C + c] = (expf(o) - (c == t ? 1.0f : 0.0f)) * inv_n;
-                if (c == t) loss_acc -= (double)o * (double)inv_n;
-            }
-        }
-        int corr = (row_ok && q == 0 && arg == t) ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { loss_acc += __shfl_xor(loss_acc, off, 64); corr += __shfl_xor(corr, off, 64); }
-        if (lane == 0) { vbnn_store_wt(&part_loss[blockIdx.x], loss_acc); vbnn_store_wt(&part_corr[blockIdx.x], (int32_t)corr); }
+        head_rows_from_logits(s, lane, n0, N, C, bias, target, rpd, inv_n, out, g_logits, logits, part_loss, part_corr);
     }
     // ---- second stage: the last workgroup to arrive adds the per-workgroup loss / hit partials in a fixed order
     // (bitwise reproducible loss; and with accumulate = 0 the caller needs no memset of the two accumulators)
-    if (!vbnn_last_arriver(counter, gridDim.x, &last)) return;
-    double ls = 0.0;
-    int cs = 0;
-    for (int b = (int)threadIdx.x; b < (int)gridDim.x; b += 64 * HEAD_FW) { ls += vbnn_load_wt(&part_loss[b]); cs += vbnn_load_wt(&part_corr[b]); }
+    head_sum_loss_partials<64 * HEAD_FW>(counter, part_loss, part_corr, loss_sum, correct, accumulate, red_l, red_c, &last);
+}
+
+// The same forward from partial logits left by the last VB layer's forward launch (EpiFwd::head_slots, gemm_v3.h): one wave per
+// 16 rows, lane (q, c16) adds classes 4q .. 4q + 3 of row n0 + c16 over the slots IN ORDER (all loads in flight together),
+// then exactly k_head_forward's row arithmetic and its in-launch loss sum. h is not read: 8 MB of slots instead of 33 MB.
+__global__ __launch_bounds__(64) void k_head_from_slots(const float* __restrict__ slots, int n_slots, const float* __restrict__ bias,
+                                                        const int32_t* __restrict__ target, int64_t N, int C, float inv_n, float* out,
+                                                        float* g_logits, float* logits, double* loss_sum, int32_t* correct, int accumulate,
+                                                        double* part_loss, int32_t* part_corr, unsigned* counter, int64_t rpd) {
+    __shared__ double red_l[1];
+    __shared__ int red_c[1];
+    __shared__ int last;
+    const int lane = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const int q = lane >> 4, c16 = lane & 15;
+    const float* p = slots + (min(n0 + c16, N - 1) * 16 + 4 * q);
+    const int64_t stride = N * 16;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 16 <= n_slots; k += 16) {
+        f32x4 v[16];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { ls += __shfl_xor(ls, off, 64); cs += __shfl_xor(cs, off, 64); }
-    if (lane == 0) { red_l[wave] = ls; red_c[wave] = cs; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double lt = 0.0;
-        int ct = 0;
+        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + u) * stride);
 #pragma unroll
-        for (int w = 0; w < HEAD_FW; ++w) { lt += red_l[w]; ct += red_c[w]; }
-        if (loss_sum) loss_sum[0] = (accumulate ? loss_sum[0] : 0.0) + lt;
-        if (correct) correct[0] = (accumulate ? correct[0] : 0) + ct;
+        for (int u = 0; u < 16; ++u) s += v[u];
     }
+    for (; k + 2 <= n_slots; k += 2) {
+        f32x4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + u) * stride);
+        s += v[0]; s += v[1];
+    }
+    for (; k < n_slots; ++k) s += *reinterpret_cast<const f32x4*>(p + (int64_t)k * stride);
+    head_rows_from_logits(s, lane, n0, N, C, bias, target, rpd, inv_n, out, g_logits, logits, part_loss, part_corr);
+    head_sum_loss_partials<64>(counter, part_loss, part_corr, loss_sum, correct, accumulate, red_l, red_c, &last);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -769,6 +822,25 @@ extern "C" int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_
     VBNN_API_END
 }
 
+extern "C" int vbnn_head_forward_slots(vbnn_ctx* ctx, const float* slots, int64_t n_slots, const float* bias, const int32_t* target,
+                                       int64_t N, int64_t C, float inv_n, float* logits, float* out, float* g_logits, int accumulate,
+                                       double* loss_sum_dev, int32_t* correct_dev, int64_t rows_per_draw) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && slots && target && g_logits, "null argument");
+    VBNN_REQUIRE(rows_per_draw >= 0, "rows_per_draw");
+    VBNN_REQUIRE(N > 0 && C > 0 && C <= HEAD_CMAX && n_slots > 0 && n_slots < (1 << 20), "shape (C <= 16)");
+    VBNN_REQUIRE(((uintptr_t)slots & 15u) == 0, "slots must be 16-byte aligned");
+    const unsigned nb = (unsigned)((N + 15) / 16);
+    VBNN_REQUIRE((size_t)nb * 2 <= ctx->scratch_doubles, "minibatch too large for the reduction scratch");
+    double* part_loss = ctx->scratch;                                       // [nb] doubles, then [nb] ints
+    int32_t* part_corr = reinterpret_cast<int32_t*>(ctx->scratch + nb);
+    hipLaunchKernelGGL(k_head_from_slots, dim3(nb), dim3(64), 0, ctx->stream, slots, (int)n_slots, bias, target, N, (int)C, inv_n, out,
+                       g_logits, logits, loss_sum_dev, correct_dev, accumulate, part_loss, part_corr, ctx->counters + VBNN_CNT_HEAD_FWD,
+                       rows_per_draw);
+    return vbnn_check_launch("k_head_from_slots");
+    VBNN_API_END
+}
+
 static int g_head_inline_finish = 1;      // A/B: VBNN_HEAD_INLINE_FINISH=0 in the environment keeps the separate finish kernel
 template <typename T>
 static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3, int64_t ld_w, const float* g_logits, int64_t N,
@@ -882,8 +954,12 @@ extern "C" int vbnn_head_forward_backward(vbnn_ctx* ctx, int dtype, const vbnn_h
         (!a->r_prev || (a->ld_r_prev % 2 == 0 && a->ld_r_prev >= H && ((uintptr_t)a->r_prev & 7u) == 0)) &&
         (!a->g_prev || (a->ld_gp % 2 == 0 && a->ld_gp >= H && (((uintptr_t)a->g_prev | (uintptr_t)a->gv_prev) & 7u) == 0)) &&
         (int64_t)(ctx->scratch_doubles * 2) >= head_floats + R * per_block;
-    if (!one_launch) {
-        const int st = vbnn_head_forward(ctx, dtype, a->h, a->ld_h, a->w3, a->ld_w, a->bias, a->target, N, H, C, a->inv_n, a->logits, a->out,
+    if (!one_launch || a->logit_slots) {
+        // the forward half: from the partial logits the last VB layer's forward left (vbnn_fwd_args.head_slots), or from h
+        const int st = a->logit_slots
+                           ? vbnn_head_forward_slots(ctx, a->logit_slots, a->n_slots, a->bias, a->target, N, C, a->inv_n, a->logits, a->out,
+                                                     a->g_logits, a->accumulate, a->loss_sum_dev, a->correct_dev, a->rows_per_draw)
+                           : vbnn_head_forward(ctx, dtype, a->h, a->ld_h, a->w3, a->ld_w, a->bias, a->target, N, H, C, a->inv_n, a->logits, a->out,
                                          a->g_logits, a->accumulate, a->loss_sum_dev, a->correct_dev, a->rows_per_draw);
         if (st != VBNN_OK) return st;
         return vbnn_head_backward(ctx, dtype, a->h, a->ld_h, a->w3, a->ld_w, a->g_logits, N, H, C, a->accumulate, a->gradWeight,

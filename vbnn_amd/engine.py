@@ -340,6 +340,14 @@ class FusedMLP:
         self.out = torch.zeros(N, self.n_classes, dtype=torch.float32, device=dev)
         self.g3_s = _Packed(N, self.n_classes, tdt, dev)
         self.g3T_s = _Packed(self.n_classes, N, tdt, dev)
+        # the fused head's logits from the last VB layer's forward tiles (vbnn_fwd_args.head_slots): where the library's forward
+        # of that layer can carry them, the head never re-reads h. opt.head_from_h = True keeps the head's own pass over h (A/B).
+        vl = self.vb[-1]
+        self.n_head_slots, self.head_slots = 0, None
+        if self.n_classes <= 16 and self.criterion == "nll" and not self.device_draw and not self.opt.get("head_from_h", False):
+            ns = lib.vbnn_forward_head_slots(self.ctx.h, self.code, N, vl.I, vl.O, self.n_classes)
+            if ns > 0:
+                self.n_head_slots, self.head_slots = ns, torch.zeros(ns * N * 16, dtype=torch.float32, device=dev)
         if need_prepare:
             self.prepare()
 
@@ -513,7 +521,12 @@ class FusedMLP:
                          ld_h=self.h_s.ld if last else nxt.x_s.ld,
                          hT=(None if (self.n_classes <= 16 and self.criterion == "nll") else self.hT_s.ptr) if last else (nxt.xT_s.ptr if nxt.xT_s else None),
                          h2T=None if (last or not lrt or not nxt.x2T_s) else nxt.x2T_s.ptr,
-                         ld_hT=self.hT_s.ld if last else (nxt.xT_s.ld if nxt.xT_s else 0), rows_per_draw=self._rpd)
+                         ld_hT=self.hT_s.ld if last else (nxt.xT_s.ld if nxt.xT_s else 0), rows_per_draw=self._rpd,
+                         **(dict(head_w3=self.w3_s.ptr, head_ld_w=self.w3_s.ld, head_C=self.n_classes, head_slots=_p(self.head_slots))
+                            if (last and self._use_head_slots()) else {}))
+
+    def _use_head_slots(self):
+        return self.n_head_slots > 0 and not self._rpd
 
     def _dw_args(self, li, N, accumulate):
         direct_x = li == 0 and self._x_in is not None
@@ -640,12 +653,19 @@ class FusedMLP:
                     a.gT_prev = vl.gT_s.ptr if vl.gT_s else None
                     a.gvT_prev = vl.gvT_s.ptr if (lrt and vl.gvT_s) else None
                     a.ld_gpT = vl.gT_s.ld if vl.gT_s else 0
+                    if self._use_head_slots():            # the logits' partial sums are in the slots the forward just wrote
+                        a.logit_slots, a.n_slots = _p(self.head_slots), self.n_head_slots
                 a.target = _p(targets)
                 L.check(lib.vbnn_head_forward_backward(ctx, code, C.byref(a)))
             else:
-                L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
-                                              _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
-                                              _p(self.g_logits), accumulate, _p(self._acc), _p(self._corr), self._rpd))
+                if self._use_head_slots():
+                    L.check(lib.vbnn_head_forward_slots(ctx, _p(self.head_slots), self.n_head_slots, _p(self.bias3), _p(targets), N, Cn,
+                                                        inv_n, _p(self.logits), _p(self.out), _p(self.g_logits), accumulate,
+                                                        _p(self._acc), _p(self._corr), self._rpd))
+                else:
+                    L.check(lib.vbnn_head_forward(ctx, code, self.h_s.ptr, self.h_s.ld, self.w3_s.ptr, self.w3_s.ld,
+                                                  _p(self.bias3), _p(targets), N, H, Cn, inv_n, _p(self.logits), _p(self.out),
+                                                  _p(self.g_logits), accumulate, _p(self._acc), _p(self._corr), self._rpd))
                 if not backward:
                     self._first = False
                     return
