@@ -859,7 +859,13 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
     const int64_t per_chunk = C * H + C + H;
     const int64_t cap = (int64_t)(ctx->scratch_doubles * 2) / per_chunk;
     VBNN_REQUIRE(!sums || cap >= 1, "hidden size too large for the reduction scratch");
-    int64_t R = (1024 + tiles_c - 1) / tiles_c;
+    // (r04: two workgroups per CU -- ONE round of the grid: 512 workgroups on 256 CUs. A launch of 1024 was two rounds, each workgroup
+    // paying its prologue (final-weight columns, first tiles) twice over: 37.2 -> 34.1 us with the finish kernel at 4096 x 4096,
+    // tools/time_head.py; 256: 47, 2048: 39. A rewrite of the loop around transpose reads and vector LDS stores -- a quarter of the
+    // LDS instructions -- measured NO faster (36.8 us): the launch is bound by its 134 MB of mixed reads and writes, not by LDS.)
+    int64_t R = (2 * (int64_t)vbnn_cu_count() + tiles_c - 1) / tiles_c;
+    static const int env_blocks = [] { const char* e = getenv("VBNN_HEAD_BLOCKS"); return e ? atoi(e) : 0; }();      // A/B: target workgroup count
+    if (env_blocks > 0) R = (env_blocks + tiles_c - 1) / tiles_c;
     if (R > tiles_r) R = tiles_r;
     if (sums && R > cap) R = cap;
     if (R < 1) R = 1;
