@@ -259,6 +259,55 @@ def side_config_row(name, torch, dist, L, FusedMLP, fill_normal, steps, warmup, 
     return out
 
 
+def sharded_train_row(cfg, torch, dist, L, FusedMLP, fill_normal, steps, warmup, world, rank, blocks=3):
+    """The TRAINING step with the sharded-update exchange (opt.exchange_mode = "sharded": reduce-scatter of the gradients by layer
+    rows, vbnn_update on this rank's rows, all-gather of the bf16 operand shadows + statistics -- 0.75 x the all-reduce's bytes,
+    1 / world of the update sweep, fp32 sums) beside the all-reduce line, same protocol. An OPTION beside north_star's all-reduce:
+    its step cannot leave the update out (the gather follows it), so it is comparable with `train_step`, not with `value`."""
+    from vbnn_amd import partition
+    N = cfg["batch"]
+    opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"], hidden=cfg["hidden"],
+               n_classes=cfg["n_classes"], fuse_kl=True, criterion=cfg.get("criterion", "nll"), exchange_mode="sharded",
+               state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
+    eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=True)
+    x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
+    fill_normal(x, 3, L.STREAM_DATA, 0, 0, row0=rank * N)
+    t = eng.synthetic_targets(x, rank * N)
+
+    def train_step():
+        eng.resetGradients(); eng.sample(); eng.run(x, t); eng.update()
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    eng.prepare()
+    for _ in range(max(3, warmup)):
+        train_step()
+    wall = []
+    for _ in range(blocks):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            train_step()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall.append(float(tt.item()) / steps * 1e3)
+    eng.check_exchange()
+    ms = sorted(wall)[len(wall) // 2]
+    ar, sh = partition.exchange_bytes(eng._lay, {"weight": (0, eng.gradWeight3.numel()), "bias": (0, eng.gradBias3.numel())}, world)
+    out = {"exchange_mode": "sharded", "backend": eng.comm_backend(), "ms_per_train_step": round(ms, 4),
+           "samples_per_s": round(N * world / (ms * 1e-3), 1), "repeats_wall_ms": [round(v, 4) for v in wall],
+           "bytes_sent_per_rank_per_step": {"all_reduce": int(ar), "sharded": int(sh), "ratio": round(sh / ar, 4) if ar else None},
+           "update_rows_per_rank": [p["rows"] for p in eng._plan],
+           "note": "reduce-scatter (fp32 sums, by layer rows) -> vbnn_update on this rank's rows (Adam state + fp32 master rows sharded, the exact "
+                   "KL gradient added there) -> all-gather of the bf16 operand shadows + the slices' prior statistics; compare with train_step"}
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def time_other_backend(eng, torch, reps=5):
     """The buckets of the step through the exchange backend the step did NOT use, back to back on the idle GPUs: vbnn_p2p (the
     direct reduce-scatter + all-gather over peer-mapped arenas) when the step ran on RCCL, RCCL when it ran on vbnn_p2p -- so
@@ -685,7 +734,15 @@ def main():
             deep = side_config_row("deep", torch, dist, L, FusedMLP, fill_normal, min(args.steps, 20), min(args.warmup, 5), world, rank, use_dist)
         except Exception as e:                  # noqa: BLE001 -- never at the price of the headline
             deep = {"error": f"{type(e).__name__}: {e}"[:300]}
+    sharded = None
+    if use_dist and cfg["dtype"] == "bf16" and args.mode == "lrt" and args.S == 1 and not args.no_train_step and cfg.get("criterion", "nll") == "nll":
+        try:
+            sharded = sharded_train_row(cfg, torch, dist, L, FusedMLP, fill_normal, min(args.steps, 20), min(args.warmup, 5), world, rank)
+        except Exception as e:                  # noqa: BLE001
+            sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
+        if sharded is not None:
+            out["train_step_sharded"] = sharded
         if deep is not None:
             out["deep_config"] = deep
         print(json.dumps(out), flush=True)

@@ -419,6 +419,25 @@ int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int6
 /* all_dev[r] = rank r's *mine_dev (device memory, 8 bytes per rank), gathered over the same communicator and stream:
  * lets the host verify that `world` distinct processes / devices take part in the exchange. */
 int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
+/* The two halves of the all-reduce as calls of their own, for the SHARDED-UPDATE exchange (an option beside north_star's
+ * all-reduce; engine.py: opt.exchange_mode = "sharded"): after accGradParameters the gradient regions are
+ * reduce-SCATTERED (rank r ends with the fp32 sums of its 1 / world of every layer's rows), rank r runs vbnn_update on that slice
+ * alone (Adam state and fp32 master parameters sharded), and what is all-GATHERED afterwards is the packed operand shadows the
+ * next forward reads -- bf16 mu and sigma^2, 4 bytes per weight instead of the 8 bytes of fp32 gradients an all-reduce's second
+ * half moves -- plus four doubles of prior statistics per layer: 0.75x the bytes, 1 / world of the update sweep, fp32 sums.
+ * Both are in place, ordered behind the context's stream, run on the exchange stream (vbnn_comm_finish orders the context's
+ * stream behind them). reduce_scatter: buf holds world x n_per_rank floats; afterwards floats [rank n_per_rank, (rank + 1)
+ * n_per_rank) are the sums over ranks (the rest is undefined). all_gather: buf holds world x bytes_per_rank bytes, rank r
+ * contributes bytes [r bytes_per_rank, (r + 1) bytes_per_rank). */
+int vbnn_comm_reduce_scatter(vbnn_comm* comm, float* buf, int64_t n_per_rank);
+int vbnn_comm_all_gather(vbnn_comm* comm, void* buf, int64_t bytes_per_rank);
+/* Device-side glue of that exchange. vbnn_stats_combine: parts = [world][n_layers][4] doubles, rank r's block being the `stats`
+ * its slice's vbnn_update left (sum(exp(lvars) + means^2), sum(lvars), -, slice weights), gathered over the ranks; writes each
+ * layer's statistics of the WHOLE layer (sums in rank order; var_hat as vbnn_update forms it) into stats[l]. Every rank computes
+ * the same doubles. vbnn_transpose_packed: dst[c][r] = src[r][c] for a packed operand -- layers that keep transposed shadows
+ * rebuild them from the gathered mu_s / var_s. */
+int vbnn_stats_combine(vbnn_ctx* ctx, int n_layers, int world, const double* parts, double* const* stats);
+int vbnn_transpose_packed(vbnn_ctx* ctx, int dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst);
 
 /* ---- the same exchange WITHOUT a collective library: direct reduce-scatter + all-gather over peer-mapped arenas
  * (vbnn_amd/csrc/p2p.hip; SURVEY.md section 5's fallback should RCCL put the 160 MB all-reduce on a single ring: every GPU of an
@@ -445,6 +464,11 @@ int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_floats, vbn
 int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles);
 int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n);
 int vbnn_p2p_finish(vbnn_p2p* p);
+/* the same two halves over the peer-mapped arena (regions of the arena, in floats; equal chunks, rank r's at offset + r x
+ * n_per_rank): whatever the sharded-update exchange gathers -- the operand shadows, the statistics -- lives IN the arena then
+ * (the host allocates it large enough and places them there) */
+int vbnn_p2p_reduce_scatter(vbnn_p2p* p, size_t offset_floats, int64_t n_per_rank);
+int vbnn_p2p_all_gather(vbnn_p2p* p, size_t offset_floats, int64_t n_per_rank);
 int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up);
 int vbnn_p2p_set_timeout(vbnn_p2p* p, double seconds);
 int vbnn_p2p_clear_status(vbnn_p2p* p);

@@ -155,11 +155,17 @@ int vbnn_comm_finish(vbnn_comm* comm);
 int vbnn_allreduce_grads_bf16(vbnn_comm* comm, void* buf_bf16, int64_t n);
 int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void* dst, int64_t n);
 int vbnn_comm_allgather_u64(vbnn_comm* comm, const uint64_t* mine_dev, uint64_t* all_dev);
+int vbnn_comm_reduce_scatter(vbnn_comm* comm, float* buf, int64_t n_per_rank);
+int vbnn_comm_all_gather(vbnn_comm* comm, void* buf, int64_t bytes_per_rank);
+int vbnn_stats_combine(vbnn_ctx* ctx, int n_layers, int world, const double* parts, double* const* stats);
+int vbnn_transpose_packed(vbnn_ctx* ctx, int dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst);
 typedef struct vbnn_p2p vbnn_p2p;
 int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_floats, vbnn_p2p** out, void** arena_out, void* handle_out);
 int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles);
 int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n);
 int vbnn_p2p_finish(vbnn_p2p* p);
+int vbnn_p2p_reduce_scatter(vbnn_p2p* p, size_t offset_floats, int64_t n_per_rank);
+int vbnn_p2p_all_gather(vbnn_p2p* p, size_t offset_floats, int64_t n_per_rank);
 int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up);
 int vbnn_p2p_set_timeout(vbnn_p2p* p, double seconds);
 int vbnn_p2p_clear_status(vbnn_p2p* p);

@@ -167,3 +167,71 @@ def test_two_ranks_through_the_p2p_exchange_match_the_single_process_step(tmp_pa
     finally:
         os.environ.pop("VBNN_EXCHANGE_FOR_WORKER", None)
 
+
+
+@pytest.mark.parametrize("world,exchange,dtype,hidden,I0,n_loc", [
+    (1, "torch", "bf16", "48,36", 70, 64),
+    (2, "torch", "bf16", "48,36", 70, 64), (3, "torch", "bf16", "48,36", 70, 64),
+    (2, "p2p", "bf16", "48,36", 70, 64), (3, "p2p", "bf16", "48,36", 70, 64),
+    # the wide configuration itself: K-major operands (no transposed shadows), the two-launch accGradParameters with its early
+    # d/dlvars message, the head's logits from the forward tiles
+    (2, "p2p", "bf16", "4096,4096", 784, 4096)])
+def test_sharded_update_exchange_leaves_bitwise_the_all_reduce_parameters(tmp_path, world, exchange, dtype, hidden, I0, n_loc):
+    """opt.exchange_mode = "sharded" (VERDICT r03 item 3): reduce-scatter of the likelihood gradients by layer rows, vbnn_update on
+    this rank's rows alone (Adam state sharded), all-gather of the bf16 operand shadows + the slices' prior statistics -- 0.75 x
+    the bytes of the all-reduce, 1 / world of the update sweep, the sums still fp32. After TWO training steps (the second Adam
+    step depends on the first's moments and on the gathered statistics) the parameters, biases, final Linear and operand shadows
+    are BITWISE those of the all-reduce mode with the same ranks over the same exchange (the reduce-scatter forms the very sums
+    the all-reduce forms, the slice update is the whole update restricted to rows); the statistics agree to 1e-14 (a sum over row
+    slices in rank order against one sum over the layer)."""
+    res = {}
+    for mode in ("allreduce", "sharded"):
+        out = str(tmp_path / f"{mode}.npz")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", VBNN_EXCHANGE=exchange)
+        env["VBNN_FORCE_DIST"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sharded_worker.py"), out, mode, dtype, hidden, str(I0),
+               str(n_loc), "2"]
+        r = _children.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert r.stdout.count("equal across ranks: True") == world, r.stdout[-1500:]
+        if exchange == "p2p" and world > 1:
+            assert r.stdout.count("exchange vbnn_p2p/ipc") == world, r.stdout[-1500:]
+        res[mode] = dict(np.load(out))
+    a, b = res["allreduce"], res["sharded"]
+    # (gloo's ring all-reduce adds three or more ranks' terms in an order that depends on where an element lies in the MESSAGE, and
+    # the two modes cut the arena into different messages: bitwise there only for one or two ranks -- a + b has one order. The
+    # library's own exchange sums in rank order whatever the message.)
+    bitwise = exchange == "p2p" or world <= 2
+    if bitwise:
+        assert np.array_equal(a["losses"], b["losses"]), (a["losses"], b["losses"])
+    else:
+        np.testing.assert_allclose(b["losses"], a["losses"], rtol=1e-6)
+    for k in a:
+        if k.startswith("stats"):
+            np.testing.assert_allclose(b[k][:3], a[k][:3], rtol=1e-14 if bitwise else 1e-6, atol=0)
+        elif k != "losses" and bitwise:
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), f"{k}: {int((a[k] != b[k]).sum())} of {a[k].size} elements differ (max {np.abs(a[k] - b[k]).max():.3e})"
+        elif k != "losses":
+            np.testing.assert_allclose(b[k], a[k], rtol=0, atol=2e-6 * np.abs(a[k]).max(), err_msg=k)
+
+
+def test_bench_line_of_a_multi_rank_run_prices_the_sharded_update_exchange():
+    """`bench.py --gpus 2` on the headline configuration (two gloo ranks sharing the GPU, the step's buckets over vbnn_p2p): beside
+    the all-reduce step and its train_step the line carries train_step_sharded -- the same training step with the reduce-scatter /
+    sliced update / shadow all-gather exchange -- with the bytes each mode sends per rank and step."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VBNN_DIST_BACKEND="gloo", VBNN_EXCHANGE="p2p")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1",
+           "--no-cpu-baseline", "--no-deep-config"]
+    res = _children.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8192 and out["comm"]["backend"] == "vbnn_p2p/ipc"
+    sh = out["train_step_sharded"]
+    assert "error" not in sh, sh
+    assert sh["backend"] == "vbnn_p2p/ipc" and sh["ms_per_train_step"] > 0 and sh["update_rows_per_rank"] == [2048, 2048]
+    assert abs(sh["bytes_sent_per_rank_per_step"]["ratio"] - 0.75) < 0.01
+    assert out["train_step"]["ms_per_train_step"] > 0 and out["comm"]["p2p_barrier_gave_up_epoch"] == 0

@@ -132,6 +132,12 @@ _SIGS = {
     "vbnn_allreduce_grads_bf16": ([_vp, _vp, _i64], _i),
     "vbnn_cast_grads": ([_vp, _i, _vp, _vp, _i64], _i),
     "vbnn_comm_allgather_u64": ([_vp, _vp, _vp], _i),
+    "vbnn_stats_combine": ([_vp, _i, _i, _vp, _vp], _i),
+    "vbnn_transpose_packed": ([_vp, _i, _vp, _i64, _i64, _i64, _vp, _i64], _i),
+    "vbnn_comm_reduce_scatter": ([_vp, _vp, _i64], _i),
+    "vbnn_comm_all_gather": ([_vp, _vp, _i64], _i),
+    "vbnn_p2p_reduce_scatter": ([_vp, C.c_size_t, _i64], _i),
+    "vbnn_p2p_all_gather": ([_vp, C.c_size_t, _i64], _i),
     "vbnn_p2p_create": ([_vp, _i, _i, C.c_size_t, C.POINTER(_vp), C.POINTER(_vp), _vp], _i),
     "vbnn_p2p_connect": ([_vp, _vp], _i),
     "vbnn_p2p_allreduce": ([_vp, C.c_size_t, _i64], _i),

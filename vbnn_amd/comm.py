@@ -31,6 +31,29 @@ class TorchExchange:
         for w in self.works:
             w.wait()
         self.works = []
+        for dst, src in getattr(self, "_copyback", []):        # (all_gather: pieces gathered into temporaries)
+            dst.copy_(src)
+        self._copyback = []
+
+    # the two halves as calls of their own (sharded-update exchange). The rehearsal transport has no in-place reduce-scatter:
+    # an all-reduce of the region leaves every rank's slice with the same sums a reduce-scatter would (and the rest too).
+    def reduce_scatter(self, buf, n_per_rank):
+        assert buf.numel() == n_per_rank * self.dist.get_world_size(self.pg)
+        self.allreduce(buf)
+
+    def all_gather(self, buf):
+        world, rank = self.dist.get_world_size(self.pg), self.dist.get_rank(self.pg)
+        flat = buf.reshape(-1)
+        assert flat.data_ptr() == buf.data_ptr() and flat.numel() % world == 0
+        n = flat.numel() // world
+        mine = flat[rank * n:(rank + 1) * n].clone()
+        pieces = [torch.empty_like(mine) for _ in range(world)]
+        self.works.append(self.dist.all_gather(pieces, mine, group=self.pg, async_op=True))
+        if not hasattr(self, "_copyback"):
+            self._copyback = []
+        for r in range(world):
+            if r != rank:
+                self._copyback.append((flat[r * n:(r + 1) * n], pieces[r]))
 
 
 class RcclExchange:
@@ -62,6 +85,15 @@ class RcclExchange:
 
     def finish(self):
         L.check(L.lib().vbnn_comm_finish(self.h))
+
+    def reduce_scatter(self, buf, n_per_rank):
+        assert buf.dtype == torch.float32 and buf.is_contiguous() and buf.numel() == n_per_rank * self.world
+        L.check(L.lib().vbnn_comm_reduce_scatter(self.h, C.c_void_p(buf.data_ptr()), n_per_rank))
+
+    def all_gather(self, buf):
+        nbytes = buf.numel() * buf.element_size()
+        assert buf.is_contiguous() and nbytes % self.world == 0
+        L.check(L.lib().vbnn_comm_all_gather(self.h, C.c_void_p(buf.data_ptr()), nbytes // self.world))
 
     def gather_u64(self, value):
         """Every rank's 64-bit word, exchanged over the communicator itself (bench.py: ranks_seen)."""
@@ -122,6 +154,23 @@ class P2PExchange:
 
     def finish(self):
         L.check(L.lib().vbnn_p2p_finish(self.h))
+
+    def _region(self, buf):
+        off = buf.data_ptr() - self._ptr
+        nbytes = buf.numel() * buf.element_size()
+        assert buf.is_contiguous() and off >= 0 and off % 4 == 0 and nbytes % 4 == 0 and off + nbytes <= self.arena.numel() * 4, \
+            "the region must lie in the exchange's arena (whole floats)"
+        return off // 4, nbytes // 4
+
+    def reduce_scatter(self, buf, n_per_rank):
+        off, n = self._region(buf)
+        assert buf.dtype == torch.float32 and n == n_per_rank * self.world
+        L.check(L.lib().vbnn_p2p_reduce_scatter(self.h, off, n_per_rank))
+
+    def all_gather(self, buf):
+        off, n = self._region(buf)
+        assert n % self.world == 0
+        L.check(L.lib().vbnn_p2p_all_gather(self.h, off, n // self.world))
 
     def gave_up(self):
         """Blocks until the exchange stream is idle; the epoch of a barrier that timed out waiting for a peer, or 0."""

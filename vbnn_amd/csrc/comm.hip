@@ -22,6 +22,7 @@ struct Rccl {
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -50,6 +51,7 @@ int bind_rccl() {
     VBNN_SYM(CommCount, "ncclCommCount")
     VBNN_SYM(AllReduce, "ncclAllReduce")
     VBNN_SYM(AllGather, "ncclAllGather")
+    VBNN_SYM(ReduceScatter, "ncclReduceScatter")
     VBNN_SYM(GetErrorString, "ncclGetErrorString")
 #undef VBNN_SYM
     g_rccl = r;
@@ -189,6 +191,31 @@ extern "C" int vbnn_comm_allgather_u64(vbnn_comm* c, const uint64_t* mine_dev, u
     VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
     VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
     VBNN_CHECK_NCCL(g_rccl.AllGather(mine_dev, all_dev, 1, ncclUint64, c->comm, c->stream));
+    c->pending += 1;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+// ---- the two halves of the all-reduce as calls of their own (the sharded-update exchange, include/vbnn_hip.h): in place, on the
+// exchange stream, ordered behind the compute stream like vbnn_allreduce_grads
+extern "C" int vbnn_comm_reduce_scatter(vbnn_comm* c, float* buf, int64_t n_per_rank) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(c && buf && n_per_rank > 0, "argument");
+    VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
+    VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    VBNN_CHECK_NCCL(g_rccl.ReduceScatter(buf, buf + (size_t)c->rank * (size_t)n_per_rank, (size_t)n_per_rank, ncclFloat32, ncclSum, c->comm, c->stream));
+    c->pending += 1;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+extern "C" int vbnn_comm_all_gather(vbnn_comm* c, void* buf, int64_t bytes_per_rank) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(c && buf && bytes_per_rank > 0, "argument");
+    VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
+    VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    char* b = static_cast<char*>(buf);
+    VBNN_CHECK_NCCL(g_rccl.AllGather(b + (size_t)c->rank * (size_t)bytes_per_rank, b, (size_t)bytes_per_rank, ncclInt8, c->comm, c->stream));
     c->pending += 1;
     return VBNN_OK;
     VBNN_API_END

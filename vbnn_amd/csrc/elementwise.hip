@@ -1172,3 +1172,62 @@ extern "C" int vbnn_cast_grads(vbnn_ctx* ctx, int to_bf16, const void* src, void
     return vbnn_check_launch("k_cast_grads");
     VBNN_API_END
 }
+
+// ---- the sharded-update exchange's two small device-side steps (include/vbnn_hip.h) -----------------------------------
+// (1) a layer's prior statistics from the per-rank statistics of its row slices: sums in RANK order, var_hat by the very
+// expression k_update_finish uses -- every rank computes the same four doubles from the same gathered parts.
+struct StatsCombineArgs { double* stats[8]; int n_layers, world; const double* parts; };
+__global__ void k_stats_combine(StatsCombineArgs a) {
+    const int l = threadIdx.x;
+    if (l >= a.n_layers) return;
+    double s0 = 0.0, s1 = 0.0, w = 0.0;
+    for (int r = 0; r < a.world; ++r) {
+        const double* p = a.parts + ((size_t)r * a.n_layers + l) * 4;
+        s0 += p[0]; s1 += p[1]; w += p[3];
+    }
+    double* st = a.stats[l];
+    st[0] = s0; st[1] = s1; st[2] = (1.0 / w) * s0; st[3] = w;
+}
+extern "C" int vbnn_stats_combine(vbnn_ctx* ctx, int n_layers, int world, const double* parts, double* const* stats) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && parts && stats && n_layers >= 1 && n_layers <= 8 && world >= 1, "argument (1..8 layers)");
+    StatsCombineArgs a{};
+    a.n_layers = n_layers; a.world = world; a.parts = parts;
+    for (int l = 0; l < n_layers; ++l) { VBNN_REQUIRE(stats[l], "null stats"); a.stats[l] = stats[l]; }
+    hipLaunchKernelGGL(k_stats_combine, dim3(1), dim3(64), 0, ctx->stream, a);
+    return vbnn_check_launch("k_stats_combine");
+    VBNN_API_END
+}
+
+// (2) the transposed copy of a packed operand (rows x ld_src -> cols x ld_dst, element type dtype): layers whose gradInput GEMM
+// wants transposed shadows rebuild them locally from the gathered mu_s / var_s (a row slice of a shadow is a COLUMN range of its
+// transpose: not something an all-gather can deliver). 64 x 64 tiles through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose_packed(const T* __restrict__ src, int64_t ld_src, int64_t rows, int64_t cols, T* dst, int64_t ld_dst) {
+    __shared__ T tile[64][65];
+    const int64_t tiles_c = (cols + 63) / 64;
+    const int64_t r0 = (blockIdx.x / tiles_c) * 64, c0 = (blockIdx.x % tiles_c) * 64;
+    for (int k = threadIdx.x; k < 4096; k += 256) {
+        const int rr = k >> 6, cc = k & 63;
+        tile[rr][cc] = (r0 + rr < rows && c0 + cc < cols) ? src[(r0 + rr) * ld_src + c0 + cc] : Elt<T>::to(0.f);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 4096; k += 256) {
+        const int cc = k >> 6, rr = k & 63;
+        if (c0 + cc < cols && r0 + rr < rows) dst[(c0 + cc) * ld_dst + r0 + rr] = tile[rr][cc];
+    }
+}
+extern "C" int vbnn_transpose_packed(vbnn_ctx* ctx, int dtype, const void* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst,
+                                     int64_t ld_dst) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "argument");
+    const int64_t tiles = ((rows + 63) / 64) * ((cols + 63) / 64);
+    VBNN_REQUIRE(tiles < (1ll << 31), "matrix too large");
+    if (dtype == VBNN_F32)
+        hipLaunchKernelGGL(k_transpose_packed<float>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (const float*)src, ld_src, rows, cols, (float*)dst, ld_dst);
+    else if (dtype == VBNN_BF16)
+        hipLaunchKernelGGL(k_transpose_packed<bf16_t>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (const bf16_t*)src, ld_src, rows, cols, (bf16_t*)dst, ld_dst);
+    else { vbnn_set_error("unsupported dtype %d", dtype); return VBNN_ERR_UNSUPPORTED; }
+    return vbnn_check_launch("k_transpose_packed");
+    VBNN_API_END
+}

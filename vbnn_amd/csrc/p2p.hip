@@ -275,6 +275,50 @@ extern "C" int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n) 
     VBNN_API_END
 }
 
+// ---- the two phases as calls of their own (the sharded-update exchange): equal chunks, rank r's at offset + r * n_per_rank.
+// reduce-scatter: barrier (every rank's region is complete) -> rank r sums chunk r of every rank's arena into its own ->
+// barrier (nobody still reads this rank's other chunks: they may be overwritten). all-gather: barrier (every rank's chunk is
+// complete) -> copy the peers' chunks -> barrier.
+extern "C" int vbnn_p2p_reduce_scatter(vbnn_p2p* p, size_t offset_floats, int64_t n_per_rank) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p && n_per_rank > 0 && offset_floats + (size_t)n_per_rank * (size_t)p->world <= p->arena_floats, "region outside the arena");
+    VBNN_REQUIRE(p->connected, "vbnn_p2p_connect first");
+    VBNN_CHECK_HIP(hipEventRecord(p->ready, p->ctx->stream));
+    VBNN_CHECK_HIP(hipStreamWaitEvent(p->stream, p->ready, 0));
+    p->pending += 1;
+    if (p->world == 1) return VBNN_OK;
+    const size_t c0 = offset_floats + (size_t)p->rank * (size_t)n_per_rank;
+    const int vec = (c0 % 4 == 0 && offset_floats % 4 == 0 && n_per_rank % 4 == 0) ? 1 : 0;
+    int st = p2p_barrier(p);
+    if (st != VBNN_OK) return st;
+    const unsigned nb = (unsigned)(((n_per_rank + 3) / 4 + 255) / 256 < 1024 ? ((n_per_rank + 3) / 4 + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_p2p_reduce_scatter, dim3(nb ? nb : 1), dim3(256), 0, p->stream, p->arenas, p->rank, p->world, c0, n_per_rank, vec, p->status);
+    st = p2p_barrier(p);
+    if (st != VBNN_OK) return st;
+    return vbnn_check_launch("vbnn_p2p_reduce_scatter");
+    VBNN_API_END
+}
+
+extern "C" int vbnn_p2p_all_gather(vbnn_p2p* p, size_t offset_floats, int64_t n_per_rank) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p && n_per_rank > 0 && offset_floats + (size_t)n_per_rank * (size_t)p->world <= p->arena_floats, "region outside the arena");
+    VBNN_REQUIRE(p->connected, "vbnn_p2p_connect first");
+    VBNN_CHECK_HIP(hipEventRecord(p->ready, p->ctx->stream));
+    VBNN_CHECK_HIP(hipStreamWaitEvent(p->stream, p->ready, 0));
+    p->pending += 1;
+    if (p->world == 1) return VBNN_OK;
+    const int vec = (offset_floats % 4 == 0 && n_per_rank % 4 == 0) ? 1 : 0;
+    int st = p2p_barrier(p);
+    if (st != VBNN_OK) return st;
+    const unsigned nb = (unsigned)(((n_per_rank + 3) / 4 + 255) / 256 < 256 ? ((n_per_rank + 3) / 4 + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_p2p_all_gather, dim3(nb ? nb : 1, p->world), dim3(256), 0, p->stream, p->arenas, p->rank, offset_floats,
+                       n_per_rank * (int64_t)p->world, n_per_rank, vec, p->status);
+    st = p2p_barrier(p);
+    if (st != VBNN_OK) return st;
+    return vbnn_check_launch("vbnn_p2p_all_gather");
+    VBNN_API_END
+}
+
 extern "C" int vbnn_p2p_finish(vbnn_p2p* p) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(p, "null p2p");

@@ -124,6 +124,15 @@ class FusedMLP:
         self.exchange_dtype = str(opt.get("exchange_dtype", "f32"))      # "bf16": the optional half-size exchange (_reduce)
         assert self.exchange_dtype in ("f32", "bf16")
         self._stage, self._staged = None, []
+        # opt.exchange_mode = "sharded" (or VBNN_EXCHANGE_MODE=sharded): the SHARDED-UPDATE exchange instead of north_star's
+        # all-reduce (partition.py): reduce-scatter of the likelihood gradients by layer rows, update() on this
+        # rank's rows only (Adam state + fp32 master rows sharded), all-gather of the operand shadows + prior statistics. An option
+        # beside the all-reduce, never its replacement: update() is then part of every step.
+        import os as _os
+        self.exchange_mode = str(opt.get("exchange_mode", _os.environ.get("VBNN_EXCHANGE_MODE", "")) or "allreduce")
+        assert self.exchange_mode in ("allreduce", "sharded")
+        self.sharded = self.reduce and self.exchange_mode == "sharded"
+        self._params_stale = False            # sharded: the fp32 means / lvars of OTHER ranks' rows are stale after an update
         self._dx_first_opt = opt.get("dx_first", None)      # None: decided from the layer sizes once they are known (below)
         self.fuse_kl = bool(opt.get("fuse_kl", True))
         # "nll": LogSoftMax + ClassNLLCriterion (mlp.lua:30-32); "mse": nn.MSECriterion on the final Linear's outputs
@@ -138,6 +147,15 @@ class FusedMLP:
         # what every host gets unless it asks for the A/B form (kl_in_update = False); fp32 epilogues read the fp32 parameters
         # and are exact either way, so they keep the total gradients in the arena.
         self.kl_in_update = bool(opt.get("kl_in_update", self.kl_from_shadows and self.fuse_kl and self.mode == "lrt"))
+        if self.sharded:
+            assert self.fuse_kl and self.mode == "lrt" and self.exchange_dtype == "f32" and not opt.get("overlap", False), \
+                "exchange_mode = sharded: the fused LRT engine, fp32 sums, one compute stream"
+            # bf16 only: there the step reads the parameters through the operand shadows alone (GEMM operands and the
+            # accGradParameters epilogue's sigma^2: vbnn_dw_args.var_s) -- which is what is gathered, at half the bytes of the
+            # gradients. The fp32 configuration's epilogue forms exp(lvars) from the fp32 master rows, which other ranks hold stale,
+            # and its "shadows" are as large as the gradients: nothing to gain there.
+            assert self.dtype == "bf16" and self.kl_from_shadows, "exchange_mode = sharded: the bf16 configuration (operand shadows)"
+            self.kl_in_update = True          # what is reduce-scattered is a pure sum of likelihood parts; the slice update adds the KL
         assert not self.kl_in_update or (self.fuse_kl and self.mode == "lrt"), "kl_in_update: the fused LRT engine"
         # optional second HIP stream (+ its own context, hence its own reduction scratch) for the accGradParameters
         # GEMMs. Measured on MI355X (wide config): 1.32 ms with, 1.29 ms without -- two 512-block GEMMs sharing the
@@ -172,13 +190,27 @@ class FusedMLP:
         # (vbnn_p2p_*, csrc/p2p.hip) instead of RCCL; that exchange owns the arena (an IPC-exportable allocation of the library's)
         import os
         self.exchange_kind = str(opt.get("exchange", os.environ.get("VBNN_EXCHANGE", "")) or "")
+        n_layers = len(hidden)
+        self._plan = partition.sharded_plan(lay, world_size) if self.sharded else None
+        arena_extra = None
         if self.reduce and self.exchange_kind == "p2p":
             assert self.exchange_dtype == "f32", "the p2p exchange sums fp32 arenas"
             from .comm import P2PExchange
-            self._exchange = P2PExchange(self.ctx, rank, world_size, n_g, process_group)
-            self.grads = self._exchange.arena
+            n_arena = (n_g + 3) // 4 * 4
+            if self.sharded:            # what the sharded exchange all-gathers lives in the peer-mapped arena too
+                n_arena += sum(2 * _Packed.floats(sizes[i + 1], sizes[i], self.tdt) for i in range(n_layers)) + 8 * world_size * n_layers
+            self._exchange = P2PExchange(self.ctx, rank, world_size, n_arena, process_group)
+            self.grads = self._exchange.arena[:n_g]
+            arena_extra = self._exchange.arena[(n_g + 3) // 4 * 4:]
         else:
             self.grads = torch.zeros(n_g, **f32)
+
+        def carve(n_floats):
+            nonlocal arena_extra
+            if arena_extra is None:
+                return None
+            piece, arena_extra = arena_extra[:n_floats], arena_extra[n_floats:]
+            return piece
 
         def take(span, shape):
             return self.grads[span[0]:span[0] + span[1]].view(*shape)
@@ -201,7 +233,9 @@ class FusedMLP:
             v.gradBias = take(lay[li]["bias"], (O,))
             v.bucket = self.grads[lay[li]["bucket"][0]:lay[li]["bucket"][1]]
             v.stats = torch.zeros(4, dtype=torch.float64, device=dev)
-            v.mu_s, v.var_s = _Packed(O, I, self.tdt, dev), _Packed(O, I, self.tdt, dev)
+            nf = _Packed.floats(O, I, self.tdt)
+            v.mu_s = _Packed(O, I, self.tdt, dev, storage=carve(nf) if self.sharded else None)
+            v.var_s = _Packed(O, I, self.tdt, dev, storage=carve(nf) if self.sharded else None)
             if li > 0:
                 v.muT_s, v.varT_s = _Packed(I, O, self.tdt, dev), _Packed(I, O, self.tdt, dev)
             else:
@@ -221,6 +255,13 @@ class FusedMLP:
             v.msg_late = self.grads[lay[li]["late"][0]:lay[li]["late"][1]]
         self.w3_s = _Packed(self.n_classes, H, self.tdt, dev)
         self.w3T_s = _Packed(H, self.n_classes, self.tdt, dev)
+        if self.sharded:
+            # every rank's statistics of its row slices, [world][layers][4] doubles, gathered after the slice update; and this
+            # rank's block of it as the in / out `stats` of the slice update (in: the whole layer's pre-update statistics)
+            st = carve(8 * world_size * n_layers)
+            self._stat_parts = (st.view(torch.float64) if st is not None else
+                                torch.zeros(4 * world_size * n_layers, dtype=torch.float64, device=dev)).view(world_size, n_layers, 4)
+            self._stat_parts.zero_()
         self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
         self._corr = torch.zeros(1, dtype=torch.int32, device=dev)
         self._lc = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -363,6 +404,8 @@ class FusedMLP:
     @_ordered
     def prepare(self):
         lib = L.lib()
+        if self._params_stale:                                # sharded update: fetch the other ranks' fp32 rows first
+            self.gather_parameters()
         if self.mode == "lrt":                                # one call: a sweep per layer + ONE finish kernel
             descs = (L.PrepDesc * len(self.vb))()
             for k, v in enumerate(self.vb):
@@ -727,13 +770,19 @@ class FusedMLP:
                         # mu GEMM still runs
                         d.part = 2
                         L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
-                        self._reduce(v.msg_early)
+                        if self.sharded:
+                            self._scatter(li, ("lv",))
+                        else:
+                            self._reduce(v.msg_early)
                         d.part = 1
                     L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
                 # the fused head already summed the last layer's g columns; ones-row layers got theirs from the GEMM
                 if not (fused_head and li == nl - 1) and not v.bias_from_dw:
                     L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
-                self._reduce(v.msg_late if self._early(v, lrt) else (self.bucket_tail if li == nl - 1 else v.bucket))
+                if self.sharded:
+                    self._scatter(li, ("mu", "small") if self._early(v, lrt) else ("lv", "mu", "small"))
+                else:
+                    self._reduce(v.msg_late if self._early(v, lrt) else (self.bucket_tail if li == nl - 1 else v.bucket))
                 if li > 0:
                     dx = self._dx_args(li, N)
                     with self._probed("updateGradInput", li):
@@ -828,6 +877,90 @@ class FusedMLP:
         self.exchange().allreduce(stage)
         self._staged.append((bucket, stage))
 
+    def _scatter(self, li, what):
+        """Sharded mode: layer li's messages (partition.sharded_plan): reduce-scatter of d/dlvars, of d/dmeans; the small all-reduce."""
+        if not self._exchange_now or self.skip_exchange:
+            return
+        p, ex, W = self._plan[li], self.exchange(), self.world
+        for key in what:
+            if key == "small":
+                s0, e0 = p["small"]
+                ex.allreduce(self.grads[s0:e0])
+            else:
+                off, per = p[key]
+                ex.reduce_scatter(self.grads[off:off + per * W], per)
+
+    def gather_parameters(self):
+        """Sharded mode: bring every rank's fp32 means / lvars rows to every rank (checkpoints, prepare(), tests) -- over the
+        out-of-band process group, on the host's schedule: not a part of the step."""
+        if not self.sharded or self.world == 1:
+            self._params_stale = False
+            return
+        import torch.distributed as dist
+        torch.cuda.synchronize(self.device)
+        for v in self.vb:
+            r0, nr = partition.layer_row_shard(v.O, self.world, self.rank)
+            for t in (v.means, v.lvars):
+                mine = t[r0:r0 + nr].cpu()
+                pieces = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(pieces, mine, group=self.pg)
+                for r, pc in enumerate(pieces):
+                    if r != self.rank:
+                        t[r * nr:(r + 1) * nr].copy_(pc)
+        self._params_stale = False
+
+    def _update_sharded(self, opt):
+        """mlp:update / VBLinear:update with the parameters SHARDED by layer rows: the reduce-scatter left this rank the summed
+        likelihood gradients of its rows; vbnn_update runs on those rows alone (+ the exact KL gradient, kl_add), then the new
+        operand shadows and the slices' prior statistics are all-gathered and every rank forms the layers' statistics from the
+        same gathered parts (vbnn_stats_combine). Biases and the final Linear: all-reduced gradients, replicated SGD."""
+        lib, h, W, R = L.lib(), self.ctx.h, self.world, self.rank
+        ex = self.exchange()
+        lr = float(opt["state"]["learningRate"])
+        st = self.__dict__.setdefault("_opt_state", {})
+        L.check(lib.vbnn_sgd_step(h, _p(self.weight3), _p(self.gradWeight3), self.weight3.numel(), lr))
+        L.check(lib.vbnn_sgd_step(h, _p(self.bias3), _p(self.gradBias3), self.bias3.numel(), lr))
+        n = len(self.vb)
+        descs = (L.UpdateDesc * n)()
+        mine = self._stat_parts[R]
+        for k, v in enumerate(self.vb):
+            L.check(lib.vbnn_sgd_step(h, _p(v.bias), _p(v.gradBias), v.O, lr))
+            r0, nr = partition.layer_row_shard(v.O, W, R)
+            mine[k].copy_(v.stats)                           # in: the WHOLE layer's pre-update statistics (var_hat of the KL terms)
+            cfgs = []
+            for key, cfg in (("mean", opt["meanState"]), ("var", opt["varState"])):
+                s = st.setdefault((v.layer_id, key), {"t": 0})
+                if "m" not in s:
+                    s["m"] = torch.zeros(nr, v.I, dtype=torch.float32, device=self.device)
+                    s["v"] = torch.zeros(nr, v.I, dtype=torch.float32, device=self.device)
+                s["t"] += 1
+                cfgs.append((s, L.AdamCfg(lr=float(cfg["learningRate"]), beta1=float(cfg.get("beta1", 0.9)),
+                                          beta2=float(cfg.get("beta2", 0.999)), eps=float(cfg.get("epsilon", 1e-8)),
+                                          lambda_=float(cfg.get("lambda", 1.0)), t=s["t"])))
+            (sm, cm), (sv, cv) = cfgs
+            descs[k] = L.UpdateDesc(means=_p(v.means[r0:r0 + nr]), lvars=_p(v.lvars[r0:r0 + nr]), O=nr, I=v.I,
+                                    mu_s=_p(v.mu_s.t[r0:r0 + nr]), var_s=_p(v.var_s.t[r0:r0 + nr]), ld_w=v.mu_s.ld,
+                                    muT_s=None, varT_s=None, ld_wT=0, stats=_p(mine[k]), grad_mu=_p(v.gradWeight[r0:r0 + nr]),
+                                    grad_lv=_p(v.gradSum[r0:r0 + nr]), m_mu=_p(sm["m"]), v_mu=_p(sm["v"]), m_lv=_p(sv["m"]),
+                                    v_lv=_p(sv["v"]), mu=cm, lv=cv, bias=None, grad_bias=None, lr_bias=lr, B=self.B,
+                                    log14=None, kl_add=1.0)
+        w3 = L.PackDesc(src=_p(self.weight3), rows=self.n_classes, cols=self.sizes[-1], ld_src=self.sizes[-1],
+                        dst=self.w3_s.ptr, ld_dst=self.w3_s.ld, dstT=self.w3T_s.ptr, ld_dstT=self.w3T_s.ld)
+        L.check(lib.vbnn_update(h, self.code, n, descs, C.byref(w3)))
+        # what the next forward reads, from every rank: the shadows (in place: rank r's rows are its contribution), the parts
+        for v in self.vb:
+            ex.all_gather(v.mu_s.t)
+            ex.all_gather(v.var_s.t)
+        ex.all_gather(self._stat_parts)
+        ex.finish()
+        ptrs = (C.c_void_p * n)(*[v.stats.data_ptr() for v in self.vb])
+        L.check(lib.vbnn_stats_combine(h, n, W, _p(self._stat_parts), ptrs))
+        for v in self.vb:
+            if v.muT_s is not None and getattr(v, "use_muT", True):       # transposed shadows: rebuilt locally from the gathered ones
+                L.check(lib.vbnn_transpose_packed(h, self.code, v.mu_s.ptr, v.mu_s.ld, v.O, v.I, v.muT_s.ptr, v.muT_s.ld))
+                L.check(lib.vbnn_transpose_packed(h, self.code, v.var_s.ptr, v.var_s.ld, v.O, v.I, v.varT_s.ptr, v.varT_s.ld))
+        self._params_stale = W > 1
+
     def exchange(self):
         if self._exchange is None:
             from .comm import make_exchange
@@ -917,6 +1050,9 @@ class FusedMLP:
         opt = opt or self.opt
         self.finish()
         self.check_exchange()                  # BEFORE a parameter is touched: an incomplete exchange must not reach them
+        if self.sharded:
+            assert not log, "the 14 logged series need whole-layer norms: not with the sharded update"
+            return self._update_sharded(opt)
         lib, h = L.lib(), self.ctx.h
         lr = float(opt["state"]["learningRate"])
         st = self.__dict__.setdefault("_opt_state", {})
@@ -975,6 +1111,8 @@ class FusedMLP:
 
     @_ordered
     def calc_lc(self, opt=None):                                         # mlp.lua:109-115, fresh statistics
+        if self._params_stale:
+            self.gather_parameters()
         lc = 0.0
         B = float((opt or self.opt).get("B", self.B))
         for v in self.vb:

@@ -83,10 +83,24 @@ def _opt_get(opt, key, default=None):
 class _Packed:
     """A GEMM-ready operand: rows x pad(cols) of dtype T, zero-initialised (pads stay zero)."""
 
-    def __init__(self, rows, cols, tdtype, device):
+    def __init__(self, rows, cols, tdtype, device, storage=None):
+        """storage: a flat fp32 device tensor to place the operand IN (the peer-mapped arena of the p2p exchange: what the
+        sharded-update exchange all-gathers must live there) instead of an allocation of its own; zeroed either way."""
         self.rows, self.cols = rows, cols
         self.ld = L.pad_ld(cols)
-        self.t = torch.zeros((rows, self.ld), dtype=tdtype, device=device)
+        if storage is None:
+            self.t = torch.zeros((rows, self.ld), dtype=tdtype, device=device)
+        else:
+            n = rows * self.ld * torch.empty(0, dtype=tdtype).element_size()
+            assert n % 4 == 0 and storage.dtype == torch.float32 and storage.numel() * 4 >= n and storage.is_contiguous()
+            self.t = storage[:n // 4].view(tdtype).view(rows, self.ld)
+            self.t.zero_()
+
+    @staticmethod
+    def floats(rows, cols, tdtype):
+        """fp32 words an operand of this shape occupies (rounded up to 4: 16-byte aligned regions)."""
+        n = rows * L.pad_ld(cols) * torch.empty(0, dtype=tdtype).element_size()
+        return (n // 4 + 3) // 4 * 4
 
     @property
     def ptr(self):

@@ -75,3 +75,50 @@ def exchange_step(arena, buckets, exchange):
     for s, e in buckets:
         exchange.allreduce(arena[s:e])
     exchange.finish()
+
+
+# ---- the SHARDED-UPDATE exchange (an option beside the all-reduce) -------------------------------
+# reduce-scatter the likelihood gradients by ROWS of each layer (rank r ends with the sums for output units
+# [r O / G, (r + 1) O / G): a contiguous range of the O x I tensors), rank r runs the update on those rows alone (Adam state and
+# fp32 master parameters sharded), all-gather the packed operand shadows (bf16 mu, sigma^2: 4 B per weight instead of the 8 B of
+# fp32 gradients an all-reduce's second half moves) + four doubles of prior statistics per layer. Biases and the final Linear
+# (a few KB) keep a plain all-reduce and a replicated update.
+def layer_row_shard(O, world, rank):
+    """Rows of an O x I parameter tensor owned by `rank`: (row0, n_rows). O must divide evenly."""
+    if O % world:
+        raise ValueError(f"{O} output units do not divide over {world} ranks (sharded-update exchange)")
+    n = O // world
+    return rank * n, n
+
+
+def sharded_plan(layers, world):
+    """Per VB layer of arena_layout's `layers`: the two reduce-scatter regions (offset, floats PER RANK) -- d/dlvars and d/dmeans,
+    each world x per_rank floats long -- and the small all-reduce message (start, end): the bias gradient, plus the final Linear's
+    gradients behind the last layer's. Issue order is the all-reduce's: last layer first, d/dlvars before d/dmeans."""
+    plan = []
+    for d in layers:
+        layer_row_shard(d["O"], world, 0)
+        per = d["O"] * d["I"] // world
+        plan.append({"lv": (d["lv"][0], per), "mu": (d["mu"][0], per), "small": (d["bias"][0], d["late"][1]), "rows": d["O"] // world})
+    return plan
+
+
+def sharded_exchange_grads(arena, plan, world, exchange):
+    """One step's gradient exchange in sharded mode, in issue order (what FusedMLP.run issues around the kernels)."""
+    for p in reversed(plan):
+        for key in ("lv", "mu"):
+            off, per = p[key]
+            exchange.reduce_scatter(arena[off:off + per * world], per)
+        s, e = p["small"]
+        exchange.allreduce(arena[s:e])
+    exchange.finish()
+
+
+def exchange_bytes(layers, final, world, shadow_bytes=2):
+    """Bytes each rank SENDS per step: (all-reduce of the whole arena, sharded-update exchange) -- ring / direct accounting alike
+    move (G - 1) / G of a buffer per phase. All-reduce: two phases over every fp32 gradient. Sharded: one phase over the fp32 O x I
+    gradients, one over the packed shadows (2 x shadow_bytes per weight), the small messages twice."""
+    f = (world - 1) / world
+    big = sum(2 * d["O"] * d["I"] for d in layers)
+    small = sum(d["O"] for d in layers) + final["weight"][1] + final["bias"][1]
+    return f * 2 * 4 * (big + small), f * (4 * big + 2 * shadow_bytes * big // 2 + 2 * 4 * small)
