@@ -124,6 +124,12 @@ int vbnn_fill_normal_hw(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, i
                         uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
                         float scale);
 
+/* Both forms of the contract's Box-Muller (include/vbnn_philox.h, vbnn_box_muller) on GIVEN Philox words x0[i], x1[i] (device
+ * arrays of n words): z_exact[2i], z_exact[2i + 1] = the bit-exact form (what the fp32 path and the oracle draw), z_hw[..] = the
+ * hardware-transcendental form the bf16 forward draws. A diagnostic for hosts and tests: it is how the hardware form's distance
+ * from the contract is pinned over ALL 2^24 radii and ALL 2^24 angles (tests/test_parity_gpu.py, tests/golden/normals_hw_error.json). */
+int vbnn_box_muller_forms(vbnn_ctx* ctx, const uint32_t* x0, const uint32_t* x1, float* z_exact, float* z_hw, int64_t n);
+
 /* VBLinear:compute_prior (VBLinear.lua:77-88). One fused sweep over means/lvars:
  *   stats[0] = sum(exp(lvars) + means^2)   (so var_hat = stats[0] / W, :86)
  *   stats[1] = sum(lvars)

@@ -36,6 +36,7 @@ int vbnn_fill_normal(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int6
 int vbnn_fill_normal_hw(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int64_t ld,
                      uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
                      float scale);
+int vbnn_box_muller_forms(vbnn_ctx* ctx, const uint32_t* x0, const uint32_t* x1, float* z_exact, float* z_hw, int64_t n);
 int vbnn_compute_prior(vbnn_ctx* ctx, const float* means, const float* lvars, int64_t W,
                        float* vars, float* stdv, float* mu_sqe, double* stats);
 int vbnn_wn_sample(vbnn_ctx* ctx, const float* means, const float* stdv, const float* lvars,

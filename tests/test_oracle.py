@@ -295,3 +295,22 @@ def test_committed_golden_vectors(oracle):
             np.testing.assert_allclose(om.gradWeight, gold[pre + "out_gradWeight"], rtol=1e-6, atol=1e-8)
             np.testing.assert_allclose(om.gradSum, gold[pre + "out_gradSum"], rtol=1e-6, atol=1e-8)
             assert abs(om.var_hat - float(gold[pre + "out_var_hat"])) <= 1e-12
+
+
+def test_numpy_philox_helper_is_the_contracts_generator(oracle):
+    """tests/_philox_np.py (the words behind a window of normals, for the hardware-form error model test): Random123's known answers,
+    the oracle's vbo_philox_raw on random counters, and float64 Box-Muller on its words against the oracle's normals."""
+    import json
+    from tests import _philox_np as P
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "philox_kat.json")))
+    for v in kat:
+        assert [int(w) for w in P.philox4x32_10(*v["ctr"], *v["key"])] == v["out"]
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        c = [int(v) for v in rng.integers(0, 2 ** 32, 4)]
+        k = [int(v) for v in rng.integers(0, 2 ** 32, 2)]
+        assert [int(v) for v in P.philox4x32_10(*c, *k)] == oracle.philox_raw(c, k)
+    x0, x1 = P.window_words(8, 64, 3, 2, 1, 5, 4096)
+    z0, z1, _ = P.ideal_box_muller(x0, x1)
+    want = oracle.fill_normal(8, 64, 3, 2, 1, 5, 4096)
+    assert np.abs(np.stack([z0, z1], -1).reshape(8, 64) - want).max() < 1e-6         # the contract's polynomial forms vs float64

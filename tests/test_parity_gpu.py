@@ -2,6 +2,8 @@
 inputs. Tolerances are stated per test. fp32 GEMM outputs: |d| <= 2e-6 * sum_k|a_k b_k| + 1e-7
 (fp32 MFMA is an exact fma chain; the K order inside a 16-wide step is permuted).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -76,6 +78,94 @@ def test_hardware_form_of_the_normals_stays_within_2e6_of_the_contract(nnmod, or
     assert abs(float(a.double().var() - b.double().var())) < 1e-6
     i = int(a.abs().argmax())
     assert abs(float(a.view(-1)[i] - b.view(-1)[i])) < 2e-6 and float(a.abs().max()) > 4.5
+
+
+def test_hardware_form_error_model_over_all_radii_all_angles_and_eight_windows(nnmod, oracle, tmp_path):
+    """the bf16 forward's normals (v_log / v_sqrt / v_sin / v_cos Box-Muller) against the contract, as an ERROR
+    MODEL rather than one window. With vbnn_box_muller_forms both forms are evaluated on GIVEN Philox words:
+      (A) ALL 2^24 radii (u1 = (k + 1) 2^-24, k = 0 .. 2^24 - 1: u1 -> 0 included) at the angles 0 and 1/8 turn;
+      (B) ALL 2^24 angles (every octant edge, every zero crossing) at the LARGEST radius (u1 = 2^-24, r = 5.768) and at r ~ 1;
+      (C) eight (layer, draw, row0) windows of 2^20 normals addressed through the counter, as the forward addresses them.
+    Bounds: |z_hw - z_contract| < 2e-6 everywhere, and both forms within 2.5e-6 of float64 Box-Muller on the same words (the
+    contract's own polynomial log / sincos are not exact either). The measured maxima are written to gpurun_out/ and held against
+    tests/golden/normals_hw_error.json (taken on an MI355X of this pool): a box whose transcendental microcode answers
+    differently by more than a quarter shows up here."""
+    import ctypes as C
+    import json
+    from vbnn_amd import _lib as L
+    from tests import _philox_np as P
+    lib, ctx = L.lib(), nnmod.Context.get()
+    n = 1 << 24
+    ks = torch.arange(n, device="cuda", dtype=torch.int64)
+
+    def forms(x0, x1):
+        x0, x1 = x0.to(torch.int32).contiguous(), x1.to(torch.int32).contiguous()
+        ze = torch.empty(2 * x0.numel(), dtype=torch.float32, device="cuda")
+        zh = torch.empty_like(ze)
+        L.check(lib.vbnn_box_muller_forms(ctx.h, C.c_void_p(x0.data_ptr()), C.c_void_p(x1.data_ptr()), C.c_void_p(ze.data_ptr()),
+                                          C.c_void_p(zh.data_ptr()), x0.numel()))
+        return ze.view(-1, 2).double(), zh.view(-1, 2).double()
+
+    def words(k):                                            # 24-bit field k -> the 32-bit word whose top 24 bits are k (as int32 bits)
+        w = (k << 8) & 0xFFFFFFFF
+        return torch.where(w >= (1 << 31), w - (1 << 32), w)
+
+    rec = {}
+    # (A) all radii, at angle 0 (z0 = r) and at 1/8 turn (z0 = z1 = r / sqrt 2)
+    u1 = (ks.double() + 1.0) * 2.0 ** -24
+    r_ideal = torch.sqrt(-2.0 * torch.log(u1))
+    for name, tk in (("angle_0", 0), ("angle_1_8", 1 << 21)):
+        ze, zh = forms(words(ks), words(torch.full_like(ks, tk)))
+        c, s_ = np.cos(2 * np.pi * tk / 2 ** 24), np.sin(2 * np.pi * tk / 2 ** 24)
+        ideal = torch.stack([r_ideal * c, r_ideal * s_], -1)
+        rec[f"all_radii_{name}"] = {"hw_vs_contract": float((zh - ze).abs().max()), "hw_vs_float64": float((zh - ideal).abs().max()),
+                                    "contract_vs_float64": float((ze - ideal).abs().max()),
+                                    "hw_vs_contract_at_u1_min": float((zh[0] - ze[0]).abs().max()), "r_max": float(ze[0].abs().max())}
+    # (B) all angles, at the largest radius (k = 0) and at r ~ 1 (u1 = exp(-1/2))
+    t = ks.double() * 2.0 ** -24
+    for name, rk in (("r_max", 0), ("r_1", int(round(2 ** 24 * np.exp(-0.5))) - 1)):
+        ze, zh = forms(words(torch.full_like(ks, rk)), words(ks))
+        r = float(np.sqrt(-2.0 * np.log((rk + 1) * 2.0 ** -24)))
+        ideal = torch.stack([r * torch.cos(2 * np.pi * t), r * torch.sin(2 * np.pi * t)], -1)
+        d = (zh - ze).abs().max(dim=1).values
+        edges = torch.arange(0, n, n // 8, device="cuda")                      # the octant edges themselves
+        rec[f"all_angles_{name}"] = {"r": r, "hw_vs_contract": float(d.max()), "hw_vs_float64": float((zh - ideal).abs().max()),
+                                     "contract_vs_float64": float((ze - ideal).abs().max()),
+                                     "hw_vs_contract_at_octant_edges": float(d[edges].max()),
+                                     "hw_vs_contract_within_4_steps_of_an_edge": float(torch.stack([d[(edges + o) % n] for o in range(-4, 5)]).max())}
+    # (C) eight windows through the counter
+    rows, cols = 512, 2048
+    a = torch.empty(rows, cols, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    for layer, draw, row0 in ((0, 1, 0), (1, 5, 4096), (2, 2, 1 << 20), (3, 1000, 28672), (4, 7, (1 << 31) - 512), (5, 1 << 30, 12345),
+                              (6, 3, 1 << 24), (7, (1 << 32) - 1, 65536)):
+        nnmod.fill_normal(a, SEED, L.STREAM_ZETA, layer, draw, row0=row0)
+        nnmod.fill_normal(b, SEED, L.STREAM_ZETA, layer, draw, row0=row0, hw=True)
+        x0, x1 = P.window_words(rows, cols, SEED, L.STREAM_ZETA, layer, draw, row0)
+        z0, z1, r = P.ideal_box_muller(x0, x1)
+        ideal = np.stack([z0, z1], -1).reshape(rows, cols)
+        ha, hb = host(a).astype(np.float64), host(b).astype(np.float64)
+        d = np.abs(hb - ha)
+        i = int(np.argmax(r))                                                  # the pair with the smallest u1 of the window
+        rec[f"window_layer{layer}_draw{draw}_row{row0}"] = {
+            "hw_vs_contract": float(d.max()), "hw_vs_float64": float(np.abs(hb - ideal).max()), "contract_vs_float64": float(np.abs(ha - ideal).max()),
+            "z_min": float(ha.min()), "z_max": float(ha.max()), "r_max_in_window": float(r.max()),
+            "hw_vs_contract_at_r_max": float(d.reshape(rows, cols // 2, 2)[i // (cols // 2), i % (cols // 2)].max()),
+            "mean_hw_minus_contract": float((hb - ha).mean())}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "normals_hw_error_measured.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    for name, v in rec.items():
+        assert v["hw_vs_contract"] < 2e-6, (name, v)
+        assert v["hw_vs_float64"] < 2.5e-6 and v["contract_vs_float64"] < 2.5e-6, (name, v)
+    gold_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "normals_hw_error.json")
+    if os.path.exists(gold_path):
+        gold = json.load(open(gold_path))
+        assert sorted(gold) == sorted(rec), "the recorded windows are not the measured ones: regenerate tests/golden/normals_hw_error.json"
+        for name, v in rec.items():
+            for k in ("hw_vs_contract", "hw_vs_float64"):
+                assert v[k] <= 1.25 * gold[name][k] + 1e-8, f"{name} {k}: {v[k]:.3e} measured, {gold[name][k]:.3e} recorded"
 
 
 # ------------------------------------------------------------------------------------------- prior / KL

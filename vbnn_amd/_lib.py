@@ -104,6 +104,7 @@ _SIGS = {
     "vbnn_buf_download": ([_vp, _vp, _vp, C.c_size_t], _i),
     "vbnn_fill_normal": ([_vp, _vp, _i64, _i64, _i64, _u64, _u32, _u32, _u32, _i64, _f], _i),
     "vbnn_fill_normal_hw": ([_vp, _vp, _i64, _i64, _i64, _u64, _u32, _u32, _u32, _i64, _f], _i),
+    "vbnn_box_muller_forms": ([_vp, _vp, _vp, _vp, _vp, _i64], _i),
     "vbnn_compute_prior": ([_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp], _i),
     "vbnn_wn_sample": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _u64, _u32, _u32], _i),
     "vbnn_pack": ([_vp, _i, _i, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64], _i),

@@ -53,6 +53,27 @@ extern "C" int vbnn_fill_normal_hw(vbnn_ctx* ctx, float* out, int64_t rows, int6
     VBNN_API_END
 }
 
+// Both forms of the contract's Box-Muller on GIVEN Philox words (include/vbnn_hip.h, vbnn_box_muller_forms): what lets a host pin the
+// hardware form's error against the bit-exact form exhaustively over either word (all 2^24 radii, all 2^24 angles) instead of on
+// whatever words a window of counters happens to hold.
+__global__ __launch_bounds__(256) void k_box_muller_forms(const uint32_t* __restrict__ x0, const uint32_t* __restrict__ x1, float* z_exact,
+                                                          float* z_hw, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float a, b, c, d;
+        vbnn_box_muller(x0[i], x1[i], &a, &b);
+        vbnn_box_muller_hw(x0[i], x1[i], &c, &d);
+        z_exact[2 * i] = a; z_exact[2 * i + 1] = b;
+        z_hw[2 * i] = c; z_hw[2 * i + 1] = d;
+    }
+}
+extern "C" int vbnn_box_muller_forms(vbnn_ctx* ctx, const uint32_t* x0, const uint32_t* x1, float* z_exact, float* z_hw, int64_t n) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(ctx && x0 && x1 && z_exact && z_hw && n > 0, "argument");
+    hipLaunchKernelGGL(k_box_muller_forms, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, x0, x1, z_exact, z_hw, n);
+    return vbnn_check_launch("k_box_muller_forms");
+    VBNN_API_END
+}
+
 // ---------------------------------------------------------------------------------- block reduce
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
