@@ -47,7 +47,10 @@ typedef struct vbnn_ctx vbnn_ctx;
 int vbnn_abi_version(void);
 const char* vbnn_last_error(void);
 
-/* test / A-B hook, PROCESS-wide (kernel selection is a property of the build under test, not of a context: set it
+/* test / A-B hook, PROCESS-wide: WHICH of the library's kernels computes a GEMM -- every setting computes the same results to
+ * rounding (the parity tests force each kernel through the same checks); nothing here changes what is computed. (r04: the keys
+ * that switched timing-only or never-selected forms -- fake noise, the K-split launches -- left the library with those forms:
+ * tools/lab/.) Kernel selection is a property of the build under test, not of a context: set it
  * before the contexts start launching, from one thread). VBNN_DEBUG_GEMM_KERNEL: 0 = pick by shape (default), 1 = always the general MFMA
  * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it, 3 = its two-pass 256 x 256 variant
  * whenever the shape and outputs allow it (whole tiles, the fused configuration). */
@@ -56,13 +59,10 @@ const char* vbnn_last_error(void);
                                       2 = interleaved with the MFMAs, 4 = 2 with skewed SIMD partners (gemm_v2.h) */
 #define VBNN_DEBUG_V2_TILE 2       /* pipelined kernel block tile: 0 = by shape (default), 256 = 256 x 128, 128 = 128 x 128,
                                       64 = 128 x 128 with a 2-stage ring, two workgroups per CU */
-#define VBNN_DEBUG_V2_SPLITK 3     /* pipelined kernel split-K (two K halves per 256 x 128 tile): -1 / 0 = off (default: it
-                                      lost inside the step), 1 = whenever possible */
 #define VBNN_DEBUG_V3_MIN_K 4      /* shortest K for which shape selection picks the two-pass 256 x 256 kernel (default 704) */
 #define VBNN_DEBUG_V2_PSPLIT 5     /* pipelined kernel pair split (the pair's two GEMMs in different workgroups, parameter
                                       gradients only): -1 = by shape (default), 0 = never, 1 = whenever possible */
-#define VBNN_DEBUG_V3_SPLIT 8      /* two-pass kernel's pair-split launches for few-tile parameter gradients: -1 = by shape (default), 0 = never, 1 = whenever possible; its half-height form without a K split: 2 = never, 3 = where it fills the CUs in one round (default), 4 = whenever the launch is taken */
-#define VBNN_DEBUG_FAKE_NOISE 7    /* TIMING ONLY, wrong results: 1 = the two-pass kernel's forward fold skips the Philox draw */
+#define VBNN_DEBUG_V3_SPLIT 8      /* two-pass kernel's pair-split half-height launch for few-tile parameter gradients: -1 = by shape (default), 0 = never, 1 = whenever possible */
 #define VBNN_DEBUG_V0 9            /* fp32 shapes of the launch-bound geometry: 1 = the latency kernel (gemm_v0.h; default), 0 = gemm_v1's 32 x 32 tile */
 #define VBNN_DEBUG_KMAJOR 6        /* K-major operands (gemm_v3.h AK / BK): 1 = use when the shape allows (default), 0 = never, 2 = gemm_v3 only */
 int vbnn_debug_set(int key, int value);

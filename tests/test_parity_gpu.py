@@ -556,24 +556,20 @@ def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidd
 @pytest.mark.parametrize("hidden,I0,N", [([256, 512], 100, 256),      # layer 1: ragged M with the ones row (101 of 256); layer 2: whole tiles
                                          ([512, 256], 260, 384),      # two M tiles, the second ragged (261 of 512); 3 K steps per half
                                          ([256, 256], 252, 128)])     # the ones row is the LAST row of the quad before a tile edge
-@pytest.mark.parametrize("form", ["ksplit", "half-height"])
-def test_split_two_pass_gradient_against_rounding_emulation(oracle, nnmod, hidden, I0, N, form):
-    """accGradParameters on gemm_v3's pair-split launches (forced: debug key 8), the launches of the 784 x 4096 gradient:
-    ragged output rows, the bias gradient from the ones row; `ksplit`: 256-row tiles, two K halves and their hand-off;
-    `half-height`: 128-row tiles, every workgroup walks all of K (what the wide configuration's input layer takes)."""
+def test_split_two_pass_gradient_against_rounding_emulation(oracle, nnmod, hidden, I0, N):
+    """accGradParameters on gemm_v3's pair-split HALF-HEIGHT launch (forced: debug key 8), the launch of the 784 x 4096 gradient:
+    128-row tiles, every workgroup walks all of K; ragged output rows, the bias gradient from the ones row."""
     from vbnn_amd import _lib as L
     L.check(L.lib().vbnn_debug_set(8, 1))
-    L.check(L.lib().vbnn_debug_set(8, 2 if form == "ksplit" else 4))
     try:
         eng = _check_bf16_step_against_emulation(oracle, hidden, I0, N, True)
         assert all(v.dw_km for v in eng.vb) and eng.vb[0].x_pad256
         g1 = eng.grads.clone()
-        for _ in range(3):                                   # arrival order of the K halves must not matter
+        for _ in range(3):
             eng.resetGradients(); eng.run(eng_x(eng, oracle, N, I0), eng_t(N))
             assert torch.equal(eng.grads, g1)
     finally:
         L.check(L.lib().vbnn_debug_set(8, -1))
-        L.check(L.lib().vbnn_debug_set(8, 3))
 
 
 def eng_x(eng, oracle, N, I0):
@@ -697,22 +693,20 @@ def _filled(nnmod, rows, cols, stream, layer, draw, row0):
     return t
 
 
-@pytest.fixture(params=[(1, 0, -1, 0), (2, 256, 0, 0), (2, 128, 0, 0), (2, 64, 0, 0), (3, 0, -1, -1), (2, 256, 1, 0), (2, 256, 0, 1)],
+@pytest.fixture(params=[(1, 0, 0), (2, 256, 0), (2, 128, 0), (2, 64, 0), (3, 0, -1), (2, 256, 1)],
                 ids=["general-kernel", "pipelined-256x128", "pipelined-128x128", "pipelined-128x128-pairs",
-                     "two-pass-256x256", "pipelined-256x128-splitK", "pipelined-256x128-pairsplit"])
+                     "two-pass-256x256", "pipelined-256x128-pairsplit"])
 def gemm_kernel(request, nnmod):
-    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in its block tiles, with split-K and with the pair
-    split / gemm_v3.h), whatever the shape heuristics say."""
+    """Run a bf16 test once per GEMM kernel (gemm_v1.h / gemm_v2.h in its block tiles and with the pair split / gemm_v3.h),
+    whatever the shape heuristics say."""
     from vbnn_amd import _lib as L
-    kernel, tile, split, psplit = request.param
+    kernel, tile, psplit = request.param
     L.check(L.lib().vbnn_debug_set(0, kernel))
     L.check(L.lib().vbnn_debug_set(2, tile))
-    L.check(L.lib().vbnn_debug_set(3, split))
     L.check(L.lib().vbnn_debug_set(5, psplit))
     yield request.param
     L.check(L.lib().vbnn_debug_set(0, 0))
     L.check(L.lib().vbnn_debug_set(2, 0))
-    L.check(L.lib().vbnn_debug_set(3, -1))
     L.check(L.lib().vbnn_debug_set(5, -1))
 
 

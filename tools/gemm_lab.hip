@@ -9,11 +9,11 @@
 #include <cstdarg>
 #include <vector>
 #include <algorithm>
-#include "../vbnn_amd/csrc/common.h"
+#include "lab/common.h"
 void vbnn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 int vbnn_cu_count() { return 256; }
-#include "../vbnn_amd/csrc/gemm_v2.h"
-#include "../vbnn_amd/csrc/gemm_v3.h"
+#include "lab/gemm_v2.h"
+#include "lab/gemm_v3.h"
 
 struct EpiSum {          // keeps both accumulators live with one 16-byte store per four outputs
     typedef bf16_t elem_t;

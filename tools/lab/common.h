@@ -16,20 +16,18 @@
 // them), so the fp32 path -- held sample for sample against the oracle -- keeps the exact form, and the bf16 path, held
 // against rounding-point emulation at bf16 tolerances, takes this one: the draw was 23 us of a 4096 x 4096 forward launch.
 #if defined(__HIPCC__)
-// Box-Muller on two Philox words, hardware form (the words' meaning is vbnn_box_muller's, include/vbnn_philox.h)
-__device__ __forceinline__ void vbnn_box_muller_hw(uint32_t x0, uint32_t x1, float* z0, float* z1) {
-    const float u1 = (float)((x0 >> 8) + 1u) * 5.96046448e-8f;          // (0, 1], as vbnn_box_muller
-    const float t = (float)(x1 >> 8) * 5.96046448e-8f;                  // the angle in revolutions, [0, 1)
-    const float rr = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), ln = ln 2 . log2
-    *z0 = rr * __builtin_amdgcn_cosf(t);
-    *z1 = rr * __builtin_amdgcn_sinf(t);
-}
 __device__ __forceinline__ vbnn_f32x4 vbnn_normal4_hw(uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, uint32_t row,
                                                       uint32_t quad) {
     const vbnn_u32x4 u = vbnn_philox4x32_10(quad, row, draw, (layer << 8) | stream, (uint32_t)seed, (uint32_t)(seed >> 32));
     vbnn_f32x4 z;
-    vbnn_box_muller_hw(u.v[0], u.v[1], &z.v[0], &z.v[1]);
-    vbnn_box_muller_hw(u.v[2], u.v[3], &z.v[2], &z.v[3]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = (float)((u.v[2 * p] >> 8) + 1u) * 5.96046448e-8f;          // (0, 1], as vbnn_box_muller
+        const float t = (float)(u.v[2 * p + 1] >> 8) * 5.96046448e-8f;              // the angle in revolutions, [0, 1)
+        const float rr = __builtin_amdgcn_sqrtf(-1.38629436f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), ln = ln 2 . log2
+        z.v[2 * p] = rr * __builtin_amdgcn_cosf(t);
+        z.v[2 * p + 1] = rr * __builtin_amdgcn_sinf(t);
+    }
     return z;
 }
 #endif
@@ -56,11 +54,13 @@ struct vbnn_ctx {
     bool own_stream;
     double* scratch;       // device scratch for block partial sums (prior / KL reductions)
     size_t scratch_doubles;
+    float* park;           // gemm_v3's parking tiles (pass 1 of a GEMM pair), grown on demand
+    size_t park_bytes;
     unsigned* counters;    // arrival tickets of the in-launch second stages (vbnn_last_arriver); zero between launches
     int cu_budget = 0;     // > 0: the stream is CU-masked to this many compute units (vbnn_ctx_create_cu_budget)
 };
 // ticket slots
-constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TILES = 16, VBNN_CNT_TILES_MAX = 1008, VBNN_CNT_TOTAL = 1024;   // [16, 1024): one ticket per column tile of the head's in-launch finish
+constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TILES = 16, VBNN_CNT_TILES_MAX = 1008, VBNN_CNT_TOTAL = 1024;   // [16, 1024): one ticket per split-K tile
 
 void vbnn_set_error(const char* fmt, ...);
 
@@ -71,17 +71,9 @@ struct vbnn_per_device_flag {
     bool done[VBNN_MAX_DEVICES] = {};
     bool& operator[](int device) { return done[(device >= 0 && device < VBNN_MAX_DEVICES) ? device : 0]; }
 };
-// compute units the shape heuristics plan for: the CU budget of the context whose API call is running on this thread
-// (vbnn_cu_scope, a thread-local: entered by the entry points that pick a kernel by shape), else the device's (all GPUs of a
-// node are one model; read once from the current device instead of assuming MI355X's 256)
+// compute units of the device the shape heuristics plan for (all GPUs of a node are one model): read once from the
+// current device instead of assuming MI355X's 256
 int vbnn_cu_count();
-struct vbnn_cu_scope {
-    int prev;
-    explicit vbnn_cu_scope(const vbnn_ctx* c);
-    ~vbnn_cu_scope();
-    vbnn_cu_scope(const vbnn_cu_scope&) = delete;
-    vbnn_cu_scope& operator=(const vbnn_cu_scope&) = delete;
-};
 
 #define VBNN_CHECK_HIP(expr)                                                             \
     do {                                                                                 \

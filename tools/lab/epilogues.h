@@ -33,7 +33,9 @@
 // DX: 2 x . acc2; DW: stores the finished d/dlvars and returns 0), and the final epilogue calls
 //     Pre pre = epi.load_folded(um, un, ln);   epi.apply_folded(um, un, ln, acc, pre, t1, t2)
 // on the single accumulator (`side` = 0). Nothing is parked between the passes. The sums are the same up to fp32
-// association (the term enters the accumulation chain first instead of last).
+// association (the term enters the accumulation chain first instead of last). A functor with PARK = true (FWD: the
+// term needs a Philox block per quad, and 32 of those beside 128 live accumulators spill) instead has the kernel park
+// the raw acc2 quads in a scratch tile, folds only the bias, and gets acc2 back as `side` in apply_folded.
 #pragma once
 #include "common.h"
 
@@ -63,13 +65,6 @@ struct EpiFwd {
     T* h; T* h2; int64_t ld_h;
     T* hT; T* h2T; int64_t ld_hT;
     int O, N;
-    // optional (gemm_v3.h only, the LAST VB layer below the fused classifier head, mlp.lua:29): the final nn.Linear's logits are
-    // formed HERE, from the output tile as it stands in the accumulators -- each wave's 128 m x 64 n of relu(y), rounded to the
-    // operand type exactly as `h` is stored, times the matching 128 columns of the packed final weight (C <= 16 rows): one
-    // [16 classes] x [64 n] partial per wave into head_slots[2 tile_m + wave row][N][16] (fp32, a FIXED slot: no atomics, the
-    // head sums the slots in order). The head's forward then never re-reads h (33 MB at 4096 x 4096).
-    const T* head_w3 = nullptr; int64_t head_ld_w = 0; int head_C = 0; float* head_slots = nullptr;
-    static constexpr bool HEAD = sizeof(T) == 2;
 
     static constexpr bool SPLITTABLE = false;     // every output needs both GEMMs of the pair
     static constexpr bool EDGE_FAST = false;      // ragged wave tiles take the guarded form
@@ -218,7 +213,8 @@ struct EpiFwd {
     }
 
     // ---- fold protocol (LRT only: acc2 = v)
-    // the noise term b + sqrt(v) z (and r) is formed between the passes
+#ifndef VBNN_FWD_PARK           // default: the noise term b + sqrt(v) z (and r) is formed between the passes
+    static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 1;          // m-blocks per batch of fold loads (only the bias here)
     static constexpr int FOLD_SERIAL = 1;         // a Philox block per quad: at most this many in flight (0 = no limit; 2 spills 24 registers and is no faster)
     // FOLD_STAGE: the fold's own output (r, N x O in the operand type) leaves through a per-wave LDS tile as whole
@@ -231,7 +227,13 @@ struct EpiFwd {
     __host__ __device__ __forceinline__ const float* fold_bias_ptr() const { return bias; }   // per-m addend of the fold, or NULL
     __device__ __forceinline__ bool fold_st_stream() const { return h2 != nullptr; }          // r of a layer with a VB layer above it: read half a step later
     __device__ __forceinline__ f32x4 fold_s(int um, int un, const Lane& ln, f32x4 v, const f32x4& b4, float (&rv)[4]) const {
-        const vbnn_f32x4 z = normal4(seed, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        vbnn_f32x4 z;
+        if (noise == 2) {                         // A/B only (vbnn_debug_set key 7): what the draw itself costs
+            const float f = (float)((um + ln.ml + un + ln.nl) & 7) * 0.25f - 0.875f;
+            z.v[0] = f; z.v[1] = -f; z.v[2] = 0.5f * f; z.v[3] = -0.5f * f;
+        } else {
+            z = normal4(seed, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        }
         f32x4 out;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -251,7 +253,13 @@ struct EpiFwd {
         return p;
     }
     __device__ __forceinline__ f32x4 fold(int um, int un, const Lane& ln, f32x4 v, const FPre& fp) const {
-        const vbnn_f32x4 z = normal4(seed, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        vbnn_f32x4 z;
+        if (noise == 2) {                         // A/B only (vbnn_debug_set key 7): what the draw itself costs
+            const float f = (float)((um + ln.ml + un + ln.nl) & 7) * 0.25f - 0.875f;
+            z.v[0] = f; z.v[1] = -f; z.v[2] = 0.5f * f; z.v[3] = -0.5f * f;
+        } else {
+            z = normal4(seed, layer, draw, (uint32_t)(row0 + un + ln.nl), (uint32_t)((um + ln.ml) >> 2));
+        }
         f32x4 out;
         float rv[4];
 #pragma unroll
@@ -278,6 +286,27 @@ struct EpiFwd {
         store4_out<T>(h + ub, ln.oh, t1[0], t1[1], t1[2], t1[3]);
         if (h2) store4_out<T>(h2 + ub, ln.oh, t2[0], t2[1], t2[2], t2[3]);
     }
+#else
+    // -DVBNN_FWD_PARK (A/B only): the kernel parks the raw variance tile in a scratch tile, the accumulator continues
+    // from the bias, the noise is applied in the final epilogue (+128 MB of L2/MALL traffic per launch)
+    static constexpr bool PARK = true;
+    static constexpr int FOLD_BATCH = 1;
+    static constexpr int FOLD_SERIAL = 0;
+    static constexpr int FOLD_STAGE = 0;
+    struct FPre { f32x4 b; };
+    __device__ __forceinline__ FPre fold_load(int um, int un, const Lane& ln) const {
+        (void)un;
+        FPre p;
+        p.b = bias ? *reinterpret_cast<const f32x4*>(bias + um + ln.ml) : f32x4{0.f, 0.f, 0.f, 0.f};
+        return p;
+    }
+    __device__ __forceinline__ f32x4 fold(int, int, const Lane&, f32x4, const FPre& fp) const { return fp.b; }
+    __device__ __forceinline__ Pre load_folded(int, int, const Lane&) const { return Pre{f32x4{0.f, 0.f, 0.f, 0.f}}; }
+    __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4 v, const Pre& pre, float (&t1)[4],
+                                                 float (&t2)[4]) const {
+        apply_fast(um, un, ln, a, v, pre, t1, t2);           // a = m + b already: pre.b is 0
+    }
+#endif
 };
 
 // ---- DX: M = input units i, N = minibatch rows n ------------------------------------------------
@@ -298,7 +327,6 @@ struct EpiDx {
 
     static constexpr bool SPLITTABLE = false;
     static constexpr bool EDGE_FAST = false;
-    static constexpr bool HEAD = false;
     __device__ __forceinline__ void bind_draw() {}                 // (no noise in gradInput: r comes from the forward)
     __host__ __device__ __forceinline__ bool has_draw_dev() const { return false; }
     __device__ __forceinline__ void edge_row(int, float) const {}
@@ -384,6 +412,7 @@ struct EpiDx {
     }
 
     // ---- fold protocol (LRT only: acc2 = gv sigma^2): the accumulator continues from 2 x . acc2
+    static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 8;          // all 32 quads' x loads (64 registers) in flight together
     static constexpr int FOLD_SERIAL = 0;
     static constexpr int FOLD_STAGE = 0;
@@ -435,7 +464,6 @@ struct EpiDw {
     // what depends on that; 0 = both accumulators, as ever.
     int part = 0;
     static constexpr bool SPLITTABLE = true;
-    static constexpr bool HEAD = false;
     __device__ __forceinline__ void set_part(int p) { part = p; }
     __device__ __forceinline__ void bind_draw() { if (draw_dev) draw += *draw_dev; }
     __host__ __device__ __forceinline__ bool has_draw_dev() const { return draw_dev != nullptr; }
@@ -587,6 +615,7 @@ struct EpiDw {
 
     // ---- fold protocol: the two outputs depend on one accumulator each, so d/dlvars is FINISHED between the passes
     // (its stores drain under the second pass) and the second pass starts from zero
+    static constexpr bool PARK = false;
     static constexpr int FOLD_BATCH = 8;          // all 32 quads' sigma^2 loads (64 registers) in flight together
     static constexpr int FOLD_SERIAL = 0;
     // FOLD_STAGE 2: the fold's output (d/dlvars, fp32 O x I) leaves through a per-wave LDS tile as whole 256-byte row

@@ -40,14 +40,37 @@ constexpr int V2_B_BYTES = V2_BN * V2_BK * 2;           // 16384
 constexpr int v2_a_bytes(int WM) { return 64 * WM * V2_BK * 2; }
 constexpr int v2_stage(int WM) { return v2_a_bytes(WM) + V2_B_BYTES; }
 // LDS per workgroup: the ring, or the epilogue's 18 KiB-per-wave staging if that is larger (2 stages, 4 waves)
-constexpr int v2_lds(int WM, int ST) { return (v2_stage(WM) * ST > 2 * WM * 18432 ? v2_stage(WM) * ST : 2 * WM * 18432) + 16; }   // 147456 / 98304 / 73728 (+ 16 spare)
+constexpr int v2_lds(int WM, int ST) { return (v2_stage(WM) * ST > 2 * WM * 18432 ? v2_stage(WM) * ST : 2 * WM * 18432) + 16; }   // 147456 / 98304 / 73728, + the split-K flag word
+
+// Diagnostic stamps (tools/gemm_lab.hip builds with -DV2_DIAG; the library never does): per-wave cycle
+// sums of the segments of schedule 0, written to a buffer of their own, never to an output.
+#ifdef V2_DIAG
+__device__ unsigned long long* g_v2_diag = nullptr;
+#define V2_STAMP_DECL unsigned long long v2_t[5] = {0, 0, 0, 0, 0}, v2_sum[4] = {0, 0, 0, 0};
+#define V2_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v2_t[i])::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if ((i) > 0) v2_sum[(i)-1] += v2_t[i] - v2_t[(i)-1];                                          \
+    } while (0)
+#define V2_STAMP_FLUSH                                                                                \
+    if (g_v2_diag && lane == 0) {                                                                     \
+        for (int k = 0; k < 4; ++k) g_v2_diag[((size_t)blockIdx.x * NW + wave) * 4 + k] = v2_sum[k];  \
+    }
+#else
+#define V2_STAMP_DECL
+#define V2_STAMP(i)
+#define V2_STAMP_FLUSH
+#endif
 
 // DMA schedule: 0 = burst after the barrier; 2 = interleaved with the MFMAs; 4 = 2 with the SIMD partners' DMA slots
 // skewed (measured: no better than 2); -1 = auto: 2 for the 8-wave 256 x 128 tile (+8 % over 0), 0 for the 4-wave
 // 128 x 128 tile (one wave per SIMD has no partner to cover an interleaved DMA issue: 0 is 8 % faster there).
-inline int g_v2_sched = -1;
-inline int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
-inline int g_v2_psplit = -1;      // pair split of the 256 x 128 tiling: -1 by shape, 0 never, 1 whenever the functor allows (key 5)
+static int g_v2_sched = -1;
+static int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
+static int g_v2_split = -1;       // split-K of the 256 x 128 tiling: -1 / 0 off, 1 whenever possible (key 3)
+static int g_v2_psplit = -1;      // pair split of the 256 x 128 tiling: -1 by shape, 0 never, 1 whenever the functor allows (key 5)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -89,7 +112,8 @@ __device__ __forceinline__ void v2_lds_barrier() { asm volatile("s_waitcnt lgkmc
 template <bool DUAL, int SCHED, int WM, int ST, class Epi, bool KM = false>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                           const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
-                                                          int M, int N, int nk, int tiles_m, int tiles_n, int psplit, Epi epi_in) {
+                                                          int M, int N, int nk, int tiles_m, int tiles_n, int ksplit, float* exch,
+                                                          unsigned* tickets, int psplit, Epi epi_in) {
     constexpr int NW = 2 * WM;                 // waves per workgroup
     constexpr int BM = 64 * WM;
     constexpr int A_BYTES = v2_a_bytes(WM), STAGE = v2_stage(WM);
@@ -107,7 +131,10 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     // the tile list; inside it tiles are walked in 4 (M) x 8 (N) groups so the ~32 blocks running
     // together on an XCD share 4 A panels and 8 B panels in its L2 (measured hit rate 81 % = the ideal
     // 1 - 12/64 of that grouping).
-    const int nblk = tiles_m * tiles_n * ((!DUAL && psplit) ? 2 : 1);
+    // Split-K (ksplit = 2: outputs too few to give every CU a tile, K long): the grid is tiles x 2, a tile's two
+    // K halves sit on neighbouring remapped ids (same XCD), and the half that finishes LAST adds the other's partial
+    // tile and runs the epilogue (see the hand-off before the epilogue).
+    const int nblk = tiles_m * tiles_n * ksplit * ((!DUAL && psplit) ? 2 : 1);
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
@@ -124,6 +151,11 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         epi.set_part(1 + part);
         if (part) { A = A2; B = B2; }
     }
+    const int kslice = ksplit > 1 ? (bid & 1) : 0;
+    if (ksplit > 1) bid >>= 1;
+    const int tile_id = bid;
+    const int kt0 = kslice * (nk / 2);                    // first K step of this block
+    if (ksplit > 1) nk = kslice ? nk - nk / 2 : nk / 2;   // K steps of this block
     int tm, tn;
     {
         constexpr int GM = 4, GN = 8;
@@ -196,16 +228,22 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     auto issue_one = [&](int u, auto pair_c, auto idx_c) {      // DMA number IDX (0..AG-1: A groups, then B groups) of tile u
         constexpr int P = decltype(pair_c)::value;
         constexpr int IDX = decltype(idx_c)::value;
-        const int64_t kstep = (int64_t)(DUAL ? (u >> 1) : u) * V2_BK;
+#ifdef V3_LAB_KWRAP     // tools/gemm_lab.hip only: every operand line an L2 hit (timing only, wrong results)
+        const int64_t kstep = (int64_t)((kt0 + (DUAL ? (u >> 1) : u)) & (V3_LAB_KWRAP - 1)) * V2_BK;
+#else
+        const int64_t kstep = (int64_t)(kt0 + (DUAL ? (u >> 1) : u)) * V2_BK;
+#endif
         const int64_t koff = KM ? kstep * (IDX < AG ? lda : ldb) : kstep;
         unsigned char* base = lds + (u % ST) * STAGE;
 #if defined(__HIP_DEVICE_COMPILE__)
         const int dma_so = __builtin_amdgcn_readfirstlane((int)(koff * 2));
         if constexpr (IDX < AG)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_ra[P], (lptr_t)(base + (wave + NW * IDX) * 1024), 16, dma_avo[IDX], dma_so, 0, 0);
+#ifndef V2_LAB_SKIP_B      // tools/gemm_lab.hip only: time the loop with a third of the DMA traffic removed (wrong results)
         else if constexpr (IDX < G)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rb[P], (lptr_t)(base + A_BYTES + (wave + NW * (IDX - AG)) * 1024), 16,
                                                      dma_bvo[IDX - AG], dma_so, 0, 0);
+#endif
 #else
         if constexpr (IDX < AG)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[P][IDX] + koff), (lptr_t)(base + (wave + NW * IDX) * 1024), 16, 0, 0);
@@ -234,9 +272,11 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         if constexpr (IDX < AG)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_ra[P], (lptr_t)(lds + la_stage + IDX * (NW * 1024) + wave * 1024), 16,
                                                      dma_avo[IDX], la_ka, 0, 0);
+#ifndef V2_LAB_SKIP_B
         else if constexpr (IDX < G)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rb[P], (lptr_t)(lds + la_stage + (A_BYTES + (IDX - AG) * (NW * 1024)) + wave * 1024),
                                                      16, dma_bvo[IDX - AG], la_kb, 0, 0);
+#endif
 #endif
     };
 
@@ -312,6 +352,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     // instead of both stalling together.
     const bool late = (WM == 4) && (__builtin_amdgcn_readfirstlane(wave) >= 4);
     (void)late;
+    V2_STAMP_DECL
 
     // ---- prologue: ST - 1 tiles in flight
     issue(0, c0);
@@ -322,7 +363,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     constexpr int LA = ST - 1;
     la_stage = (unsigned)(LA % ST) * STAGE;
     {
-        const int kidx = DUAL ? (LA >> 1) : LA;
+        const int kidx = kt0 + (DUAL ? (LA >> 1) : LA);
         la_ka = 2 * kidx * V2_BK * (KM ? (int)lda : 1);
         la_kb = 2 * kidx * V2_BK * (KM ? (int)ldb : 1);
     }
@@ -331,8 +372,21 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     auto step = [&](int u, auto pair_c, auto next_c, f32x4 (&acc)[4][4], auto always_c) {
         constexpr bool ALWAYS = decltype(always_c)::value;
         auto la_c = std::conditional_t<ST == 3, decltype(pair_c), decltype(next_c)>();
+        V2_STAMP(0);
+#if defined(V2_DIAG) || defined(V2_LAB_SKIP_B)      // lab builds: the wait and the barrier apart, a stamp between them
+#ifdef V2_LAB_SKIP_B
+        if (u + 1 < U) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#else
+        if (ST == 3 && (ALWAYS || u + 1 < U)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+#endif
+        else                       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        V2_STAMP(1);                                     // [0->1] waiting for this wave's DMAs
+        __builtin_amdgcn_s_barrier();
+        V2_STAMP(2);                                     // [1->2] barrier
+#else
         if (ST == 3 && (ALWAYS || u + 1 < U)) v2_wait_barrier<G>();   // tile u + 1's DMAs may stay in flight
         else                                  v2_wait_barrier<0>();
+#endif
         const bool more = ALWAYS ? true : (u + LA < U);
         if (SCHED == 0 && more) {
             issue_one_at(la_c, std::integral_constant<int, 0>()); issue_one_at(la_c, std::integral_constant<int, 1>());
@@ -340,6 +394,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
             issue_one_at(la_c, std::integral_constant<int, 4>()); issue_one_at(la_c, std::integral_constant<int, 5>());
             issue_one_at(la_c, std::integral_constant<int, 6>()); issue_one_at(la_c, std::integral_constant<int, 7>());
         }
+        V2_STAMP(3);                                     // [2->3] issuing the DMAs (schedule 0)
         const unsigned char* stage = lds + (u % ST) * STAGE;
         bf16x8 paf[4], pbf[4];                           // (K-major) the first k-half's fragments: kept out of the second's reads
 #pragma unroll
@@ -392,6 +447,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
                 }
             }
         }
+        V2_STAMP(4);                                     // [3->4] 16 ds_read_b128 + 32 MFMA
         la_stage = la_stage == (unsigned)(ST - 1) * STAGE ? 0u : la_stage + STAGE;       // tile u + 1 + LA
         if constexpr (!DUAL || decltype(la_c)::value == 1) { la_ka += la_dka; la_kb += la_dkb; }
     };
@@ -404,6 +460,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         for (; u + LA < U; ++u) step(u, c0, c0, acc1, std::true_type());
         for (; u < U; ++u) step(u, c0, c0, acc1, std::false_type());
     }
+    V2_STAMP_FLUSH
 
     // ---- epilogue. The ring is idle now: each wave re-lays its 64 x 64 accumulator tile through a private
     // 18 KiB LDS region from the MFMA layout (n = lane & 15, 4 m per lane-group) into rows of n, so that one
@@ -432,6 +489,45 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     else {
 #pragma unroll
         for (int p = 0; p < 16; ++p) r2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (ksplit > 1) {
+        // ---- split-K hand-off (cdna_hip_programming.md Guideline 16 R1 in its ticket form; vbnn_last_arriver's
+        // protocol with 16-byte write-through stores, so no release fence): BOTH halves store their partial tile (row
+        // layout, thread-private slots), drain, and take a ticket; ticket 0 is finished; ticket 1 acquires, adds the
+        // other half's partial (a + b is commutative: the result does not depend on which half came last) and runs
+        // the epilogue. Nobody waits for anybody. (Measured on the 784 x 4096 gradient: 92 us; letting only ticket 0
+        // store and ticket 1 wait for its flag halves the traffic but serialises store and load: 100 us.)
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        f32x4* mine = reinterpret_cast<f32x4*>(exch) + ((size_t)(tile_id * 2 + kslice) * 32) * (64 * NW);
+        f32x4* other = reinterpret_cast<f32x4*>(exch) + ((size_t)(tile_id * 2 + (kslice ^ 1)) * 32) * (64 * NW);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 32 * 64 * NW * 16, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, r1[p]), rs, (p * 64 * NW + tid) * 16, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, r2[p]), rs, ((16 + p) * 64 * NW + tid) * 16, 0, 16);
+        }
+        int* flag = reinterpret_cast<int*>(lds + v2_lds(WM, ST) - 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, then the barrier, then ONE ticket
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 1u) {
+                __hip_atomic_store(tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flag = (int)t;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+#pragma unroll
+        for (int p0 = 0; p0 < 16; p0 += 8) {
+            f32x4 o1[8], o2[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { o1[b] = other[(p0 + b) * 64 * NW + tid]; o2[b] = other[(16 + p0 + b) * 64 * NW + tid]; }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { r1[p0 + b] += o1[b]; r2[p0 + b] += o2[b]; }
+        }
     }
     const int wm0 = m0 + wm * 64, wn0 = n0 + wn * 64;
     ET* tp1 = epi.t1_ptr();
@@ -564,13 +660,21 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         // of layer 1 (26 tile steps, then an epilogue as long as the main loop); measured 113 us against 110 us for
         // the 256 x 128 tile there (and 291 vs 257 us at K = 4096), so it is never picked automatically.
         const bool pairs = g_v2_tile == 64;
+        // Split-K: each 256 x 128 tile is computed by TWO blocks, one per K half. Meant for outputs that give at most
+        // half the CUs a block (the 784 x 4096 gradient: 128 tiles -> 256 blocks of 32 K steps). Measured against the
+        // 128 x 128 tiling: 92 vs 103 us back to back in isolation, but 10 us SLOWER inside the step (1.110 vs 1.098
+        // ms/step, twice each: the 96 MB partial-tile exchange meets cold caches there) -- so it is never picked by
+        // shape; vbnn_debug_set(VBNN_DEBUG_V2_SPLITK, 1) turns it on. g_v2_split: -1 / 0 off, 1 whenever possible.
+        const bool can_split = t256 <= VBNN_CNT_TILES_MAX && nk >= 2;
+        const bool split = !pairs && g_v2_tile != 128 && can_split &&
+                           g_v2_split == 1;
         // Pair split: see the kernel. By shape when the functor allows it, the dual 256 x 128 tiling gives at most half
         // the CUs a block (the 784 x 4096 gradient: 128 tiles) and K is long; g_v2_psplit: -1 by shape, 0 never, 1 always.
         bool psplit = false;
         if constexpr (DUAL && Epi::SPLITTABLE)
-            psplit = !pairs && g_v2_tile != 128 && gemm_v2_psplit_by_shape(M, N, K);
+            psplit = !pairs && !split && g_v2_tile != 128 && gemm_v2_psplit_by_shape(M, N, K);
         if (kmajor && !psplit) return VBNN_ERR_UNSUPPORTED;
-        const bool small = !psplit && (pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256));
+        const bool small = !split && !psplit && (pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256));
         const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small && !pairs ? 0 : 2);
         const int vi0 = pairs ? 2 : small ? 1 : 0;       // variant: 256 x 128 / 128 x 128 / 128 x 128 co-resident / pair split
         const int si = sched >> 1;                       // 0, 1, 2
@@ -602,14 +706,28 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
             configured[vi][si][ctx->device] = true;
         }
         const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + V2_BN - 1) / V2_BN;
+        int ksplit_ = split ? 2 : 1;
+        if (split) {                                          // two partial tiles per tile: 2 x 32 f32x4 per thread
+            const size_t need = (size_t)tiles_m * tiles_n * 2 * 32 * threads * 16;
+            if (need > ctx->park_bytes) {
+                (void)hipStreamSynchronize(stream);
+                if (ctx->park) (void)hipFree(ctx->park);
+                ctx->park = nullptr; ctx->park_bytes = 0;
+                hipError_t e2 = hipMalloc((void**)&ctx->park, need);
+                if (e2 != hipSuccess) { vbnn_set_error("hipMalloc(split-K scratch, %zu bytes): %s", need, hipGetErrorString(e2)); return VBNN_ERR_NOMEM; }
+                ctx->park_bytes = need;
+            }
+        }
         const bf16_t* a = (const bf16_t*)A; const bf16_t* a2 = (const bf16_t*)A2;
         const bf16_t* b = (const bf16_t*)B; const bf16_t* b2 = (const bf16_t*)B2;
         int nk_ = nk, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
         int64_t lda_ = lda, ldb_ = ldb;
+        float* exch_ = ctx->park;
+        unsigned* tickets_ = ctx->counters + VBNN_CNT_TILES;
         Epi epi_ = epi;
         int psplit_ = psplit ? 1 : 0;
-        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &psplit_, &epi_};
-        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * (psplit ? 2 : 1)), dim3(threads), args, lds_bytes, stream);
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &ksplit_, &exch_, &tickets_, &psplit_, &epi_};
+        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * ksplit_ * (psplit ? 2 : 1)), dim3(threads), args, lds_bytes, stream);
         if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v2 failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
         return vbnn_check_launch("gemm_nt_v2");
     }

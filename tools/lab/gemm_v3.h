@@ -12,8 +12,8 @@
 // d/dmeans and d/dlvars depend on one GEMM each), so the pair runs as two passes of the SAME workgroup over the same
 // accumulator registers and nothing is parked in between. (FWD's term needs a Philox block per quad; 32 of them beside
 // 128 live accumulators spilled until the folds were serialised -- FOLD_SERIAL in epilogues.h -- so that one quad's
-// draw is live at a time. r01's form, which parked the variance tile in a per-workgroup scratch tile and drew the noise in
-// the final epilogue, cost +128 MB of cache traffic per launch, 10-15 us: tools/lab/ keeps it.)
+// draw is live at a time. The earlier form, which parked the variance tile in a per-workgroup scratch tile and drew the
+// noise in the final epilogue, is kept behind -DVBNN_FWD_PARK: +128 MB of cache traffic per launch, 10-15 us.)
 //
 //   workgroup   8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = acc[8][4] (128 accumulator registers)
 //   K step      64 bf16 (128-B rows, the swizzle of gemm_v2.h), two PHASES of 32 MFMAs per wave:
@@ -28,16 +28,29 @@
 #pragma once
 #include "gemm_v2.h"
 
+#ifndef V3_HM_AHEAD
+// 1 (default): the half-height form reads a step's B fragments and its first A pair ONE STEP AHEAD into a second register set
+// (pieces three steps ahead), so a step opens with MFMAs instead of two LDS round trips behind its barrier. In-kernel stamps
+// (tools/split_lab, profiles/r03_stamps.txt): main loop 66.1-68.3 -> 64.2-64.5 us, the launch 76.6-78.3 -> 71.9-74.5 us (two
+// rounds on one box; without pieces 52.4-53.1 -> 49.4-50.5) -- 5 %, a quarter of what the exposed latencies add up to on
+// paper; inside the wide step the difference drowns in the box's noise (0.8297-0.8321 against 0.8290-0.8328 ms). 0: the plain
+// form (A/B: make LIBDIR=../lib/ab EXTRA=-DV3_HM_AHEAD=0). The half-phase stagger of waves 4-7 tried on the full-height
+// loop the same day (bitwise equal, 104.9 -> 105.0 us per 4096^3 pass) did nothing at all.
+#define V3_HM_AHEAD 1
+#endif
 constexpr int V3_BM = 256, V3_BN = 256;
 constexpr int V3_APART = 128 * 128;                  // bytes: 128 rows x 128 B
 constexpr int V3_BTILE = 256 * 128;
 constexpr int V3_LDS = 4 * V3_APART + 3 * V3_BTILE;  // 163840: all of the CU's LDS
 
-inline int g_v3_min_k = 704;        // shortest K the shape selection gives to this kernel (vbnn_debug_set key 4)
+static int g_v3_min_k = 704;        // shortest K the shape selection gives to this kernel (vbnn_debug_set key 4)
 
-// Stamp hook: a build that wants in-kernel time stamps defines V3_ST(k) before including this file (tools/lab/ has r03's); the
-// library does not.
-#ifndef V3_ST
+// Diagnostic stamps (tools/split_lab.hip builds with -DV3_STAMP; the library never does): wave 0 of every workgroup
+// stores the 100 MHz real-time counter at a few points of the kernel into g_v3_stamp[blockIdx.x * 8 + k].
+#ifdef V3_STAMP
+__device__ unsigned long long* g_v3_stamp = nullptr;
+#define V3_ST(k) do { if (g_v3_stamp && threadIdx.x == 0) g_v3_stamp[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
 #define V3_ST(k) do { } while (0)
 #endif
 
@@ -52,20 +65,28 @@ inline int g_v3_min_k = 704;        // shortest K the shape selection gives to t
 //               8 k-rows x 32 B a half-wave's tr read touches fall on 8 distinct 32-byte bank slots
 //   fragment    lane 4 r + p of a 16-lane group addresses (k-row r, columns 4 p .. 4 p + 3) of the 4 x 16 block and
 //               receives column (lane & 15) of its four rows: k = 32 s + 8 q + 0..3, then + 4..7 with the second read
-// SPLIT + HM (accGradParameters of a layer whose output has too few 256 x 256 tiles to fill the CUs: the 784 x 4096 gradient of the
-// input layer): the PAIR is split over workgroups as in gemm_v2.h -- each computes ONE GEMM of the pair with the single-pass loop and
-// writes only the outputs that depend on it (EpiDw::part) -- over HALF-HEIGHT tiles, 128 x 256 (wave tile 64 x 64 = acc[0..3][], every
-// K step one phase of 32 MFMAs per wave), each workgroup walking ALL of K: 785 x 4096 -> 7 x 16 x 2 = 224 workgroups, ONE round, no
-// partial tiles to hand over. The output may be ragged in M (rows past m_dim() are computed on zero padding and never stored; the row
-// AT m_dim() is the ones row: edge_row). LDS: A parts as a ring of four (A of step t in part t & 3), B triple-buffered as before.
-// (r02's form of this launch -- full-height tiles, each GEMM split again over two K halves that met through write-through slabs and
-// tickets -- lost to this one, 84 against 68 us in the step, and lives on in tools/lab/ only.)
+// SPLIT (accGradParameters of a layer whose output has too few 256 x 256 tiles to fill the CUs: the 784 x 4096 gradient of
+// the input layer, 4 x 16 tiles): the grid is tiles x 2 x 2. A tile's PAIR is split over workgroups as in gemm_v2.h (each
+// computes one GEMM of the pair with the single-pass loop and writes only the outputs that depend on it, EpiDw::part), and
+// each of those is split again over two K halves whose partial tiles meet through a write-through slab + ticket (the
+// hand-off of gemm_v2.h's split-K: both halves store, the one whose ticket is 1 adds the other's -- a + b is commutative,
+// so the result does not depend on arrival order -- and runs the epilogue). 64 tiles -> 256 workgroups of 32 K steps on
+// this kernel's main loop (1.4 us per step against 0.9-1.2 us per HALF-size step of gemm_v2's single-accumulator tile).
+// The output may be ragged in M (rows past m_dim() are computed on zero padding and never stored; the row AT m_dim() is
+// the ones row: edge_row).
+// HM (a form of SPLIT; r03): the pair split alone over HALF-HEIGHT tiles -- 128 x 256, the wave tile 64 x 64 = acc[0..3][], every K
+// step one phase of 32 MFMAs per wave -- each workgroup walking ALL of K: no partial tiles, no slabs, no tickets. For an output
+// whose 128-row tiles x 2 fill most of the CUs in one round (785 x 4096: 7 x 16 x 2 = 224 workgroups) the launch costs its
+// 64 K steps (0.98 us each in the lab: two A + four B pieces beside 32 MFMAs) + one epilogue, against 32 steps of 1.62 us
+// + slab store + ticket + the partner's slab + epilogue on the finishing half of the K-split form.
+// LDS: A parts as a ring of four (A of step t in part t & 3, refilled two steps ahead), B as before.
 template <bool DUAL, bool AK, bool BK, class Epi, bool SPLIT = false, bool HM = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ A, const bf16_t* __restrict__ A2, int64_t lda,
                                                      const bf16_t* __restrict__ B, const bf16_t* __restrict__ B2, int64_t ldb,
-                                                     int M, int N, int nk, int tiles_m, int tiles_n, Epi epi_in) {
+                                                     int M, int N, int nk, int tiles_m, int tiles_n, float* mscratch,
+                                                     unsigned* tickets, Epi epi_in) {
     static_assert(!(SPLIT && DUAL), "the split form computes one GEMM of the pair per workgroup");
-    static_assert(SPLIT == HM && (!HM || (AK && BK)), "the pair-split launch is the half-height K-major form");
+    static_assert(!HM || (SPLIT && AK && BK), "the half-height form is a K-major pair-split launch");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     V3_ST(0);
     const int tid = threadIdx.x;
@@ -79,20 +100,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     Epi epi = epi_in;
 
     // ---- block -> tile mapping: as gemm_v2.h (blocks that share an XCD get a compact 4 x 8 group of tiles)
-    const int nblk = tiles_m * tiles_n * (SPLIT ? 2 : 1);
+    const int nblk = tiles_m * tiles_n * (SPLIT ? (HM ? 2 : 4) : 1);
     int bid = blockIdx.x;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    int kslice = 0, unit = 0;                  // SPLIT: K half of this workgroup; (tile, part) id = ticket / slab index
     if (SPLIT) {
-        // part-major: the blocks that share an XCD (a contiguous range of remapped ids) all compute the SAME GEMM of the pair for a
-        // compact group of tiles, so they share operand panels in its L2 exactly as the unsplit launch does
+        // combination-major: the blocks that share an XCD (a contiguous range of remapped ids) all compute the SAME
+        // (GEMM of the pair, K half) for a compact group of tiles, so they share operand panels in its L2 exactly as the
+        // unsplit launch does (a tile's four blocks side by side would share none: 37 % of the panel reads unique instead
+        // of 19 %). The partner K halves then sit on different XCDs: their slabs are write-through anyway.
         const int ntile = tiles_m * tiles_n;
-        const int part = bid / ntile;
-        bid -= part * ntile;
+        const int combo = bid / ntile;
+        bid -= combo * ntile;
+        kslice = HM ? 0 : combo >> 1;
+        const int part = combo & 1;
+        unit = bid * 2 + part;
         epi.set_part(1 + part);
         if (part) { A = A2; B = B2; }
+        if (!HM) {
+            const int kt0 = kslice * (nk / 2);
+            nk = kslice ? nk - nk / 2 : nk / 2;
+            A += (int64_t)kt0 * (AK ? V2_BK * lda : V2_BK);
+            B += (int64_t)kt0 * (BK ? V2_BK * ldb : V2_BK);
+        }
     }
     int tm, tn;
     {
@@ -146,7 +179,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     const int a_kstep = AK ? V2_BK * (int)lda : V2_BK, b_kstep = BK ? V2_BK * (int)ldb : V2_BK;
     const bf16_t* Ap = A;
     const bf16_t* Bp = B;
+#ifdef V3_LAB_KWRAP     // tools/gemm_lab.hip only: wrap the K walk so every operand line is an L2 hit (timing only, wrong results)
+#define V3_KT(t) ((t) & (V3_LAB_KWRAP - 1))
+#else
 #define V3_KT(t) (t)
+#endif
     // The LDS-DMA pieces go out in their BUFFER form: resource in SGPRs, the lane's byte offset in one VGPR, the K step in
     // an SGPR -- no 64-bit address arithmetic per piece, and the piece issues a few cycles sooner (lab: -2.5 ... -5 %
     // on the pipelined loops, which are bound by exactly this issue). The host pass never runs the body.
@@ -181,10 +218,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     // the main loop's form: LDS destination and K offset are LOOP-CARRIED scalars (run_pass), so a piece costs one
     // scalar add for M0 instead of six scalar operations recomputing both from the step index (lab: the address work
     // was 8-10 % of the loop, which is bound by the issue of these pieces)
+#if defined(V3_LAB_PIECE)
+    typedef int lab_i32x4 __attribute__((ext_vector_type(4)));
+    lab_i32x4 lab_stg[4] = {lab_i32x4{0, 0, 0, 0}, lab_i32x4{0, 0, 0, 0}, lab_i32x4{0, 0, 0, 0}, lab_i32x4{0, 0, 0, 0}};
+#endif
     auto dma_a_at = [&](unsigned lds_off, int so_bytes, auto P_c, auto d_c) {
         constexpr int P = decltype(P_c)::value, D = decltype(d_c)::value;
         unsigned char* dst = lds + lds_off + (P * V3_APART + D * 8192) + wave * 1024;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(V3_LAB_PIECE)
+        // tools/gemm_lab.hip only (timing, wrong results): what a piece costs in other forms. 1: no piece at all; 2: a plain
+        // 16-byte buffer load into registers, no LDS write; 3: that load + a ds_write_b128 of the registers loaded one phase ago
+        if constexpr (V3_LAB_PIECE >= 2) {
+            if constexpr (V3_LAB_PIECE == 3) *reinterpret_cast<lab_i32x4*>(dst + lane * 16) = lab_stg[D];
+            lab_stg[D] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(2u * (unsigned)a_off[P][D]), so_bytes, 0);
+        }
+#elif defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)dst, 16, (int)(2u * (unsigned)a_off[P][D]), so_bytes, 0, 0);
 #else
         __builtin_amdgcn_global_load_lds((gptr_t)(Ap + a_off[P][D] + so_bytes / 2), (lptr_t)dst, 16, 0, 0);
@@ -193,7 +241,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     auto dma_b_at = [&](unsigned lds_off, int so_bytes, auto d_c) {
         constexpr int D = decltype(d_c)::value;
         unsigned char* dst = lds + lds_off + (4 * V3_APART + D * 8192) + wave * 1024;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(V3_LAB_PIECE)
+        if constexpr (V3_LAB_PIECE >= 2) {
+            if constexpr (V3_LAB_PIECE == 3) *reinterpret_cast<lab_i32x4*>(dst + lane * 16) = lab_stg[2 + (D & 1)];
+            lab_stg[2 + (D & 1)] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(2u * (unsigned)b_off[D]), so_bytes, 0);
+        }
+#elif defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)dst, 16, (int)(2u * (unsigned)b_off[D]), so_bytes, 0, 0);
 #else
         __builtin_amdgcn_global_load_lds((gptr_t)(Bp + b_off[D] + so_bytes / 2), (lptr_t)dst, 16, 0, 0);
@@ -347,10 +400,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             dma_b(1, 1, c0); dma_b(1, 1, c1); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c0); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c1);
             dma_b(1, 1, c2); dma_b(1, 1, c3);
         }
+#if V3_HM_AHEAD
         if (nk > 2) {                   // ... and of step 2: the pieces run three steps ahead of the MFMAs (run_pass)
             dma_b(2, 2, c0); dma_b(2, 2, c1); dma_a_at(2u * V3_APART, 4 * a_kstep, c0, c0); dma_a_at(2u * V3_APART, 4 * a_kstep, c0, c1);
             dma_b(2, 2, c2); dma_b(2, 2, c3);
         }
+#endif
     };
     auto run_pass = [&]() {
         // loop-carried scalars of step t: LDS offset of A part (t & 1) * 2, of B slots t % 3 and (t + 2) % 3, and the
@@ -363,7 +418,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         auto kstep = [&](const int t, auto tail_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
             const bool n1 = TAIL ? (t + 1 < nk) : true, n2 = TAIL ? (t + 2 < nk) : true;
+#ifdef V3_LAB_KWRAP
+            const int so_a1 = 2 * V3_KT(t + 1) * a_kstep, so_a2 = 2 * V3_KT(t + 2) * a_kstep, so_b2 = 2 * V3_KT(t + 2) * b_kstep;
+#else
             const int so_a1 = ka + da, so_a2 = ka + 2 * da, so_b2 = kb + 2 * db;
+#endif
             const unsigned oa_next = oa ^ (2u * V3_APART);        // A part pair of step t + 1
             const unsigned char* sb = lds + 4 * V3_APART + ob;
             bf16x8 bf[2][4];
@@ -500,6 +559,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
             ka += da; kb += db;
         };
+#if V3_HM_AHEAD
         if constexpr (HM) {
             // ---- the half-height form, fragments read ONE STEP AHEAD: one phase per K step on the wave's 64 x 64 tile
             // (acc[0..3][]). The step's B fragments (both k-halves) and its first A pair are read from LDS at the END of the
@@ -606,6 +666,75 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             if (t < nk) step(t, X, Y);
             return;
         }
+#else
+        if constexpr (HM) {
+            // ---- the half-height form: one phase per K step on the wave's 64 x 64 tile (acc[0..3][]), the A parts a ring of four.
+            // Step t: s_waitcnt vmcnt(6) (the six pieces of step t + 1 may stay in flight) -> barrier -> the phase-0 schedule of
+            // the K-major loop above with six pieces beside the 32 MFMAs: A of step t + 2 (two, into part (t + 2) & 3, last read
+            // in step t - 2), B of step t + 2 (four, into the slot step t - 1 read).
+            unsigned oa4 = 0;                                       // A part of step t: (t & 3) * V3_APART
+            auto kstep_hm = [&](const int t) {
+                const bool n2 = t + 2 < nk;
+                const int so_a2 = ka + 2 * da, so_b2 = kb + 2 * db;
+                const unsigned oa2 = oa4 ^ (2u * V3_APART);
+                const unsigned char* sb = lds + 4 * V3_APART + ob;
+                const unsigned char* sa = lds + oa4;
+                bf16x8 bf[2][4];
+                if (t + 1 < nk) v2_wait_barrier<6>(); else v2_wait_barrier<0>();
+                auto dma_slot = [&](int k) {
+                    if (!n2) return;
+                    if (k == 0) dma_a_at(oa2, so_a2, c0, c0);
+                    if (k == 1) dma_a_at(oa2, so_a2, c0, c1);
+                    if (k == 2) dma_b_at(ob2, so_b2, c0);
+                    if (k == 3) dma_b_at(ob2, so_b2, c1);
+                    if (k == 4) dma_b_at(ob2, so_b2, c2);
+                    if (k == 5) dma_b_at(ob2, so_b2, c3);
+                };
+                const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
+                TrPair g[3];
+                auto issue = [&](auto idx_c) {             // as in the full-height loop: three pairs in rotation, the two before kept
+                    constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                    if constexpr (IDX == 0)
+                        tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                  std::integral_constant<int, S * 8192 + 1024>(), g[0]);
+                    else
+                        tr_issue2_keep(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                       std::integral_constant<int, S * 8192 + 1024>(), g[IDX % 3], g[(IDX + 2) % 3],
+                                       g[IDX >= 2 ? (IDX + 1) % 3 : (IDX + 2) % 3]);
+                };
+                auto work = [&](auto idx_c) {
+                    constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                    TrPair& p = g[IDX % 3];
+                    tr_wait2(p);
+                    if constexpr (IDX < 3) issue(std::integral_constant<int, IDX + 1>());
+                    if constexpr (IDX == 1) {                            // the other k-half's B fragments
+                        const unsigned bb = (unsigned)(uintptr_t)(ldsb_t)sb;
+                        tr_load4_keep(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], std::integral_constant<int, 16384>(),
+                                      std::integral_constant<int, 16384 + 2048>(), bf[1], p, g[0]);
+                    }
+                    const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bf[S][j], acc[F][j], 0, 0, 0);
+                    if constexpr (IDX < 2) { dma_slot(2 * IDX); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[F + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bf[S][j], acc[F + 1][j], 0, 0, 0);
+                    dma_slot(IDX < 2 ? 2 * IDX + 1 : IDX + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                load_b(sb, c0, bf[0]);
+                issue(c0);
+                work(c0); work(c1); work(c2); work(c3);
+                keep_frags(bf[0]); keep_frags(bf[1]);
+                oa4 = (oa4 + V3_APART) & (4u * V3_APART - 1u);
+                ob = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+                ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
+                ka += da; kb += db;
+            };
+            for (int t = 0; t < nk; ++t) kstep_hm(t);
+            return;
+        }
+#endif
         int t = 0;
         for (; t + 2 < nk; ++t) kstep(t, std::false_type());
         for (; t < nk; ++t) kstep(t, std::true_type());
@@ -637,6 +766,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     };
     const typename Epi::Lane eln = epi.lane_init(q4, 4 * c16);
 
+    // PARK functors only: this workgroup's scratch tile, [8 i][4 j][512 threads] f32x4, written and read by the same thread
+    f32x4* park = reinterpret_cast<f32x4*>(mscratch + (size_t)blockIdx.x * (V3_BM * V3_BN));
     auto for_quarters = [&](auto&& fn) {
         fn(c0, c0, 0); fn(c0, c1, 1);
         if constexpr (!HM) { fn(c1, c0, 2); fn(c1, c1, 3); }
@@ -677,6 +808,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         int fc16 = c16, fq4 = q4, fm0 = m0 + wr * 128, fn0 = n0 + wc * 64;
         asm volatile("" : "+v"(fc16), "+v"(fq4), "+s"(fm0), "+s"(fn0));
         const typename Epi::Lane fln = epi.lane_init(fc16, 4 * fq4);
+        if (Epi::PARK) {                                      // acc2 as it stands: one coalesced 16-byte store per quad
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) (park + (i * 4 + j) * 512)[tid] = acc[i][j];
+        }
         // Quads are folded in batches of Epi::FOLD_BATCH m-blocks (4 quads each): a batch's loads fly together, ahead of
         // their first use. (Indices are compile-time constants, not `#pragma unroll` loops over the m-blocks: a loop
         // the optimiser declines to unroll would index the accumulators dynamically and send them all to scratch.)
@@ -817,44 +954,56 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     }
     __syncthreads();
     V3_ST(1);
+#if defined(V3_LAB_PIECE)
+    asm volatile("" ::"v"(lab_stg[0]), "v"(lab_stg[1]), "v"(lab_stg[2]), "v"(lab_stg[3]));
+#endif
 
-    // ---- the classifier head's logits from this tile (EpiFwd::head_slots; see epilogues.h). The accumulators ARE y (the fold
-    // put b + sqrt(v) z under pass 2): lane (q4, c16) holds m = 16 i + 4 q4 + 0..3 of row n = 16 j + c16 in acc[i][j]. An MFMA
-    // contracts over its k slots whatever they stand for, so slot (q4, e) of the B operand is taken to mean m = 16 i0 + 4 q4 + e
-    // (e < 4) and 16 i1 + 4 q4 + e - 4 (e >= 4) for a PAIR of m-blocks (i0, i1): the B fragment is then the two accumulator
-    // quads as they stand (ReLU, rounded to bf16 -- the values `h` gets), no LDS trip, and the A fragment is the final weight's
-    // row `class = c16` at the same m: two 8-byte loads per pair. 16 MFMAs per wave.
-    if constexpr (!SPLIT && Epi::HEAD) {
-        if (epi.head_slots) {
-            const int hq4 = lane >> 4, hc16 = lane & 15;
-            const bf16_t* wrow = epi.head_w3 + (int64_t)min(hc16, epi.head_C - 1) * epi.head_ld_w + (m0 + wr * 128) + 4 * hq4;
-            bf16x8 wf[4];
+    if constexpr (SPLIT && !HM) {
+        // ---- split-K hand-off (gemm_v2.h's protocol: cdna_hip_programming.md Guideline 16 R1 in its ticket form). Both K
+        // halves store their partial tile as it stands in the MFMA layout (thread-private 16-byte slots, write-through),
+        // drain, take a ticket; ticket 0 is done; ticket 1 acquires, adds the other half's partial and goes on.
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        f32x4* mine = reinterpret_cast<f32x4*>(mscratch) + (size_t)(unit * 2 + kslice) * (32 * 512);
+        const f32x4* other = reinterpret_cast<const f32x4*>(mscratch) + (size_t)(unit * 2 + (kslice ^ 1)) * (32 * 512);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 32 * 512 * 16, 0x00020000);
+        // one lane offset for all 32 quads; the quad's slab offset rides in the scalar operand
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(wrow + 32 * pr);
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(wrow + 32 * pr + 16);
-                wf[pr] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, acc[i][j]), rs, tid * 16, (i * 4 + j) * 8192, 16);
+        int* flag = reinterpret_cast<int*>(lds + V3_LDS - 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, then the barrier, then ONE ticket
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(tickets + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 1u) {
+                __hip_atomic_store(tickets + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            const bool relu = epi.relu != 0;
-            float* const sl = epi.head_slots + ((int64_t)(tm * 2 + wr) * epi.N + (n0 + wc * 64)) * 16 + hc16 * 16 + 4 * hq4;
+            *flag = (int)t;
+        }
+        __syncthreads();
+        V3_ST(2);
+        if (*flag == 0) return;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(other), 0, 32 * 512 * 16, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, tid * 16, (i * 4 + j) * 8192, 0));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    const f32x4 a0 = acc[2 * pr][j], a1 = acc[2 * pr + 1][j];
-                    bf16x8 hb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        hb[e] = (bf16_t)(relu ? fmaxf(a0[e], 0.f) : a0[e]);
-                        hb[4 + e] = (bf16_t)(relu ? fmaxf(a1[e], 0.f) : a1[e]);
-                    }
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[pr], hb, d, 0, 0, 0);
-                }
-                // classes 4 q4 .. + 3 of row 16 j + c16: 16 rows x 64 contiguous bytes per wave-instruction
-                *reinterpret_cast<f32x4*>(sl + j * 256) = d;
+                acc[i][j] += o[j];
+                // the sum is formed HERE: left to itself the optimiser sinks the adds into the epilogue and keeps all 32
+                // loaded quads alive beside the accumulators (it spilled)
+                asm volatile("" : "+v"(acc[i][j]));
             }
         }
+        __syncthreads();                                          // the flag's LDS word is staging space from here on
+        V3_ST(3);
     }
 
     ET* tp1 = epi.t1_ptr();
@@ -871,9 +1020,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl) av[2 * i + jl] = acc[4 * HH + i][2 * JJ + jl];
         f32x4 r2[8];
-        relayout(av, r1);
+        if (DUAL && Epi::PARK) {
+            f32x4 sv[8];                                      // the parked acc2 quarter: its loads fly during the first trip
 #pragma unroll
-        for (int p = 0; p < 8; ++p) r2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) sv[2 * i + jl] = (park + ((4 * HH + i) * 4 + 2 * JJ + jl) * 512)[tid];
+            relayout(av, r1);
+            relayout(sv, r2);
+        } else {
+            relayout(av, r1);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) r2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // the functor's FAST protocol (epilogues.h): every tile of this kernel is interior and vector-aligned (the
         // launcher checks), so the epilogue's global loads are issued a batch at a time, ahead of their first use
         constexpr int FB = Epi::FAST_BATCH;
@@ -1001,6 +1160,16 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         }
         if (!gemm_v3_possible(M, N, K, lda, ldb, AK, BK, epi)) { vbnn_set_error("gemm_v3: shape / outputs outside its fast path"); return VBNN_ERR_UNSUPPORTED; }
         const int tiles_m = (M + V3_BM - 1) / V3_BM, tiles_n = (N + V3_BN - 1) / V3_BN;
+        const size_t need = (DUAL && Epi::PARK) ? (size_t)tiles_m * tiles_n * V3_BM * V3_BN * sizeof(float) : 0;
+        if (need > ctx->park_bytes) {                        // the parking tiles (grown on demand, kept)
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->park) (void)hipFree(ctx->park);
+            ctx->park = nullptr; ctx->park_bytes = 0;
+            hipError_t e = hipMalloc((void**)&ctx->park, need);
+            if (e != hipSuccess) { vbnn_set_error("hipMalloc(gemm_v3 scratch, %zu bytes): %s", need, hipGetErrorString(e)); return VBNN_ERR_NOMEM; }
+            ctx->park_bytes = need;
+        }
+        float* park = ctx->park;
         const void* kern = (const void*)gemm_nt_v3<DUAL, AK, BK, Epi>;
         static vbnn_per_device_flag configured_on;           // per instantiation and device
         bool& configured = configured_on[ctx->device];
@@ -1014,26 +1183,29 @@ static int launch_gemm_v3(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
         int nk_ = nk, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
         int64_t lda_ = lda, ldb_ = ldb;
         Epi epi_ = epi;
-        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &epi_};
+        unsigned* tickets_ = nullptr;
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &park, &tickets_, &epi_};
         hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n), dim3(512), args, V3_LDS, ctx->stream);
         if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v3 failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
         return vbnn_check_launch("gemm_nt_v3");
     }
 }
 
-// ---- the pair-split HALF-HEIGHT launch (K-major operands only: accGradParameters reading x and g as the other GEMMs hold them)
-inline int g_v3_split = -1;         // -1 by shape, 0 never, 1 whenever possible (vbnn_debug_set key 8)
-// shape part: M rows of output (the ones row included) on N columns, K deep. Wanted when the pair split over 256 x 128 tiles
-// (gemm_v2.h) would leave half the CUs idle and this form's 128-row tiles x 2 make ONE round that fills at least 5/8 of them.
+// ---- the SPLIT launch (K-major operands only: accGradParameters reading x and g as the other GEMMs hold them)
+static int g_v3_split = -1;         // -1 by shape, 0 never, 1 whenever possible (vbnn_debug_set key 8)
+static int g_v3_hm = 1;             // the half-height pair-split form (HM): 0 never, 1 where its grid fills the CUs in one round,
+                                    // 2 whenever the split launch is taken (vbnn_debug_set key 8, values 2 / 3 / 4)
+// shape part: M rows of output (the ones row included) on N columns, K deep. Wanted when the pair split alone would leave
+// half the CUs idle and both K halves are long enough to amortise the pipeline fill and the hand-off.
 static inline bool gemm_v3_split_shape_ok(int64_t M, int64_t N, int64_t K) {
     if (g_v3_split == 0 || N % V3_BN || K % (2 * V2_BK)) return false;
-    if (g_v3_split == 1) return true;
     const int64_t tiles = ((M + V3_BM - 1) / V3_BM) * (N / V3_BN);
-    const int64_t blocks = ((M + V3_BM / 2 - 1) / (V3_BM / 2)) * (N / V3_BN) * 2;
+    if (tiles * 2 > VBNN_CNT_TILES_MAX) return false;
+    if (g_v3_split == 1) return true;
     const int64_t cus = vbnn_cu_count();
-    return tiles * 16 <= 5 * cus && tiles * 16 >= 3 * cus && K >= 2048 && blocks <= cus && blocks * 8 >= 5 * cus;
+    return tiles * 16 <= 5 * cus && tiles * 16 >= 3 * cus && K >= 2048;      // pair split alone <= 5/8 of the CUs, with the K split >= 3/4
 }
-// the pitch of the K rows of A this launch needs: whole 256-column tiles (the columns past M are zero padding)
+// the pitch of the K rows of A the split launch needs: whole 256-column tiles (the columns past M are zero padding)
 static inline int64_t gemm_v3_split_lda(int64_t M) { return (M + V3_BM - 1) / V3_BM * V3_BM; }
 
 template <typename T, class Epi>
@@ -1048,10 +1220,23 @@ static int launch_gemm_v3_split(vbnn_ctx* ctx, const T* A, const T* A2, int64_t 
             lda < gemm_v3_split_lda(M) || ldb < N || (int64_t)K * lda >= (1ll << 30) || (int64_t)K * ldb >= (1ll << 30))
             return VBNN_ERR_UNSUPPORTED;
         const int tiles_n = N / V3_BN;
-        const int tiles_m = (M + V3_BM / 2 - 1) / (V3_BM / 2);
-        const void* kern = (const void*)gemm_nt_v3<false, true, true, Epi, true, true>;
-        static vbnn_per_device_flag configured_on;           // per instantiation and device
-        bool& configured = configured_on[ctx->device];
+        // the half-height form (HM) when its 128-row tiles x 2 make ONE round that fills at least 5/8 of the CUs: no K split
+        const int tiles_hm = (M + V3_BM / 2 - 1) / (V3_BM / 2);
+        const int64_t cus = vbnn_cu_count();
+        const bool hm = g_v3_hm == 2 || (g_v3_hm == 1 && (int64_t)tiles_hm * tiles_n * 2 <= cus && (int64_t)tiles_hm * tiles_n * 16 >= 5 * cus);
+        const int tiles_m = hm ? tiles_hm : (M + V3_BM - 1) / V3_BM;
+        const size_t need = hm ? 0 : (size_t)tiles_m * tiles_n * 2 * 2 * V3_BM * V3_BN * sizeof(float);     // a partial tile per K half
+        if (need > ctx->park_bytes) {
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->park) (void)hipFree(ctx->park);
+            ctx->park = nullptr; ctx->park_bytes = 0;
+            hipError_t e = hipMalloc((void**)&ctx->park, need);
+            if (e != hipSuccess) { vbnn_set_error("hipMalloc(gemm_v3 split-K slabs, %zu bytes): %s", need, hipGetErrorString(e)); return VBNN_ERR_NOMEM; }
+            ctx->park_bytes = need;
+        }
+        const void* kern = hm ? (const void*)gemm_nt_v3<false, true, true, Epi, true, true> : (const void*)gemm_nt_v3<false, true, true, Epi, true>;
+        static vbnn_per_device_flag configured_on[2];        // per form and device
+        bool& configured = configured_on[hm ? 1 : 0][ctx->device];
         if (!configured) {
             hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
             if (e != hipSuccess) { vbnn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
@@ -1061,10 +1246,12 @@ static int launch_gemm_v3_split(vbnn_ctx* ctx, const T* A, const T* A2, int64_t 
         const bf16_t* b = (const bf16_t*)B; const bf16_t* b2 = (const bf16_t*)B2;
         int nk_ = K / V2_BK, M_ = M, N_ = N, tm_ = tiles_m, tn_ = tiles_n;
         int64_t lda_ = lda, ldb_ = ldb;
+        float* park = ctx->park;
+        unsigned* tickets_ = ctx->counters + VBNN_CNT_TILES;
         Epi epi_ = epi;
-        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &epi_};
-        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * 2), dim3(512), args, V3_LDS, ctx->stream);
-        if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v3 (pair split) failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
-        return vbnn_check_launch("gemm_nt_v3 pair split");
+        void* args[] = {&a, &a2, &lda_, &b, &b2, &ldb_, &M_, &N_, &nk_, &tm_, &tn_, &park, &tickets_, &epi_};
+        hipError_t e = hipLaunchKernel(kern, dim3(tiles_m * tiles_n * (hm ? 2 : 4)), dim3(512), args, V3_LDS, ctx->stream);
+        if (e != hipSuccess) { vbnn_set_error("launch of gemm_nt_v3 (split) failed: %s", hipGetErrorString(e)); return VBNN_ERR_HIP; }
+        return vbnn_check_launch("gemm_nt_v3 split");
     }
 }

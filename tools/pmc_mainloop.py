@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where do the cycles of the bare pipelined main loops go? PMC passes (rocprofv3 --pmc, one group per pass, --kernel-trace
-only) over tools/bin/gemm_lab_nd -- the library's own gemm_nt_v2 / gemm_nt_v3 main loops with a trivial epilogue on random
+only) over tools/bin/gemm_lab_nd -- the gemm_nt_v2 / gemm_nt_v3 main loops (tools/lab/: the headers as of round 3; the main loops are the shipped ones) with a trivial epilogue on random
 bf16 operands at 4096^3 -- summarised per kernel: every counter as its mean per dispatch, and the derived shares the
 round-3 question needs (is 1.5 PFLOP/s the ceiling of a dual-GEMM tile on this CU, and why?).
 ON the GPU box, from the repository root:   python3 tools/pmc_mainloop.py r03   -> gpurun_out/<tag>_mainloop_pmc.json"""

@@ -6,12 +6,12 @@
 #include <cstdarg>
 #include <vector>
 #include <algorithm>
-#include "../vbnn_amd/csrc/common.h"
+#include "lab/common.h"
 void vbnn_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 int vbnn_cu_count() { return 256; }
-#include "../vbnn_amd/csrc/epilogues.h"
-#include "../vbnn_amd/csrc/gemm_v2.h"
-#include "../vbnn_amd/csrc/gemm_v3.h"
+#include "lab/epilogues.h"
+#include "lab/gemm_v2.h"
+#include "lab/gemm_v3.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 int main(int argc, char** argv) {

@@ -112,7 +112,6 @@ extern "C" int vbnn_ctx_destroy(vbnn_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->counters) (void)hipFree(ctx->counters);
-    if (ctx->park) (void)hipFree(ctx->park);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VBNN_OK;

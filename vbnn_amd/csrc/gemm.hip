@@ -6,13 +6,10 @@ extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_GEMM_KERNEL && value >= 0 && value <= 3) { g_force_kernel = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_SCHEDULE && (value == -1 || value == 0 || value == 2 || value == 4)) { g_v2_sched = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_TILE && (value == 0 || value == 64 || value == 128 || value == 256)) { g_v2_tile = value; return VBNN_OK; }
-    if (key == VBNN_DEBUG_V2_SPLITK && value >= -1 && value <= 1) { g_v2_split = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V3_MIN_K && value >= 64) { g_v3_min_k = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V2_PSPLIT && value >= -1 && value <= 1) { g_v2_psplit = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_KMAJOR && value >= 0 && value <= 2) { g_kmajor = value; return VBNN_OK; }   // 2: gemm_v3 only
     if (key == VBNN_DEBUG_V3_SPLIT && value >= -1 && value <= 1) { g_v3_split = value; return VBNN_OK; }
-    if (key == VBNN_DEBUG_V3_SPLIT && value >= 2 && value <= 4) { g_v3_hm = value - 2; return VBNN_OK; }   // its half-height form: off / by shape / whenever the split launch is taken
-    if (key == VBNN_DEBUG_FAKE_NOISE && (value == 0 || value == 1)) { g_fake_noise = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V0 && (value == 0 || value == 1)) { g_v0 = value; return VBNN_OK; }
     vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
     return VBNN_ERR_INVALID;

@@ -15,7 +15,6 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; 
 // Test / A-B hook: vbnn_debug_set(VBNN_DEBUG_GEMM_KERNEL, ..).
 inline int g_force_kernel = 0;
 inline int g_kmajor = 1;              // K-major operands when the shape allows (vbnn_debug_set key 6)
-inline int g_fake_noise = 0;          // A/B only (key 7): the forward fold skips Philox + Box-Muller (wrong results, timing only)
 
 // would a GEMM of this shape run on gemm_v3 in its K-major form right now? (shape and debug keys only; the functor's
 // fast-path conditions are checked at launch)
@@ -29,7 +28,7 @@ static inline bool kmajor_selected(int64_t M, int64_t N, int64_t K) {
 static inline bool kmajor_dw_v2_selected(int64_t M, int64_t N, int64_t K) {
     if (K * (M + 64) >= (1ll << 30) || K * (N + 64) >= (1ll << 30)) return false;
     return g_kmajor == 1 && K % V2_BK == 0 && (g_force_kernel == 0 || g_force_kernel == 2) && g_v2_tile != 128 && g_v2_tile != 64 &&
-           g_v2_split != 1 && gemm_v2_eligible<bf16_t>(M, N, K, 64, 64) && gemm_v2_psplit_by_shape(M, N, K);
+           gemm_v2_eligible<bf16_t>(M, N, K, 64, 64) && gemm_v2_psplit_by_shape(M, N, K);
 }
 // 0: transposed copies needed; 1: K-major operands as the other GEMMs hold them; 2: K-major, and x / x.x must be allocated
 // with their row pitch padded to whole 256-column tiles (zero fill): the split launch of gemm_v3.h

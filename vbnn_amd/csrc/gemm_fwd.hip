@@ -5,7 +5,7 @@ template <typename T>
 static int forward_t(vbnn_ctx* ctx, const vbnn_fwd_args* a) {
     EpiFwd<T> e;
     e.bias = a->bias;
-    e.noise = a->w2 != nullptr ? (g_fake_noise ? 2 : 1) : 0;
+    e.noise = a->w2 != nullptr ? 1 : 0;
     e.seed = a->seed; e.layer = a->layer; e.draw = a->draw; e.row0 = a->row0; e.draw_dev = a->draw_dev;
     e.rpd = (int)a->rows_per_draw;
     e.y = a->y; e.ld_y = a->ld_y; e.y_vec = a->y && aligned16(a->y) && (a->ld_y % 4 == 0);
