@@ -207,7 +207,7 @@ def reporting_config_row(torch, L, FusedMLP, fill_normal, with_cpu):
     return out
 
 
-def side_config_row(name, torch, dist, L, FusedMLP, fill_normal, steps, warmup, world, rank, use_dist, blocks=3):
+def side_config_row(name, torch, dist, L, FusedMLP, fill_normal, steps, warmup, world, rank, use_dist, blocks=3, exchange=None):
     """Another BASELINE.json configuration measured in the SAME run, by the same protocol (warm-up, `blocks` blocks of `steps`
     steps between barrier + synchronize, MAX over ranks, the median block): configs[4], the 8 x 4096 VBLinear stack with its
     regression head, so that the driver's line carries it. Its own engine, its own exchange when N > 1."""
@@ -215,6 +215,8 @@ def side_config_row(name, torch, dist, L, FusedMLP, fill_normal, steps, warmup, 
     N = cfg["batch"]
     opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"], hidden=cfg["hidden"],
                n_classes=cfg["n_classes"], fuse_kl=True, criterion=cfg.get("criterion", "nll"))
+    if exchange:
+        opt["exchange"] = exchange
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist)
     x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
     fill_normal(x, 3, L.STREAM_DATA, 0, 0, row0=rank * N)
@@ -259,7 +261,7 @@ def side_config_row(name, torch, dist, L, FusedMLP, fill_normal, steps, warmup, 
     return out
 
 
-def sharded_train_row(cfg, torch, dist, L, FusedMLP, fill_normal, steps, warmup, world, rank, blocks=3):
+def sharded_train_row(cfg, torch, dist, L, FusedMLP, fill_normal, steps, warmup, world, rank, blocks=3, exchange=None):
     """The TRAINING step with the sharded-update exchange (opt.exchange_mode = "sharded": reduce-scatter of the gradients by layer
     rows, vbnn_update on this rank's rows, all-gather of the bf16 operand shadows + statistics -- 0.75 x the all-reduce's bytes,
     1 / world of the update sweep, fp32 sums) beside the all-reduce line, same protocol. An OPTION beside north_star's all-reduce:
@@ -269,6 +271,8 @@ def sharded_train_row(cfg, torch, dist, L, FusedMLP, fill_normal, steps, warmup,
     opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype=cfg["dtype"], seed=3, input_size=cfg["input_size"], hidden=cfg["hidden"],
                n_classes=cfg["n_classes"], fuse_kl=True, criterion=cfg.get("criterion", "nll"), exchange_mode="sharded",
                state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
+    if exchange:
+        opt["exchange"] = exchange
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=True)
     x = torch.empty(N, cfg["input_size"], dtype=torch.float32, device="cuda")
     fill_normal(x, 3, L.STREAM_DATA, 0, 0, row0=rank * N)
@@ -305,6 +309,60 @@ def sharded_train_row(cfg, torch, dist, L, FusedMLP, fill_normal, steps, warmup,
                    "KL gradient added there) -> all-gather of the bf16 operand shadows + the slices' prior statistics; compare with train_step"}
     del eng
     torch.cuda.empty_cache()
+    return out
+
+
+def probe_exchange_backends(torch, dist, rank, world, local_rank, n_floats=1 << 24, reps=5):
+    """Which exchange moves a 64 MB all-reduce faster on THIS node -- the collective library (vbnn_comm over RCCL; torch.distributed in a
+    gloo rehearsal) or the direct reduce-scatter + all-gather over peer-mapped arenas (vbnn_p2p)? SURVEY.md section 5's plan ("measure
+    RCCL's achieved bus bandwidth; if RCCL serialises onto one ring, fall back to the peer-to-peer kernels") as a measurement at the
+    start of every multi-rank run: both are timed back to back on the idle GPUs, MAX over ranks, and the step uses the faster. Every
+    step of it is collective in failure as well (comm.make_exchange / comm.P2PExchange agree over the process group)."""
+    from vbnn_amd import comm
+    from vbnn_amd.nn import Context
+    ctx = Context.get(torch.device("cuda", local_rank))
+    out = {"bytes": n_floats * 4}
+
+    def timed(ex, buf):
+        for _ in range(2):
+            ex.allreduce(buf); ex.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ex.allreduce(buf)
+        ex.finish()
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+    for name in ("library", "p2p"):
+        ex = None
+        try:
+            if name == "library":
+                ex = comm.make_exchange(ctx, rank, world, None)
+                buf = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
+            else:
+                ex = comm.P2PExchange(ctx, rank, world, n_floats, None)
+                buf = ex.arena
+            ms = timed(ex, buf)
+            bad = int(ex.gave_up()) if hasattr(ex, "gave_up") else 0
+            out[name] = {"backend": ex.backend, "ms": round(ms, 4), "bus_GBps": round(n_floats * 4 / (ms * 1e-3) / 1e9 * 2 * (world - 1) / world, 1)}
+            if bad:
+                out[name]["barrier_gave_up_epoch"] = bad
+                out[name]["ms"] = None
+        except Exception as e:                  # noqa: BLE001 -- (raised on EVERY rank: see the docstring)
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            try:
+                if ex is not None and hasattr(ex, "close"):
+                    ex.close()
+            except Exception:                   # noqa: BLE001
+                pass
+            del ex
+            torch.cuda.empty_cache()
+    lib_ms, p2p_ms = out["library"].get("ms"), out["p2p"].get("ms")
+    out["choice"] = "p2p" if (p2p_ms is not None and (lib_ms is None or p2p_ms < lib_ms)) else "library"
     return out
 
 
@@ -405,6 +463,9 @@ def main():
                     "draw counter); auto = off (measured slower than stream launches on this ROCm)")
     ap.add_argument("--cu-budget", type=int, default=0, help="data-parallel A/B: the engine's launches on a CU-masked stream of that many "
                     "compute units (vbnn_ctx_create_cu_budget), the rest left to RCCL's channels; 0 = no mask")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "p2p"], help="N > 1: the gradient exchange -- the collective library "
+                    "(vbnn_comm over RCCL), the direct peer-to-peer reduce-scatter + all-gather (vbnn_p2p), or auto: both are timed on a 64 MB "
+                    "message at start-up and the faster one carries the step (comm.probe in the line); VBNN_EXCHANGE in the environment wins")
     ap.add_argument("--exchange-dtype", default="f32", choices=["f32", "bf16"], help="data-parallel exchange payload: fp32 (default, the "
                     "metric) or the optional bf16 copy (half the bytes, a DIFFERENT gradient: reported as an option, config.exchange_dtype)")
     args = ap.parse_args()
@@ -474,6 +535,14 @@ def main():
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)                     # (everything of this process from here on: fills, events, the step)
         opt["device_draw"] = True
+    xprobe = None
+    if use_dist and not os.environ.get("VBNN_EXCHANGE"):
+        if args.exchange == "p2p":
+            opt["exchange"] = "p2p"
+        elif args.exchange == "auto" and world > 1:
+            xprobe = probe_exchange_backends(torch, dist, rank, world, local_rank)
+            if xprobe["choice"] == "p2p":
+                opt["exchange"] = "p2p"
     eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist, stream=stream)
     if args.cu_budget > 0:
         torch.cuda.set_stream(eng.ctx.torch_stream)      # the masked stream is the process's stream from here on
@@ -645,6 +714,8 @@ def main():
         dist.all_gather_object(ident, (rank, local_rank, device_identity(torch, local_rank), os.getpid()))
         comm = {"backend": eng.comm_backend(), "payload": eng.exchange_dtype, "ranks_seen": [list(i) for i in ident],
                 "distinct_devices": len({i[2] for i in ident}), "allreduce": eng.time_buckets(5)}
+        if xprobe is not None:
+            comm["probe"] = xprobe
         if noex is not None:
             comm["step_without_exchange"] = noex
         if world > 1 and os.environ.get("VBNN_BENCH_OTHER_BACKEND", "1") != "0":
@@ -731,13 +802,15 @@ def main():
         try:
             del eng
             torch.cuda.empty_cache()
-            deep = side_config_row("deep", torch, dist, L, FusedMLP, fill_normal, min(args.steps, 20), min(args.warmup, 5), world, rank, use_dist)
+            deep = side_config_row("deep", torch, dist, L, FusedMLP, fill_normal, min(args.steps, 20), min(args.warmup, 5), world, rank, use_dist,
+                                   exchange=opt.get("exchange"))
         except Exception as e:                  # noqa: BLE001 -- never at the price of the headline
             deep = {"error": f"{type(e).__name__}: {e}"[:300]}
     sharded = None
     if use_dist and cfg["dtype"] == "bf16" and args.mode == "lrt" and args.S == 1 and not args.no_train_step and cfg.get("criterion", "nll") == "nll":
         try:
-            sharded = sharded_train_row(cfg, torch, dist, L, FusedMLP, fill_normal, min(args.steps, 20), min(args.warmup, 5), world, rank)
+            sharded = sharded_train_row(cfg, torch, dist, L, FusedMLP, fill_normal, min(args.steps, 20), min(args.warmup, 5), world, rank,
+                                        exchange=opt.get("exchange"))
         except Exception as e:                  # noqa: BLE001
             sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:

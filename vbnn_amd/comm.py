@@ -124,22 +124,36 @@ class P2PExchange:
     `process_group` (any backend) only carries the 128-byte IPC handles, once."""
 
     def __init__(self, ctx, rank, world, arena_floats, process_group=None):
+        """Collective over `process_group` when world > 1 -- and collective in FAILURE too: a rank that cannot allocate / export /
+        map says so in the handle exchange and in the agreement after the mapping, so that every rank raises together instead of
+        one rank leaving the others in an all-gather or a barrier (as comm.make_exchange does for RCCL)."""
         lib = L.lib()
         self.ctx, self.rank, self.world = ctx, rank, world
         h, arena = C.c_void_p(), C.c_void_p()
         mine = (C.c_ubyte * 128)()
-        L.check(lib.vbnn_p2p_create(ctx.h, rank, world, arena_floats, C.byref(h), C.byref(arena), mine))
-        self.h, self._ptr = h, arena.value
+        st = lib.vbnn_p2p_create(ctx.h, rank, world, arena_floats, C.byref(h), C.byref(arena), mine)
+        err = None if st == L.OK else (lib.vbnn_last_error() or b"?").decode()
+        self.h, self._ptr = (h, arena.value) if err is None else (None, None)
         if world > 1:
             import torch.distributed as dist
             box = [None] * world
-            dist.all_gather_object(box, bytes(mine), group=process_group)
-            allh = (C.c_ubyte * (128 * world)).from_buffer_copy(b"".join(box))
-            L.check(lib.vbnn_p2p_connect(h, allh))
-            # one HOST barrier before the first exchange: every rank has mapped every arena and flag page, and the device-side
-            # barriers' bounded poll only ever has to cover the skew of a running step, not another rank's start-up
-            dist.barrier(group=process_group)
+            dist.all_gather_object(box, (err, bytes(mine)), group=process_group)
+            bad = [(r, e) for r, (e, _) in enumerate(box) if e is not None]
+            if bad:
+                self.close()
+                raise L.VbnnError(f"vbnn_p2p_create failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}")
+            allh = (C.c_ubyte * (128 * world)).from_buffer_copy(b"".join(hb for _, hb in box))
+            st = lib.vbnn_p2p_connect(h, allh)
+            err = None if st == L.OK else (lib.vbnn_last_error() or b"?").decode()
+            box = [None] * world
+            dist.all_gather_object(box, err, group=process_group)        # (also the host barrier before the first exchange: every rank has
+            bad = [(r, e) for r, e in enumerate(box) if e is not None]   # mapped every arena and flag page when this returns)
+            if bad:
+                self.close()
+                raise L.VbnnError(f"vbnn_p2p_connect failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}")
         else:
+            if err is not None:
+                raise L.VbnnError(f"vbnn_p2p_create: {err}")
             L.check(lib.vbnn_p2p_connect(h, None))
         self._keep = _DevArray(self._ptr, arena_floats)
         self.arena = torch.as_tensor(self._keep, device=ctx.device)
