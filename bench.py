@@ -336,14 +336,33 @@ def probe_exchange_backends(torch, dist, rank, world, local_rank, n_floats=1 << 
         tt = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
+    # crash guard for the one path that has never seen a second device: rank 0 leaves a marker while the p2p probe runs; a run that
+    # finds the marker of an earlier run on this checkout (that run died inside its probe: a fault on a peer mapping kills the process,
+    # it cannot be caught) does not probe p2p again and says so
+    marker = os.path.join(ROOT, "gpurun_out", ".p2p_probe_inflight")
+    skip = torch.tensor([1 if os.path.exists(marker) else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(skip, op=dist.ReduceOp.MAX)
     for name in ("library", "p2p"):
         ex = None
+        if name == "p2p" and int(skip.item()):
+            out[name] = {"skipped": "a previous run on this checkout did not come back from its p2p probe (marker gpurun_out/.p2p_probe_inflight)"}
+            continue
+        if name == "p2p" and rank == 0:
+            try:
+                os.makedirs(os.path.dirname(marker), exist_ok=True)
+                with open(marker, "w") as f:
+                    f.write(f"world {world}\n")
+                    f.flush()
+                    os.fsync(f.fileno())
+            except OSError:
+                pass
         try:
             if name == "library":
                 ex = comm.make_exchange(ctx, rank, world, None)
                 buf = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
             else:
                 ex = comm.P2PExchange(ctx, rank, world, n_floats, None)
+                ex.set_timeout(5.0)                 # a probe that cannot see its peers gives up in seconds, not minutes
                 buf = ex.arena
             ms = timed(ex, buf)
             bad = int(ex.gave_up()) if hasattr(ex, "gave_up") else 0
@@ -361,6 +380,13 @@ def probe_exchange_backends(torch, dist, rank, world, local_rank, n_floats=1 << 
                 pass
             del ex
             torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 0 and os.path.exists(marker) and not int(skip.item()):
+        try:
+            os.remove(marker)
+        except OSError:
+            pass
     lib_ms, p2p_ms = out["library"].get("ms"), out["p2p"].get("ms")
     out["choice"] = "p2p" if (p2p_ms is not None and (lib_ms is None or p2p_ms < lib_ms)) else "library"
     return out

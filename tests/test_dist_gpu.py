@@ -181,6 +181,7 @@ def test_two_ranks_through_the_p2p_exchange_match_the_single_process_step(tmp_pa
 
 @pytest.mark.parametrize("world,exchange,dtype,hidden,I0,n_loc", [
     (1, "torch", "bf16", "48,36", 70, 64),
+    (1, "rccl", "bf16", "48,36", 70, 64),          # vbnn_comm_reduce_scatter / _all_gather: RCCL itself, a world of one (it wants a device per rank)
     (2, "torch", "bf16", "48,36", 70, 64), (3, "torch", "bf16", "48,36", 70, 64),
     (2, "p2p", "bf16", "48,36", 70, 64), (3, "p2p", "bf16", "48,36", 70, 64),
     # the wide configuration itself: K-major operands (no transposed shadows), the two-launch accGradParameters with its early
@@ -207,6 +208,8 @@ def test_sharded_update_exchange_leaves_bitwise_the_all_reduce_parameters(tmp_pa
         assert r.stdout.count("equal across ranks: True") == world, r.stdout[-1500:]
         if exchange == "p2p" and world > 1:
             assert r.stdout.count("exchange vbnn_p2p/ipc") == world, r.stdout[-1500:]
+        if exchange == "rccl":
+            assert r.stdout.count("exchange vbnn_comm/rccl") == world, r.stdout[-1500:]
         res[mode] = dict(np.load(out))
     a, b = res["allreduce"], res["sharded"]
     # (gloo's ring all-reduce adds three or more ranks' terms in an order that depends on where an element lies in the MESSAGE, and

@@ -265,6 +265,7 @@ struct EpiFwd {
         if (r_t) store4_out<T>(r_t + ((int64_t)un * ld_r + um), ln.orr, rv[0], rv[1], rv[2], rv[3]);
         return out;
     }
+    __device__ __forceinline__ bool folded_pre_needed() const { return false; }
     __device__ __forceinline__ Pre load_folded(int, int, const Lane&) const { return Pre{f32x4{0.f, 0.f, 0.f, 0.f}}; }
     __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre&, float (&t1)[4],
                                                  float (&t2)[4]) const {
@@ -399,6 +400,7 @@ struct EpiDx {
         for (int j = 0; j < 4; ++j) out[j] = 2.0f * Elt<T>::from(fp.x[j]) * a2[j];
         return out;
     }
+    __device__ __forceinline__ bool folded_pre_needed() const { return true; }
     __device__ __forceinline__ Pre load_folded(int um, int un, const Lane& ln) const { return load_fast(um, un, ln); }
     __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre& pre, float (&t1)[4],
                                                  float (&t2)[4]) const {
@@ -552,6 +554,7 @@ struct EpiDw {
     __device__ __forceinline__ bf16x4 shadow4(const bf16_t* p, int um, int un, const Lane& ln) const {
         return *reinterpret_cast<const bf16x4*>(p + ((int64_t)un * ld_w + um) + ln.os);
     }
+    __device__ __forceinline__ bool fast_pre_needed() const { return !(part == 1 && kl_scale == 0.f); }
     __device__ __forceinline__ Pre load_fast(int um, int un, const Lane& ln) const {
         // two UNCONDITIONAL loads whatever the part (a branch around a load costs one load latency per position): a
         // one-GEMM launch reads its one tensor twice from the same address instead
@@ -630,6 +633,7 @@ struct EpiDw {
         *reinterpret_cast<f32x4*>(grad_lv + ((int64_t)un * I + um) + ln.o) = gl;
         return f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    __device__ __forceinline__ bool folded_pre_needed() const { return kl_scale != 0.f; }     // (mu enters through the KL term only)
     __device__ __forceinline__ Pre load_folded(int um, int un, const Lane& ln) const {
         Pre p;
         p.mu = shadow4(mu_s, um, un, ln);

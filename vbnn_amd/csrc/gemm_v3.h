@@ -886,8 +886,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             for (int p0 = 0; p0 < 8; p0 += FB) {
                 if (lane_in) {
                     typename Epi::Pre pre[FB];
+                    if (epi.fast_pre_needed()) {              // (the d/dmeans half with kl_scale = 0 reads nothing: workgroup-uniform)
 #pragma unroll
-                    for (int b = 0; b < FB; ++b) pre[b] = epi.load_fast(wm0, wn0 + 4 * (p0 + b), eln);
+                        for (int b = 0; b < FB; ++b) pre[b] = epi.load_fast(wm0, wn0 + 4 * (p0 + b), eln);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < FB; ++b) pre[b] = typename Epi::Pre{};
+                    }
 #pragma unroll
                     for (int b = 0; b < FB; ++b) {
                         float t1[4], t2[4];
@@ -904,9 +909,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
 #pragma unroll
         for (int p0 = 0; p0 < 8; p0 += FB) {
             typename Epi::Pre pre[FB];
+            // (a functor whose folded epilogue reads nothing -- accGradParameters with the KL gradient left to the update sweep,
+            // kl_scale = 0: the default of the bf16 configuration -- skips the batch as a whole: one wave-uniform branch around
+            // all of its loads, not one around each)
+            if (!DUAL || epi.folded_pre_needed()) {
 #pragma unroll
-            for (int b = 0; b < FB; ++b)
-                pre[b] = DUAL ? epi.load_folded(wm0, wn0 + 4 * (p0 + b), eln) : epi.load_fast(wm0, wn0 + 4 * (p0 + b), eln);
+                for (int b = 0; b < FB; ++b)
+                    pre[b] = DUAL ? epi.load_folded(wm0, wn0 + 4 * (p0 + b), eln) : epi.load_fast(wm0, wn0 + 4 * (p0 + b), eln);
+            } else {
+#pragma unroll
+                for (int b = 0; b < FB; ++b) pre[b] = typename Epi::Pre{};
+            }
 #pragma unroll
             for (int b = 0; b < FB; ++b) {
                 const int p = p0 + b;
