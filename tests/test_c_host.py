@@ -102,6 +102,8 @@ CASES = [
     ("bf16", 256, [512, 256], 512, 1, 3, True, True),           # + update + the RCCL exchange (layerwise order)
     ("bf16", 784, [4096, 4096], 4096, 1, 2, True, False),       # the bench's configuration: K-major, split launch, dx-first
     ("bf16", 784, [4096, 4096], 4096, 1, 2, False, True),       # + RCCL: early d/dlvars messages, three all-reduces per step
+    ("bf16", 256, [512, 256], 512, 1, 3, True, "sharded"),      # the sharded-update exchange driven from C (a world of one): reduce-scatter,
+    ("bf16", 784, [4096, 4096], 4096, 1, 3, True, "sharded"),   # slice update, shadow + statistics all-gather, vbnn_stats_combine, transposes rebuilt
     ("f32", 784, [400, 400], 256, 1, 4, False, "graph"),        # the C host captures its step and replays it: own stream, device draw counter
     ("f32", 784, [400, 400], 100, 3, 3, False, "graph"),        # ... with S = 3 accumulating draws inside the graph
 ]
@@ -118,9 +120,11 @@ def test_c_host_gradient_arena_is_bitwise_the_python_engines(tmp_path, dtype, I0
     cmd = [exe, "--dtype", dtype, "--input", str(I0), "--hidden", ",".join(str(h) for h in hidden), "--classes", "10",
            "--batch", str(N), "--S", str(S), "--steps", str(steps), "--out", out]
     graph = comm == "graph"
+    sharded = comm == "sharded"
     comm = bool(comm) and not graph
     cmd += ["--update"] if update else []
     cmd += ["--comm"] if comm else []
+    cmd += ["--sharded"] if sharded else []
     cmd += ["--graph"] if graph else []
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VBNN_RCCL_PATH="/opt/rocm/lib/librccl.so.1")
     res = _children.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -132,6 +136,8 @@ def test_c_host_gradient_arena_is_bitwise_the_python_engines(tmp_path, dtype, I0
     opt = dict(var_init=1e-3, mu_init=1, B=1e6, S=S, mode="lrt", dtype=dtype, seed=3, input_size=I0, hidden=hidden,
                n_classes=10, fuse_kl=True, state=dict(learningRate=1e-3), meanState=dict(learningRate=1e-4),
                varState=dict(learningRate=5e-2))
+    if sharded:
+        opt["exchange_mode"] = "sharded"
     eng = FusedMLP(opt, force_reduce=comm)
     x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
     fill_normal(x, 3, 4, 0, 0)

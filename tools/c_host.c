@@ -13,7 +13,7 @@
  * vbnn_amd/engine.py:FusedMLP on the same configuration.
  *
  *   c_host --dtype f32|bf16 --input 784 --hidden 400,400 --classes 10 --batch 256 [--S 1] [--steps 2] [--update]
- *          [--comm] [--graph] [--kl-shadows] [--seed 3] --out arena.bin
+ *          [--comm [--sharded]] [--graph] [--kl-shadows] [--seed 3] --out arena.bin
  *   --graph: the context gets a stream of its own (vbnn_ctx_create_cu_budget), the draw counter lives on the device
  *   (vbnn_fwd_args.draw_dev, vbnn_sample), step 2 is CAPTURED (vbnn_capture_begin / _end) and steps 2.. are replays of it.
  *   arena.bin: int64 n_grads, double loss, int32 correct, int32 flags, then n_grads floats (the arena after the last
@@ -80,6 +80,8 @@ typedef struct {
 
 typedef struct {
     int dtype, esize, n_layers, n_classes, world, rank, dx_first;
+    int sharded;              /* --sharded: the sharded-update exchange (reduce-scatter by layer rows, slice update, shadow all-gather) */
+    double* stat_parts;       /* [world][layers][4] doubles: every rank's statistics of its row slices */
     int n_head_slots; float* head_slots;   /* vbnn_forward_head_slots x N x 16 floats, or 0 / NULL */
     int kl_in_update;         /* 1 (default for bf16): the arena holds the likelihood parts, vbnn_update adds the exact fp32 KL gradient (kl_add) */
     int direct;               /* fp32: operands as their producers left them (no packing launch, no squares, no transposes) */
@@ -288,6 +290,21 @@ static void dx_block(fused_mlp* m, int li, int64_t N, vbnn_dx_args* a) {
     a->w = v->mu_s.p; a->w2 = v->var_s.p; a->ld_w = v->mu_s.ld;
 }
 
+/* sharded-update exchange (engine.py: _scatter): layer li's messages after its accGradParameters -- `lv` / `mu`: reduce-scatter of the
+   d/dlvars / d/dmeans region by layer rows (rank r keeps the sums of rows [r O / G, (r + 1) O / G)); `small`: the bias gradient (and,
+   behind the last layer's, the final Linear's) as a plain all-reduce */
+static void fm_scatter(fused_mlp* m, int li, int lv, int mu, int small) {
+    layer_t* v = &m->vb[li];
+    const int64_t per = v->O * v->I / m->world;
+    if (lv) CHECK(vbnn_comm_reduce_scatter(m->comm, m->grads + v->bucket_off, per));
+    if (mu) CHECK(vbnn_comm_reduce_scatter(m->comm, m->grads + v->bucket_off + v->O * v->I, per));
+    if (small) {
+        const int64_t off = v->bucket_off + 2 * v->O * v->I;
+        const int64_t end = (li == m->n_layers - 1) ? m->n_grads : (v->bucket_off + v->bucket_n);
+        CHECK(vbnn_allreduce_grads(m->comm, m->grads + off, end - off));
+    }
+}
+
 /* ---- mlp.lua:76-84, fused. inputs: DEVICE pointer to N x input_size floats (row pitch ld), targets: device int32[N], 0-based */
 static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t* targets, int64_t N) {
     fm_alloc_batch(m, N);
@@ -375,14 +392,17 @@ static void fm_run(fused_mlp* m, const float* inputs, int64_t ld, const int32_t*
                    the mu GEMM still runs (d/dlvars is the first block of the layer's bucket) */
                 dd.part = 2;
                 CHECK(vbnn_acc_grad_parameters(g_ctx, m->dtype, &dd));
-                CHECK(vbnn_allreduce_grads(m->comm, m->grads + v->bucket_off, v->O * v->I));
+                if (m->sharded) fm_scatter(m, li, 1, 0, 0);
+                else CHECK(vbnn_allreduce_grads(m->comm, m->grads + v->bucket_off, v->O * v->I));
                 dd.part = 1;
                 msg_off = v->bucket_off + v->O * v->I;
             }
             CHECK(vbnn_acc_grad_parameters(g_ctx, m->dtype, &dd));
             if (li < nl - 1 && !v->bias_from_dw)
                 CHECK(vbnn_acc_grad_bias(g_ctx, m->dtype, v->g_s.p, v->g_s.ld, N, v->O, 1.0f, accumulate, v->gradBias));
-            if (m->comm) {                                        /* the final Linear's gradients ride in the last layer's message */
+            if (m->comm && m->sharded) {
+                fm_scatter(m, li, !early, 1, 1);
+            } else if (m->comm) {                                 /* the final Linear's gradients ride in the last layer's message */
                 const int64_t n = ((li == nl - 1) ? m->n_grads : (v->bucket_off + v->bucket_n)) - msg_off;
                 CHECK(vbnn_allreduce_grads(m->comm, m->grads + msg_off, n));
             }
@@ -401,8 +421,59 @@ static void fm_finish(fused_mlp* m) {                             /* end of the 
 
 /* mlp:update + VBLinear:update (mlp.lua:117-142, VBLinear.lua:124-166) in one call, which also leaves the operand
    shadows and prior statistics of the next minibatch */
+/* the same update with the parameters SHARDED by layer rows (engine.py: _update_sharded): vbnn_update on this rank's rows, then the
+   all-gather of the operand shadows and of the slices' statistics, vbnn_stats_combine, transposed shadows rebuilt locally */
+static void fm_update_sharded(fused_mlp* m, float lr, float lr_mu, float lr_lv) {
+    const int64_t H = m->sizes[m->n_layers];
+    const int G = m->world, R = m->rank, n = m->n_layers;
+    CHECK(vbnn_sgd_step(g_ctx, m->weight3, m->gradWeight3, m->n_classes * H, lr));
+    CHECK(vbnn_sgd_step(g_ctx, m->bias3, m->gradBias3, m->n_classes, lr));
+    vbnn_update_desc d[MAX_LAYERS];
+    memset(d, 0, sizeof d);
+    double* mine = m->stat_parts + (size_t)R * n * 4;
+    for (int k = 0; k < n; ++k) {
+        layer_t* v = &m->vb[k];
+        CHECK(vbnn_sgd_step(g_ctx, v->bias, v->gradBias, v->O, lr));
+        v->t += 1;
+        const int64_t nr = v->O / G, r0 = (int64_t)R * nr, o = r0 * v->I;
+        double st[4];                                             /* in: the WHOLE layer's pre-update statistics */
+        CHECK(vbnn_buf_download(g_ctx, st, v->stats, sizeof st));
+        CHECK(vbnn_buf_upload(g_ctx, mine + 4 * k, st, sizeof st));
+        vbnn_update_desc* e = &d[k];
+        e->means = v->means + o; e->lvars = v->lvars + o; e->O = nr; e->I = v->I;
+        e->mu_s = (char*)v->mu_s.p + r0 * v->mu_s.ld * m->esize; e->var_s = (char*)v->var_s.p + r0 * v->var_s.ld * m->esize; e->ld_w = v->mu_s.ld;
+        e->stats = mine + 4 * k; e->grad_mu = v->grad_mu + o; e->grad_lv = v->grad_lv + o;
+        e->m_mu = v->m_mu + o; e->v_mu = v->v_mu + o; e->m_lv = v->m_lv + o; e->v_lv = v->v_lv + o;     /* (allocated whole here; a rank touches its rows) */
+        e->mu.lr = lr_mu; e->mu.beta1 = 0.9f; e->mu.beta2 = 0.999f; e->mu.eps = 1e-8f; e->mu.lambda = 1.0f; e->mu.t = v->t;
+        e->lv.lr = lr_lv; e->lv.beta1 = 0.9f; e->lv.beta2 = 0.999f; e->lv.eps = 1e-8f; e->lv.lambda = 1.0f; e->lv.t = v->t;
+        e->lr_bias = lr; e->B = m->B; e->kl_add = 1.0f;
+    }
+    vbnn_pack_desc w3;
+    memset(&w3, 0, sizeof w3);
+    w3.src = m->weight3; w3.rows = m->n_classes; w3.cols = H; w3.ld_src = H;
+    w3.dst = m->w3_s.p; w3.ld_dst = m->w3_s.ld; w3.dstT = NULL; w3.ld_dstT = 0;
+    CHECK(vbnn_update(g_ctx, m->dtype, n, d, &w3));
+    double* stats[MAX_LAYERS];
+    for (int k = 0; k < n; ++k) {
+        layer_t* v = &m->vb[k];
+        CHECK(vbnn_comm_all_gather(m->comm, v->mu_s.p, v->O / G * v->mu_s.ld * m->esize));
+        CHECK(vbnn_comm_all_gather(m->comm, v->var_s.p, v->O / G * v->var_s.ld * m->esize));
+        stats[k] = v->stats;
+    }
+    CHECK(vbnn_comm_all_gather(m->comm, m->stat_parts, (int64_t)n * 4 * 8));
+    CHECK(vbnn_comm_finish(m->comm));
+    CHECK(vbnn_stats_combine(g_ctx, n, G, m->stat_parts, stats));
+    for (int k = 0; k < n; ++k) {
+        layer_t* v = &m->vb[k];
+        if (!v->use_muT) continue;
+        CHECK(vbnn_transpose_packed(g_ctx, m->dtype, v->mu_s.p, v->mu_s.ld, v->O, v->I, v->muT_s.p, v->muT_s.ld));
+        CHECK(vbnn_transpose_packed(g_ctx, m->dtype, v->var_s.p, v->var_s.ld, v->O, v->I, v->varT_s.p, v->varT_s.ld));
+    }
+}
+
 static void fm_update(fused_mlp* m, float lr, float lr_mu, float lr_lv) {
     fm_finish(m);
+    if (m->sharded) { fm_update_sharded(m, lr, lr_mu, lr_lv); return; }
     const int64_t H = m->sizes[m->n_layers];
     CHECK(vbnn_sgd_step(g_ctx, m->weight3, m->gradWeight3, m->n_classes * H, lr));
     CHECK(vbnn_sgd_step(g_ctx, m->bias3, m->gradBias3, m->n_classes, lr));
@@ -483,7 +554,12 @@ int main(int argc, char** argv) {
     }
     fused_mlp net;
     fm_new(&net, dtype, sizes, n_layers, n_classes, seed, 1e-3, 1e6f, (float)S, with_comm);
-    if (arg_flag(argc, argv, "--kl-shadows")) net.kl_in_update = 0;    /* A/B: the KL gradient fused into the accGradParameters epilogue, from the bf16 shadows */
+    if (arg_flag(argc, argv, "--kl-shadows")) net.kl_in_update = 0;
+    if (arg_flag(argc, argv, "--sharded")) {                      /* the sharded-update exchange instead of the all-reduce (a world of one here) */
+        if (!with_comm || dtype != VBNN_BF16) { fprintf(stderr, "c_host: --sharded needs --comm and --dtype bf16\n"); return 1; }
+        net.sharded = 1; net.kl_in_update = 1;
+        net.stat_parts = (double*)dev_alloc((size_t)net.world * n_layers * 4 * 8);
+    }    /* A/B: the KL gradient fused into the accGradParameters epilogue, from the bf16 shadows */
     if (with_graph) net.draw_dev = (uint32_t*)dev_alloc(4);
 
     /* the synthetic minibatch of the parity tests: x ~ N(0,1) from the Philox contract (stream DATA), targets by row */
