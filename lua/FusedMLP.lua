@@ -37,6 +37,13 @@ function FusedMLP.new(opt)
     -- opt.kl_in_update (default: true for bf16, as engine.py): the gradient arena holds the LIKELIHOOD parts and update() adds the
     -- exact fp32 KL gradient (vbnn_update_desc.kl_add); false = the KL part fused into the accGradParameters epilogue (A/B)
     if opt.kl_in_update == nil then self.kl_in_update = (self.dtype == C.VBNN_BF16) else self.kl_in_update = opt.kl_in_update end
+    -- opt.exchange_mode = 'sharded' (data-parallel, bf16): the sharded-update exchange instead of the all-reduce -- reduce-scatter of the
+    -- gradients by layer rows, update() on this rank's rows, all-gather of the operand shadows + statistics (INTEGRATION.md section 4)
+    self.sharded = opt.exchange_mode == 'sharded'
+    if self.sharded then
+        assert(opt.comm_id and self.dtype == C.VBNN_BF16, "exchange_mode = 'sharded': data-parallel (comm_id), bf16")
+        self.kl_in_update = true
+    end
     self.n_classes = opt.n_classes
     assert(self.n_classes <= 16, 'FusedMLP.lua drives the fused classifier head (mlp.lua:29-32); see engine.py for wider ones')
     local sizes = { opt.input_size }
@@ -173,6 +180,72 @@ function FusedMLP:sample()                                        -- mlp.lua:69-
 end
 
 -- mlp.lua:76-84, fused. inputs: DEVICE pointer to N x input_size floats (row pitch ld), targets: device int32[N], 0-based
+-- sharded-update exchange: layer li's messages after its accGradParameters (tools/c_host.c: fm_scatter)
+function FusedMLP:_scatter(li, lv, mu, small)
+    local v = self.vb[li]
+    local per = v.O * v.I / self.world
+    if lv then check(C.vbnn_comm_reduce_scatter(self.comm, f32(self.grads) + v.bucket_off, per)) end
+    if mu then check(C.vbnn_comm_reduce_scatter(self.comm, f32(self.grads) + v.bucket_off + v.O * v.I, per)) end
+    if small then
+        local off = v.bucket_off + 2 * v.O * v.I
+        local stop = (li == #self.vb) and self.n_grads or (v.bucket_off + v.bucket_n)
+        check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + off, stop - off))
+    end
+end
+
+-- the update with the parameters SHARDED by layer rows (tools/c_host.c: fm_update_sharded; engine.py: _update_sharded)
+function FusedMLP:_update_sharded(opt)
+    local lr = opt.state.learningRate
+    local H, G, R, n = self.sizes[#self.sizes], self.world, self.rank, #self.vb
+    check(C.vbnn_sgd_step(vb.ctx, f32(self.weight3), self.gradWeight3, self.n_classes * H, lr))
+    check(C.vbnn_sgd_step(vb.ctx, f32(self.bias3), self.gradBias3, self.n_classes, lr))
+    self.stat_parts = self.stat_parts or vb.alloc(G * n * 4 * 8)
+    local parts = ffi.cast('double*', self.stat_parts)
+    local mine = parts + R * n * 4
+    local d = ffi.new('vbnn_update_desc[?]', n)
+    local st = ffi.new('double[4]')
+    for k, v in ipairs(self.vb) do
+        check(C.vbnn_sgd_step(vb.ctx, f32(v.bias), v.gradBias, v.O, lr))
+        v.t = v.t + 1
+        local nr = v.O / G
+        local r0 = R * nr
+        local o = r0 * v.I
+        check(C.vbnn_buf_download(vb.ctx, st, v.stats, 32))          -- in: the WHOLE layer's pre-update statistics
+        check(C.vbnn_buf_upload(vb.ctx, mine + 4 * (k - 1), st, 32))
+        local e = d[k - 1]
+        e.means, e.lvars, e.O, e.I = f32(v.means) + o, f32(v.lvars) + o, nr, v.I
+        e.mu_s = ffi.cast('char*', v.mu_s.p) + r0 * v.mu_s.ld * self.esize
+        e.var_s = ffi.cast('char*', v.var_s.p) + r0 * v.var_s.ld * self.esize
+        e.ld_w = v.mu_s.ld
+        e.stats, e.grad_mu, e.grad_lv = mine + 4 * (k - 1), v.grad_mu + o, v.grad_lv + o
+        e.m_mu, e.v_mu, e.m_lv, e.v_lv = f32(v.m_mu) + o, f32(v.v_mu) + o, f32(v.m_lv) + o, f32(v.v_lv) + o
+        for key, cfg in pairs({ mu = opt.meanState, lv = opt.varState }) do
+            e[key].lr, e[key].beta1, e[key].beta2 = cfg.learningRate, cfg.beta1 or 0.9, cfg.beta2 or 0.999
+            e[key].eps, e[key].lambda, e[key].t = cfg.epsilon or 1e-8, cfg.lambda or 1, v.t
+        end
+        e.lr_bias, e.B, e.kl_add = lr, self.B, 1
+    end
+    local w3 = ffi.new('vbnn_pack_desc[1]')
+    w3[0].src, w3[0].rows, w3[0].cols, w3[0].ld_src = f32(self.weight3), self.n_classes, H, H
+    w3[0].dst, w3[0].ld_dst, w3[0].dstT, w3[0].ld_dstT = self.w3_s.p, self.w3_s.ld, nil, 0
+    check(C.vbnn_update(vb.ctx, self.dtype, n, d, w3))
+    local stats = ffi.new('double*[?]', n)
+    for k, v in ipairs(self.vb) do
+        check(C.vbnn_comm_all_gather(self.comm, v.mu_s.p, v.O / G * v.mu_s.ld * self.esize))
+        check(C.vbnn_comm_all_gather(self.comm, v.var_s.p, v.O / G * v.var_s.ld * self.esize))
+        stats[k - 1] = ffi.cast('double*', v.stats)
+    end
+    check(C.vbnn_comm_all_gather(self.comm, self.stat_parts, n * 4 * 8))
+    check(C.vbnn_comm_finish(self.comm))
+    check(C.vbnn_stats_combine(vb.ctx, n, G, parts, stats))
+    for _, v in ipairs(self.vb) do
+        if v.use_muT then
+            check(C.vbnn_transpose_packed(vb.ctx, self.dtype, v.mu_s.p, v.mu_s.ld, v.O, v.I, v.muT_s.p, v.muT_s.ld))
+            check(C.vbnn_transpose_packed(vb.ctx, self.dtype, v.var_s.p, v.var_s.ld, v.O, v.I, v.varT_s.p, v.varT_s.ld))
+        end
+    end
+end
+
 function FusedMLP:run(inputs, ld, targets, N)
     self:_alloc_batch(N)
     local accumulate = self.first and 0 or 1
@@ -285,7 +358,8 @@ function FusedMLP:run(inputs, ld, targets, N)
                 -- mu GEMM still runs (d/dlvars is the first block of the layer's bucket)
                 dd.part = 2
                 check(C.vbnn_acc_grad_parameters(vb.ctx, self.dtype, dd))
-                check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + v.bucket_off, v.O * v.I))
+                if self.sharded then self:_scatter(li, true, false, false)
+                else check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + v.bucket_off, v.O * v.I)) end
                 dd.part = 1
                 msg_off = v.bucket_off + v.O * v.I
             end
@@ -293,7 +367,9 @@ function FusedMLP:run(inputs, ld, targets, N)
             if li < #self.vb and not v.bias_from_dw then
                 check(C.vbnn_acc_grad_bias(vb.ctx, self.dtype, v.g_s.p, v.g_s.ld, N, v.O, 1, accumulate, v.gradBias))
             end
-            if self.comm then                                     -- the final Linear's gradients ride in the last layer's message
+            if self.comm and self.sharded then
+                self:_scatter(li, not early, true, true)
+            elseif self.comm then                                 -- the final Linear's gradients ride in the last layer's message
                 local n = ((li == #self.vb) and self.n_grads or (v.bucket_off + v.bucket_n)) - msg_off
                 check(C.vbnn_allreduce_grads(self.comm, f32(self.grads) + msg_off, n))
             end
@@ -313,6 +389,7 @@ end
 -- shadows and prior statistics of the next minibatch; `log` (a FloatTensor-free double[14 * layers] on the device)
 function FusedMLP:update(opt, log14)
     self:finish()
+    if self.sharded then return self:_update_sharded(opt) end
     local lr = opt.state.learningRate
     local H = self.sizes[#self.sizes]
     check(C.vbnn_sgd_step(vb.ctx, f32(self.weight3), self.gradWeight3, self.n_classes * H, lr))

@@ -78,7 +78,8 @@ def test_lua_fused_mlp_issues_the_calls_of_the_c_host_in_the_same_order():
         return out
 
     pairs = [("fm_run", lua_fn(":run", ":finish")), ("fm_prepare", lua_fn(":prepare", ":sample")),
-             ("fm_update", lua_fn(":update", ":calc_lc")), ("fm_alloc_batch", lua_fn(":_alloc_batch", ":resetGradients"))]
+             ("fm_update", lua_fn(":update", ":calc_lc")), ("fm_alloc_batch", lua_fn(":_alloc_batch", ":resetGradients")),
+             ("fm_scatter", lua_fn(":_scatter", ":_update_sharded")), ("fm_update_sharded", lua_fn(":_update_sharded", ":run"))]
     for cname, lbody in pairs:
         cc = [n for n in _c_calls(c_fn(cname)) if n not in ("vbnn_last_error",)]
         ll = lua_calls(lbody)
