@@ -394,20 +394,34 @@ struct EpiDx {
         p.x = *reinterpret_cast<const typename V4<T>::type*>(x + ((int64_t)un * ld_x + um) + ln.ox);
         return p;
     }
+    // The ReLU mask of the module in between rides THROUGH pass 2 in the accumulator itself (r04): where the layer input is not
+    // positive the fold leaves a quiet NaN instead of 2 x . acc2 (= 0 there anyway), the mean GEMM accumulates on top of it -- NaN + c
+    // stays NaN, element by element -- and the final epilogue reads the mask back as (a != a): it no longer re-reads x (33.5 MB of an
+    // HBM-bound store burst at 4096 x 4096; handing the mask over as 128 bits per lane had cost more than the read, r03). The values
+    // are bitwise what they were. (A genuine NaN of an unmasked element -- a diverged run -- is zeroed in g_prev with it; the loss and
+    // every other tensor still show it.)
     __device__ __forceinline__ f32x4 fold(int, int, const Lane&, f32x4 a2, const FPre& fp) const {
         f32x4 out;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[j] = 2.0f * Elt<T>::from(fp.x[j]) * a2[j];
+        for (int j = 0; j < 4; ++j) {
+            const float xv = Elt<T>::from(fp.x[j]);
+            out[j] = (relu_mask && !(xv > 0.f)) ? __builtin_nanf("") : 2.0f * xv * a2[j];
+        }
         return out;
     }
-    __device__ __forceinline__ bool folded_pre_needed() const { return true; }
-    __device__ __forceinline__ Pre load_folded(int um, int un, const Lane& ln) const { return load_fast(um, un, ln); }
+    __device__ __forceinline__ bool folded_pre_needed() const { return r_prev_t != nullptr; }
+    __device__ __forceinline__ Pre load_folded(int um, int un, const Lane& ln) const {       // (r alone: the mask is in the accumulator)
+        Pre p;
+        p.x = typename V4<T>::type{};
+        if (r_prev_t) p.r = vbnn_load_last_use(reinterpret_cast<const typename V4<T>::type*>(r_prev_t + ((int64_t)un * ld_r_prev + um) + ln.orp));
+        else p.r = typename V4<T>::type{};
+        return p;
+    }
     __device__ __forceinline__ void apply_folded(int um, int un, const Lane& ln, f32x4 a, f32x4, const Pre& pre, float (&t1)[4],
                                                  float (&t2)[4]) const {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float xv = Elt<T>::from(pre.x[j]);
-            t1[j] = (relu_mask && !(xv > 0.f)) ? 0.f : a[j];
+            t1[j] = (relu_mask && a[j] != a[j]) ? 0.f : a[j];
             t2[j] = t1[j] * Elt<T>::from(pre.r[j]);
         }
         const int64_t ub = (int64_t)un * ld_gp + um;
