@@ -40,6 +40,21 @@ inline int g_v3_min_k = 704;        // shortest K the shape selection gives to t
 #ifndef V3_ST
 #define V3_ST(k) do { } while (0)
 #endif
+// (the same for the alternating K step's cluster stamps: tools/lab/pst.h)
+#ifndef V3_PST
+#define V3_PST_DECL
+#define V3_PST(k) do { } while (0)
+#define V3_PST_ACC() do { } while (0)
+#define V3_PST_PASS_BEGIN() do { } while (0)
+#define V3_PST_PASS_END() do { } while (0)
+#define V3_PST_FLUSH(w, l) do { } while (0)
+#endif
+#ifndef V3_PP
+#define V3_PP 1                     // the alternating (M cluster / C cluster) K step of the full-height loop; 0: both halves in phase
+#endif
+#ifndef V3_PP_DMA
+#define V3_PP_DMA 2                 // where a phase's four pieces are issued (kstep_pp): 0 M cluster behind the reads, 1 C cluster, 2 M cluster between the reads, 3 two and two
+#endif
 
 
 // AK / BK: the operand is stored K-MAJOR -- element (row, k) at X[k * ld + row], i.e. the untransposed activation /
@@ -68,6 +83,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     static_assert(SPLIT == HM && (!HM || (AK && BK)), "the pair-split launch is the half-height K-major form");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     V3_ST(0);
+    V3_PST_DECL
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform on the scalar side
@@ -500,6 +516,148 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
             ka += da; kb += db;
         };
+        // ---- V3_PP: the same K step as two ALTERNATING clusters per phase, the workgroup's two halves one cluster apart
+        //   M cluster  every LDS read of the phase (A part: 8 fragments; phase 0 also the step's 8 B fragments) and the phase's four
+        //              pieces, then s_waitcnt vmcnt(8 | 10) lgkmcnt(0) + s_barrier
+        //   C cluster  the phase's 32 MFMAs, nothing else, then s_barrier
+        // Waves 4-7 (the SIMD partners of waves 0-3) enter the pass one barrier late and waves 0-3 leave it one barrier late, so
+        // between any two barriers one wave of every SIMD is in an M cluster and the other in a C cluster: the matrix pipe gets an
+        // uninterrupted stream from one wave while the other pays the LDS round trips and the pieces' issue stalls, instead of both
+        // waves of a SIMD paying them at the same time (kstep above: both halves in the same phase behind every barrier).
+        // Same pieces in the same order as kstep, so the same counted waits; same MFMA order per accumulator, so the same bits.
+        // RAW: a wave waits for its pieces at the END of an M cluster; the first read of that data is by the other half, behind
+        //      that barrier, in the next slot. WAR: a part is refilled from the M cluster that follows, by at least one barrier,
+        //      the slot in which the late half read it (its reads retired by the lgkmcnt(0) in front of that slot's barrier).
+        auto kstep_pp = [&](const int t, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
+            const bool n1 = TAIL ? (t + 1 < nk) : true, n2 = TAIL ? (t + 2 < nk) : true;
+            const int so_a1 = ka + da, so_a2 = ka + 2 * da, so_b2 = kb + 2 * db;
+            const unsigned oa_next = oa ^ (2u * V3_APART);
+            const unsigned char* sb = lds + 4 * V3_APART + ob;
+            bf16x8 bf[2][4];
+            bf16x4 bl[2][4], bh[2][4];
+            auto tr_issue4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x4 (&l)[4], bf16x4 (&h)[4]) {
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+                asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+                             "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+                             "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+                             "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
+                             : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
+                             : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI)
+                             : "memory");
+            };
+            auto landed4 = [&](bf16x4 (&l)[4], bf16x4 (&h)[4]) {
+                asm volatile("" : "+v"(l[0]), "+v"(h[0]), "+v"(l[1]), "+v"(h[1]), "+v"(l[2]), "+v"(h[2]), "+v"(l[3]), "+v"(h[3])::"memory");
+            };
+            auto phase = [&](auto P_c) {
+                constexpr int P = decltype(P_c)::value;
+                const unsigned char* sa = lds + oa + P * V3_APART;
+                bf16x8 af[2][4];
+                bf16x4 al[2][4], ah[2][4];
+                // ---------------- M cluster
+                V3_PST(0);
+                // the phase's read groups (four fragments each): phase 0 reads the step's B fragments (both k-halves) first
+                auto rd_b = [&](auto s_c) {
+                    constexpr int S = decltype(s_c)::value;
+                    if constexpr (BK) {
+                        const unsigned bb = (unsigned)(uintptr_t)(ldsb_t)sb;
+                        tr_issue4(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], std::integral_constant<int, S * 16384>(),
+                                  std::integral_constant<int, S * 16384 + 2048>(), bl[S], bh[S]);
+                    } else {
+                        load_b(sb, s_c, bf[S]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                auto rd_a = [&](auto s_c) {
+                    constexpr int S = decltype(s_c)::value;
+                    if constexpr (AK) {
+                        const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
+                        tr_issue4(ba + a_tr[0], ba + a_tr[1], ba + a_tr[2], ba + a_tr[3], std::integral_constant<int, S * 8192>(),
+                                  std::integral_constant<int, S * 8192 + 1024>(), al[S], ah[S]);
+                    } else {
+                        load_a(sa, s_c, af[S]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // the phase's four pieces, in issue order k = 0..3 (the same pieces in the same order as kstep)
+                auto piece = [&](int k) {
+                    if constexpr (P == 0) {
+                        if (k == 0 && n1) dma_a_at(oa_next, so_a1, c1, c0);
+                        if (k == 1 && n1) dma_a_at(oa_next, so_a1, c1, c1);
+                        if (k == 2 && n2) dma_b_at(ob2, so_b2, c0);
+                        if (k == 3 && n2) dma_b_at(ob2, so_b2, c1);
+                    } else {
+                        if (k == 0 && n2) dma_a_at(oa, so_a2, c0, c0);
+                        if (k == 1 && n2) dma_a_at(oa, so_a2, c0, c1);
+                        if (k == 2 && n2) dma_b_at(ob2, so_b2, c2);
+                        if (k == 3 && n2) dma_b_at(ob2, so_b2, c3);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // V3_PP_DMA: 0 reads, then the four pieces | 1 all four pieces between the C cluster's MFMAs | 2 pieces BETWEEN the read
+                // groups (the texture path works on a piece while the LDS works on the reads) | 3 two between the read groups, two in C
+                constexpr int MP = V3_PP_DMA == 1 ? 0 : V3_PP_DMA == 3 ? 2 : 4;       // pieces issued in the M cluster
+                constexpr bool MIX = V3_PP_DMA >= 2;
+                if constexpr (P == 0) {
+                    rd_b(c0); if (MIX) piece(0);
+                    rd_b(c1); if (MIX) piece(1);
+                    rd_a(c0); if (MIX && MP == 4) piece(2);
+                    rd_a(c1); if (MIX && MP == 4) piece(3);
+                } else {
+                    rd_a(c0); if (MIX) { piece(0); if (MP == 4) piece(1); }
+                    rd_a(c1); if (MIX) { if (MP == 4) { piece(2); piece(3); } else piece(1); }
+                }
+                if constexpr (V3_PP_DMA == 0) { piece(0); piece(1); piece(2); piece(3); }
+                V3_PST(1);
+                // the counted wait of kstep, less the pieces of this phase that are not issued yet (4 - MP)
+                if constexpr (P == 0) {
+                    if (TAIL && t == nk - 1) v2_wait_barrier<0>();
+                    else if (TAIL && t == nk - 2) v2_wait_barrier<(MP == 0 ? 6 : 8)>();      // (the phase's B pieces do not exist: n2 false)
+                    else v2_wait_barrier<6 + MP>();
+                } else {
+                    if (TAIL && t >= nk - 2) { if (t == nk - 1) v2_wait_barrier<0>(); else v2_wait_barrier<2>(); } else v2_wait_barrier<4 + MP>();
+                }
+                if constexpr (P == 0 && BK) {
+                    landed4(bl[0], bh[0]); landed4(bl[1], bh[1]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bf[s2][j] = __builtin_shufflevector(bl[s2][j], bh[s2][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                if constexpr (AK) {
+                    landed4(al[0], ah[0]); landed4(al[1], ah[1]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[s2][i] = __builtin_shufflevector(al[s2][i], ah[s2][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---------------- C cluster
+                V3_PST(2);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[4 * P + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], bf[s2][j], acc[4 * P + i][j], 0, 0, 0);
+                        if constexpr (MP < 4) {                      // the C cluster's pieces: after MFMAs 4, 12, 20, 28 (all four) or 12, 28 (two)
+                            if (MP == 0 && (i & 1) == 0) piece(2 * s2 + (i >> 1));
+                            if (MP == 2 && i == 2) piece(2 + s2);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                V3_PST(3);
+                V3_PST_ACC();
+                asm volatile("s_barrier" ::: "memory");
+            };
+            phase(c0);
+            phase(c1);
+            oa = oa_next;
+            ob = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+            ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
+            ka += da; kb += db;
+        };
         if constexpr (HM) {
             // ---- the half-height form, fragments read ONE STEP AHEAD: one phase per K step on the wave's 64 x 64 tile
             // (acc[0..3][]). The step's B fragments (both k-halves) and its first A pair are read from LDS at the END of the
@@ -607,6 +765,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             return;
         }
         int t = 0;
+        if constexpr (V3_PP != 0) {
+            // every wave: the pieces of (0, 0) have landed, for everybody behind the barrier; then the late half's extra barrier
+            if (nk > 1) v2_wait_barrier<8>(); else v2_wait_barrier<2>();
+            V3_PST_PASS_BEGIN();
+            if (wave >= 4) asm volatile("s_barrier" ::: "memory");
+            for (; t + 2 < nk; ++t) kstep_pp(t, std::false_type());
+            for (; t < nk; ++t) kstep_pp(t, std::true_type());
+            if (wave < 4) asm volatile("s_barrier" ::: "memory");
+            V3_PST_PASS_END();
+            V3_PST_FLUSH(wave, lane);
+            return;
+        }
         for (; t + 2 < nk; ++t) kstep(t, std::false_type());
         for (; t < nk; ++t) kstep(t, std::true_type());
     };
