@@ -3,10 +3,10 @@
 
 A `ds_read_b64_tr_b16` issued by one asm statement is waited for by a LATER one; hipcc knows nothing about the
 load in flight, so nothing in between may read or write its destination registers (a compiler-inserted copy or spill
-there would move garbage). This script compiles csrc/gemm.hip to assembly and checks exactly that for every
+there would move garbage). This script compiles csrc/gemm_fwd.hip, gemm_dx.hip and gemm_dw.hip to assembly and checks exactly that for every
 gemm_nt_v3 / gemm_nt_v2 instantiation with a K-major operand. LDS operations return in order, so a counted
 `s_waitcnt lgkmcnt(N)` retires all but the N youngest of them: the reads are tracked as a FIFO. Run it after any change to gemm_v3.h or to the compiler:
-    python3 tools/audit_tr_reads.py        (CPU only; ~2 min)
+    python3 tools/audit_tr_reads.py        (CPU only; ~6 min)
 """
 import os, re, subprocess, sys, tempfile
 
@@ -24,12 +24,14 @@ def regs_of(tok):
 
 
 def main():
+    txt = ""
     with tempfile.TemporaryDirectory() as d:
-        asm = os.path.join(d, "gemm.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include",
-                        f"-I{ROOT}/vbnn_amd/csrc", "-S", "--cuda-device-only", "-o", asm, f"{ROOT}/vbnn_amd/csrc/gemm.hip"],
-                       check=True, stderr=subprocess.DEVNULL)
-        txt = open(asm).read()
+        for src in ("gemm_fwd.hip", "gemm_dx.hip", "gemm_dw.hip"):          # the translation units that instantiate the pipelined kernels
+            asm = os.path.join(d, src + ".s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include",
+                            f"-I{ROOT}/vbnn_amd/csrc", "-S", "--cuda-device-only", "-o", asm, f"{ROOT}/vbnn_amd/csrc/{src}"],
+                           check=True, stderr=subprocess.DEVNULL)
+            txt += open(asm).read() + "\n"
     total_bad, kernels = 0, 0
     names = re.findall(r"^(_Z10gemm_nt_v3ILb[01]E(?:Lb1ELb[01]|Lb0ELb1)\S+):", txt, re.M)
     names += re.findall(r"^(_Z10gemm_nt_v2I\S+?Lb1EEv\S+):", txt, re.M)

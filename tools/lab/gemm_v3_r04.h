@@ -21,11 +21,10 @@
 //   LDS         160 KiB = A parts [2 K steps][2 phases] x 16 KiB + B tiles [3 K steps] x 32 KiB.
 //               A part P holds the 2 x 64 rows the two wave rows use in phase P, so it is free for refill after that
 //               phase: A is double-buffered at PHASE granularity, B triple-buffered at K-step granularity.
-//   per phase   two clusters, the workgroup's halves (waves 0-3 | 4-7: the two waves of every SIMD) one cluster apart (kstep_pp):
-//               M: 8 (16 in phase 0) fragment reads with the phase's 4 DMAs between them -> s_waitcnt vmcnt(8 | 10) lgkmcnt(0), s_barrier
-//               C: 32 MFMAs -> s_barrier
-//               DMAs:  phase 0 of step t: A part 1 of t+1 (x2), B of t+2 (x2);  phase 1 of step t: A part 0 of t+2 (x2), B of t+2 (x2)
-//               every DMA is in flight for at least four clusters (two of them 32 MFMAs of its own wave) before its data is needed.
+//   per phase   s_waitcnt vmcnt(8 | 10) lgkmcnt(0) -> s_barrier (one asm, v2_wait_barrier) -> 8 (16 in phase 0) ds_read_b128 + 32 MFMA, with 4 DMAs issued
+//               between the MFMAs:  phase 0 of step t: A part 1 of t+1 (x2), B of t+2 (x2)
+//                                   phase 1 of step t: A part 0 of t+2 (x2), B of t+2 (x2)
+//               every DMA is in flight for at least two phases (64 MFMAs per wave) before its data is needed.
 #pragma once
 #include "gemm_v2.h"
 
@@ -40,6 +39,23 @@ inline int g_v3_min_k = 704;        // shortest K the shape selection gives to t
 // library does not.
 #ifndef V3_ST
 #define V3_ST(k) do { } while (0)
+#endif
+// (the same for the alternating K step's cluster stamps: tools/lab/pst.h)
+#ifndef V3_PST
+#define V3_PST_DECL
+#define V3_PST(k) do { } while (0)
+#define V3_PST_ACC() do { } while (0)
+#define V3_PST_PASS_BEGIN() do { } while (0)
+#define V3_PST_PASS_END() do { } while (0)
+#define V3_PST_FLUSH(w, l) do { } while (0)
+#define V3_PST_WAIT_BARRIER(N) v2_wait_barrier<N>()
+#define V3_PSTM(i) do { } while (0)
+#endif
+#ifndef V3_PP
+#define V3_PP 1                     // the alternating (M cluster / C cluster) K step of the full-height loop; 0: both halves in phase
+#endif
+#ifndef V3_PP_DMA
+#define V3_PP_DMA 2                 // where a phase's four pieces are issued (kstep_pp): 0 M cluster behind the reads, 1 C cluster, 2 M cluster between the reads, 3 two and two
 #endif
 
 
@@ -69,6 +85,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     static_assert(SPLIT == HM && (!HM || (AK && BK)), "the pair-split launch is the half-height K-major form");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     V3_ST(0);
+    V3_PST_DECL
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform on the scalar side
@@ -246,10 +263,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
         f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    // Transpose reads of the half-height loop, two fragments (four reads) at a time: a pair is ISSUED by one asm statement and waited
-    // for by a later one that names its registers ("+v": every use comes after that wait), so the reads fly under the MFMAs before.
+    // Pipelined transpose reads of the A fragments, two fragments (four reads) at a time: a pair is ISSUED by one asm
+    // statement and waited for by a later one that names its registers ("+v": every use comes after that wait), so the
+    // reads fly under the eight MFMAs of the pair before -- register-neutral (two pairs = the four fragments of before).
     struct TrPair { bf16x4 l0, h0, l1, h1; };
-    // Issued while `keep` (the pair in use) still feeds MFMAs: `keep` is an INPUT and the outputs are
+    auto tr_issue2 = [&](unsigned a0, unsigned a1, auto lo_c, auto hi_c, TrPair& o) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
+                     "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
+                     : "=v"(o.l0), "=v"(o.h0), "=v"(o.l1), "=v"(o.h1)
+                     : "v"(a0), "v"(a1), "n"(LO), "n"(HI)
+                     : "memory");
+    };
+    // The same, issued while `keep` (the pair in use) still feeds MFMAs: `keep` is an INPUT and the outputs are
     // early-clobber, so the reads cannot land in its registers. Found with a lab build that issued eight such reads
     // behind eight MFMAs into the just-used fragment registers: the last four MFMAs' products were wrong, differently from
     // launch to launch -- as if a wave's MFMAs, queued behind the partner wave's, read their A / B operands after a later
@@ -267,6 +293,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
     };
     auto tr_wait2 = [&](TrPair& o) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.l0), "+v"(o.h0), "+v"(o.l1), "+v"(o.h1)::"memory");
+    };
+    // (tr_load4 with the pair in use kept out of its destination registers, as tr_issue2_keep)
+    auto tr_load4_keep = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x8 (&f)[4], const auto& keep, const auto& keep2) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI), "v"(keep.l0), "v"(keep.h0), "v"(keep.l1), "v"(keep.h1),
+                       "v"(keep2.l0), "v"(keep2.h0), "v"(keep2.l1), "v"(keep2.h1)
+                     : "memory");
+        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+        f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     // ... and the B fragments stay allocated to the end of the phase that reads them last (an empty asm that names them):
     // phase 1 otherwise gives the k-half-0 fragments' registers to its A pairs two MFMAs after their last use.
@@ -331,32 +375,173 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         // operands' byte offsets of step t (see dma_a_at)
         unsigned oa = 0, ob = 0, ob2 = 2 * V3_BTILE;
         int ka = 0, kb = 0;
+#ifdef V3_LAB_NOSTRIDE          // LAB (tools/lab/pst.h builds only; wrong results): every K step re-reads the FIRST one's tiles, i.e. every piece hits in L2
+        const int da = 0, db = 0;
+#else
         const int da = 2 * a_kstep, db = 2 * b_kstep;
-        // ---- the full-height K step: per phase two ALTERNATING clusters, the workgroup's two halves one cluster apart (r04)
-        //   M cluster  every LDS read of the phase (A part: 8 fragments; phase 0 also the step's 8 B fragments) with the phase's four
-        //              pieces BETWEEN the read groups, then s_waitcnt vmcnt(10 | 8) lgkmcnt(0) + s_barrier
-        //   C cluster  the phase's 32 MFMAs, nothing else, then s_barrier
-        // Waves 4-7 (the SIMD partners of waves 0-3) enter the pass one barrier late and waves 0-3 leave it one barrier late, so
-        // between any two barriers one wave of every SIMD is in an M cluster and the other in a C cluster: the matrix pipe gets an
-        // uninterrupted stream from one wave while the other pays the LDS round trips and the pieces' issue stalls. (r01-r03's step had
-        // both waves of a SIMD in the same phase behind every barrier, reads and pieces interleaved with the MFMAs: they stalled
-        // together, 56 % MFMA-busy; this form 65 % at 12 % fewer cycles -- tools/lab/README.md has that form and the other placements of
-        // the pieces that were priced: behind the reads, in the C cluster, two and two, one burst per wave, k-half-0 reads under the
-        // MFMAs.) Same pieces in the same order as r03's step, so the same counted waits; same MFMA order per accumulator: the same bits.
-        // RAW: a wave waits for its pieces at the END of an M cluster; the first read of that data is by the other half, behind
-        //      that barrier, in the next slot. WAR: a part is refilled from the M cluster that follows, by at least one barrier,
-        //      the slot in which the late half read it (its reads retired by the lgkmcnt(0) in front of that slot's barrier).
-        // Stamp hooks (lab builds only): V3_ST(10) M cluster starts, (11) C cluster starts, (12) C cluster's MFMAs issued.
-        auto kstep_pp = [&](const int t, auto tail_c) {
+#endif
+        // TAIL = false: a step with both prefetches ahead of it (every DMA unconditional, constant waits); the last two
+        // steps take the guarded form
+        auto kstep = [&](const int t, auto tail_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
             const bool n1 = TAIL ? (t + 1 < nk) : true, n2 = TAIL ? (t + 2 < nk) : true;
             const int so_a1 = ka + da, so_a2 = ka + 2 * da, so_b2 = kb + 2 * db;
             const unsigned oa_next = oa ^ (2u * V3_APART);        // A part pair of step t + 1
             const unsigned char* sb = lds + 4 * V3_APART + ob;
             bf16x8 bf[2][4];
+            // ------------------------------------------------ phase 0: A rows 0..63 of the wave
+            if (TAIL && t == nk - 1) v2_wait_barrier<2>(); else v2_wait_barrier<8>();      // (+ lgkmcnt(0): gemm_v2.h)
+            {
+                const unsigned char* sa = lds + oa;
+                auto dma_slot = [&](int s, int i) {
+                    if (s == 0 && i == 1 && n1) dma_a_at(oa_next, so_a1, c1, c0);
+                    if (s == 0 && i == 3 && n1) dma_a_at(oa_next, so_a1, c1, c1);
+                    if (s == 1 && i == 1 && n2) dma_b_at(ob2, so_b2, c0);
+                    if (s == 1 && i == 3 && n2) dma_b_at(ob2, so_b2, c1);
+                };
+                if constexpr (AK) {
+                    const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
+                    TrPair g[3];
+                    auto issue = [&](auto idx_c) {             // pair idx: k-half idx >> 1, fragments 2 (idx & 1), +1
+                        constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                        // three pairs in rotation: the reads of pair IDX must not land in pair IDX - 1 (in use) nor in
+                        // pair IDX - 2 (its MFMAs were issued last): both are kept; with two pairs one of them was the target
+                        if constexpr (IDX == 0)
+                            tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                      std::integral_constant<int, S * 8192 + 1024>(), g[0]);
+                        else
+                            tr_issue2_keep(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                           std::integral_constant<int, S * 8192 + 1024>(), g[IDX % 3], g[(IDX + 2) % 3],
+                                           g[IDX >= 2 ? (IDX + 1) % 3 : (IDX + 2) % 3]);
+                    };
+                    auto work = [&](auto idx_c) {
+                        constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                        TrPair& p = g[IDX % 3];
+                        tr_wait2(p);
+                        if constexpr (IDX < 3) issue(std::integral_constant<int, IDX + 1>());
+                        if constexpr (IDX == 1) {                            // the other k-half's B fragments
+                            if constexpr (BK) {
+                                const unsigned bb = (unsigned)(uintptr_t)(ldsb_t)sb;
+                                tr_load4_keep(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], std::integral_constant<int, 16384>(),
+                                              std::integral_constant<int, 16384 + 2048>(), bf[1], p, g[0]);
+                            } else {
+                                load_b(sb, c1, bf[1]);
+                            }
+                        }
+                        const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bf[S][j], acc[F][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[F + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bf[S][j], acc[F + 1][j], 0, 0, 0);
+                        dma_slot(S, F + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    load_b(sb, c0, bf[0]);
+                    issue(c0);
+                    work(c0); work(c1); work(c2); work(c3);
+                } else {
+                    auto half = [&](auto s_c) {
+                        constexpr int s = decltype(s_c)::value;
+                        bf16x8 af[4];
+                        load_a(sa, s_c, af);
+                        load_b(sb, s_c, bf[s]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s][j], acc[i][j], 0, 0, 0);
+                            dma_slot(s, i);
+                            if (i & 1) __builtin_amdgcn_sched_barrier(0);      // keep each DMA where it was put
+                        }
+                    };
+                    half(c0); half(c1);
+                }
+            }
+            // ------------------------------------------------ phase 1: A rows 64..127 of the wave, B from registers
+            if (TAIL && t == nk - 1) v2_wait_barrier<0>(); else if (TAIL && t == nk - 2) v2_wait_barrier<8>(); else v2_wait_barrier<10>();
+            {
+                const unsigned char* sa = lds + oa + V3_APART;
+                auto dma_slot = [&](int s, int i) {
+                    if (s == 0 && i == 1 && n2) dma_a_at(oa, so_a2, c0, c0);      // (t + 2) & 1 == t & 1: this step's part 0
+                    if (s == 0 && i == 3 && n2) dma_a_at(oa, so_a2, c0, c1);
+                    if (s == 1 && i == 1 && n2) dma_b_at(ob2, so_b2, c2);
+                    if (s == 1 && i == 3 && n2) dma_b_at(ob2, so_b2, c3);
+                };
+                if constexpr (AK) {
+                    const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)sa;
+                    TrPair g[3];
+                    auto issue = [&](auto idx_c) {
+                        constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                        // three pairs in rotation: the reads of pair IDX must not land in pair IDX - 1 (in use) nor in
+                        // pair IDX - 2 (its MFMAs were issued last): both are kept; with two pairs one of them was the target
+                        if constexpr (IDX == 0)
+                            tr_issue2(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                      std::integral_constant<int, S * 8192 + 1024>(), g[0]);
+                        else
+                            tr_issue2_keep(ba + a_tr[F], ba + a_tr[F + 1], std::integral_constant<int, S * 8192>(),
+                                           std::integral_constant<int, S * 8192 + 1024>(), g[IDX % 3], g[(IDX + 2) % 3],
+                                           g[IDX >= 2 ? (IDX + 1) % 3 : (IDX + 2) % 3]);
+                    };
+                    auto work = [&](auto idx_c) {
+                        constexpr int IDX = decltype(idx_c)::value, S = IDX >> 1, F = (IDX & 1) * 2;
+                        TrPair& p = g[IDX % 3];
+                        tr_wait2(p);
+                        if constexpr (IDX < 3) issue(std::integral_constant<int, IDX + 1>());
+                        const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[4 + F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bf[S][j], acc[4 + F][j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[5 + F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bf[S][j], acc[5 + F][j], 0, 0, 0);
+                        dma_slot(S, F + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    issue(c0);
+                    work(c0); work(c1); work(c2); work(c3);
+                    keep_frags(bf[0]); keep_frags(bf[1]);
+                } else {
+                    auto half = [&](auto s_c) {
+                        constexpr int s = decltype(s_c)::value;
+                        bf16x8 af[4];
+                        load_a(sa, s_c, af);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s][j], acc[4 + i][j], 0, 0, 0);
+                            dma_slot(s, i);
+                            if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    };
+                    half(c0); half(c1);
+                }
+            }
+            oa = oa_next;
+            ob = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+            ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
+            ka += da; kb += db;
+        };
+        // ---- V3_PP: the same K step as two ALTERNATING clusters per phase, the workgroup's two halves one cluster apart
+        //   M cluster  every LDS read of the phase (A part: 8 fragments; phase 0 also the step's 8 B fragments) and the phase's four
+        //              pieces, then s_waitcnt vmcnt(8 | 10) lgkmcnt(0) + s_barrier
+        //   C cluster  the phase's 32 MFMAs, nothing else, then s_barrier
+        // Waves 4-7 (the SIMD partners of waves 0-3) enter the pass one barrier late and waves 0-3 leave it one barrier late, so
+        // between any two barriers one wave of every SIMD is in an M cluster and the other in a C cluster: the matrix pipe gets an
+        // uninterrupted stream from one wave while the other pays the LDS round trips and the pieces' issue stalls, instead of both
+        // waves of a SIMD paying them at the same time (kstep above: both halves in the same phase behind every barrier).
+        // Same pieces in the same order as kstep, so the same counted waits; same MFMA order per accumulator, so the same bits.
+        // RAW: a wave waits for its pieces at the END of an M cluster; the first read of that data is by the other half, behind
+        //      that barrier, in the next slot. WAR: a part is refilled from the M cluster that follows, by at least one barrier,
+        //      the slot in which the late half read it (its reads retired by the lgkmcnt(0) in front of that slot's barrier).
+        auto kstep_pp = [&](const int t, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
+            const bool n1 = TAIL ? (t + 1 < nk) : true, n2 = TAIL ? (t + 2 < nk) : true;
+            const int so_a1 = ka + da, so_a2 = ka + 2 * da, so_b2 = kb + 2 * db;
+            const unsigned oa_next = oa ^ (2u * V3_APART);
+            const unsigned char* sb = lds + 4 * V3_APART + ob;
+            bf16x8 bf[2][4];
             bf16x4 bl[2][4], bh[2][4];
-            // eight transpose reads (four fragments of one k-half), issued only: the cluster's closing lgkmcnt(0) retires them and
-            // landed4 hands the registers to the compiler behind it
             auto tr_issue4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x4 (&l)[4], bf16x4 (&h)[4]) {
                 constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
                 asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
@@ -376,7 +561,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 bf16x8 af[2][4];
                 bf16x4 al[2][4], ah[2][4];
                 // ---------------- M cluster
-                V3_ST(10);
+                V3_PST(0);
+                // the phase's read groups (four fragments each): phase 0 reads the step's B fragments (both k-halves) first
                 auto rd_b = [&](auto s_c) {
                     constexpr int S = decltype(s_c)::value;
                     if constexpr (BK) {
@@ -399,8 +585,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                // the phase's four pieces, in issue order k = 0..3 (r03's pieces in r03's order):
-                //   phase 0 of step t: A part 1 of t + 1 (x2), B of t + 2 (x2);  phase 1: A part 0 of t + 2 (x2), B of t + 2 (x2)
+                // the phase's four pieces, in issue order k = 0..3 (the same pieces in the same order as kstep)
                 auto piece = [&](int k) {
                     if constexpr (P == 0) {
                         if (k == 0 && n1) dma_a_at(oa_next, so_a1, c1, c0);
@@ -408,33 +593,55 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                         if (k == 2 && n2) dma_b_at(ob2, so_b2, c0);
                         if (k == 3 && n2) dma_b_at(ob2, so_b2, c1);
                     } else {
-                        if (k == 0 && n2) dma_a_at(oa, so_a2, c0, c0);      // (t + 2) & 1 == t & 1: this step's part 0
+                        if (k == 0 && n2) dma_a_at(oa, so_a2, c0, c0);
                         if (k == 1 && n2) dma_a_at(oa, so_a2, c0, c1);
                         if (k == 2 && n2) dma_b_at(ob2, so_b2, c2);
                         if (k == 3 && n2) dma_b_at(ob2, so_b2, c3);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                // (the last two steps choose their counted wait at run time: their reads are retired by a wait of its own IN FRONT of that
-                // choice, so that no path through it -- tools/check_barrier_lgkm.py walks them all -- reaches a barrier with a read in flight)
-                auto tail_reads_back = [&]() { if constexpr (TAIL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-                // a piece BETWEEN the read groups: the wave that issues one gets its next issue slot 30-70 cycles later (the half's four
-                // waves offer the texture path their pieces at the same moment); read groups in between overlap part of that
-                if constexpr (P == 0) {
-                    rd_b(c0); piece(0);
-                    rd_b(c1); piece(1);
-                    rd_a(c0); piece(2);
-                    rd_a(c1); piece(3);
-                    // every piece but the youngest ten landed: A part 1 of this step (read in the NEXT M cluster; the other half reads it
-                    // one slot after this barrier at the earliest)
-                    tail_reads_back();
-                    if (TAIL && t == nk - 1) v2_wait_barrier<0>(); else if (TAIL && t == nk - 2) v2_wait_barrier<8>(); else v2_wait_barrier<10>();
+                // V3_PP_DMA: 0 reads, then the four pieces | 1 all four pieces between the C cluster's MFMAs | 2 pieces BETWEEN the read
+                // groups (the texture path works on a piece while the LDS works on the reads) | 3 two between the read groups, two in C
+                constexpr int MP = V3_PP_DMA == 1 ? 0 : V3_PP_DMA == 3 ? 2 : 4;       // pieces issued in the M cluster
+                constexpr bool MIX = V3_PP_DMA == 2 || V3_PP_DMA == 3;
+                if constexpr (V3_PP_DMA == 4) {
+                    // a wave's four pieces as ONE burst, at a place among its read groups that ROTATES with the wave: the four waves of an
+                    // M cluster then feed the texture path one after the other (a piece costs its wave ~22 cycles there, but ~90 when all
+                    // four waves offer theirs at the same moment: each waits for the other three) while the other three read the LDS
+                    const int rot = wave & 3;
+                    auto burst = [&](int at) { if (rot == at) { piece(0); piece(1); piece(2); piece(3); } };
+                    if constexpr (P == 0) {
+                        burst(0); rd_b(c0); burst(1); rd_b(c1); burst(2); rd_a(c0); burst(3); rd_a(c1);
+                    } else {
+                        burst(0); burst(3); rd_a(c0); burst(1); rd_a(c1); burst(2);
+                    }
+                } else if constexpr (P == 0) {
+                    rd_b(c0); V3_PSTM(0); if (MIX) piece(0); V3_PSTM(1);
+                    rd_b(c1); V3_PSTM(2); if (MIX) piece(1); V3_PSTM(3);
+                    rd_a(c0); V3_PSTM(4); if (MIX && MP == 4) piece(2); V3_PSTM(5);
+                    rd_a(c1); V3_PSTM(6); if (MIX && MP == 4) piece(3); V3_PSTM(7);
                 } else {
-                    rd_a(c0); piece(0); piece(1);
-                    rd_a(c1); piece(2); piece(3);
-                    // ... but the youngest eight: A part 0 and B of step t + 1
-                    tail_reads_back();
-                    if (TAIL && t >= nk - 2) { if (t == nk - 1) v2_wait_barrier<0>(); else v2_wait_barrier<2>(); } else v2_wait_barrier<8>();
+                    rd_a(c0); if (MIX) { piece(0); if (MP == 4) piece(1); }
+                    rd_a(c1); if (MIX) { if (MP == 4) { piece(2); piece(3); } else piece(1); }
+                }
+                if constexpr (V3_PP_DMA == 0) { piece(0); piece(1); piece(2); piece(3); }
+                V3_PST(1);
+                // the counted wait of kstep, less the pieces of this phase that are not issued yet (4 - MP)
+                if constexpr (P == 0) {
+                    if (TAIL && t == nk - 1) v2_wait_barrier<0>();
+                    else if (TAIL && t == nk - 2) v2_wait_barrier<(MP == 0 ? 6 : 8)>();      // (the phase's B pieces do not exist: n2 false)
+#ifdef V3_LAB_TIGHT             // LAB: wait for the pieces one phase YOUNGER than the reads need (prices a prefetch one phase shorter; results unchanged)
+                    else V3_PST_WAIT_BARRIER(2 + MP);
+#else
+                    else V3_PST_WAIT_BARRIER(6 + MP);
+#endif
+                } else {
+                    if (TAIL && t >= nk - 2) { if (t == nk - 1) v2_wait_barrier<0>(); else v2_wait_barrier<2>(); }
+#ifdef V3_LAB_TIGHT
+                    else V3_PST_WAIT_BARRIER(MP);
+#else
+                    else V3_PST_WAIT_BARRIER(4 + MP);
+#endif
                 }
                 if constexpr (P == 0 && BK) {
                     landed4(bl[0], bh[0]); landed4(bl[1], bh[1]);
@@ -452,22 +659,169 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---------------- C cluster
-                V3_ST(11);
+                V3_PST(2);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[4 * P + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], bf[s2][j], acc[4 * P + i][j], 0, 0, 0);
+                        if constexpr (MP < 4) {                      // the C cluster's pieces: after MFMAs 4, 12, 20, 28 (all four) or 12, 28 (two)
+                            if (MP == 0 && (i & 1) == 0) piece(2 * s2 + (i >> 1));
+                            if (MP == 2 && i == 2) piece(2 + s2);
+                        }
+                    }
                 __builtin_amdgcn_sched_barrier(0);
-                V3_ST(12);
+                V3_PST(3);
+                V3_PST_ACC();
                 asm volatile("s_barrier" ::: "memory");
             };
             phase(c0);
             phase(c1);
             oa = oa_next;
             ob = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+            ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
+            ka += da; kb += db;
+        };
+        // ---- V3_PP == 2: the alternating K step with HALF of the fragment reads moved under the wave's own MFMAs.
+        // An instruction of the M-cluster wave gets an issue slot about once per MFMA of its SIMD partner (tools/lab/lds_rate.hip: 16.5
+        // cycles per ds_read_b64_tr_b16, 18-20 per ds_read_b128 beside a streaming partner, 8-16 alone), so an M cluster of 16-32 reads +
+        // 4 pieces + their scalar work lasts 620-800 cycles against the C cluster's 512: the M cluster is the pole. The wave that
+        // STREAMS the MFMAs, on the other hand, issues a read between two of its own at next to no cost. So:
+        //   M(t, 0)   reads the k-half-1 fragments of B(t), A(t, 0) [8]; the phase's 4 pieces between them   -> wait, barrier
+        //   C(t, 0)   16 MFMAs on k-half 0 (read during the C cluster BEFORE), 16 on k-half 1; between the last 16: the k-half-0
+        //             fragments of A(t, 1) [4] into the registers the first 16 have freed                     -> barrier
+        //   M(t, 1)   k-half 1 of A(t, 1) [4]; 4 pieces                                                      -> wait, barrier
+        //   C(t, 1)   as C(t, 0); between its last 16 MFMAs: k-half 0 of B(t + 1), A(t + 1, 0) [8]           -> barrier
+        // Reading a buffer one cluster EARLIER moves its counted wait one M cluster earlier (both halves run the same code, and the
+        // early half reads in its C cluster what the late half must have waited for in its M cluster before: two barriers back):
+        //   end of M(t, 0): A(t + 1, 0), B(t + 1) landed [all but this cluster's 4 pieces];  end of M(t, 1): also A(t + 1, 1) [all but 6]
+        // (the prefetch is one phase shorter than kstep_pp's; a build of kstep_pp with these waits ran as fast: the pieces land early).
+        // WAR: the last read of every buffer is still an M-cluster read retired by that cluster's lgkmcnt(0); refills as in kstep_pp.
+        // Same pieces in the same order, same MFMA order per accumulator as kstep / kstep_pp: the same bits.
+        struct FragSet { bf16x8 f[4]; bf16x4 l[4], h[4]; };          // plain operands use f, K-major operands l / h (two transpose reads)
+        FragSet A0, A1, B0, B1;
+        auto rd_frag = [&](auto km_c, unsigned base, const int (&tr)[4], const int (&rd)[2], auto s_c, auto i_c, auto stride_c, FragSet& d) {
+            constexpr bool KM = decltype(km_c)::value;
+            constexpr int S = decltype(s_c)::value, I = decltype(i_c)::value, STRIDE = decltype(stride_c)::value;   // STRIDE: bytes per k-half of a K-major image
+            if constexpr (KM) {
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                             : "=&v"(d.l[I]), "=&v"(d.h[I]) : "v"(base + tr[I]), "n"(S * STRIDE), "n"(S * STRIDE + STRIDE / 8) : "memory");
+            } else {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d.f[I]) : "v"(base + rd[S]), "n"(I * 2048) : "memory");
+            }
+        };
+        auto rd_a2 = [&](unsigned ba, auto s_c, auto i_c, FragSet& d) {
+            rd_frag(std::integral_constant<bool, AK>(), ba, a_tr, a_rd, s_c, i_c, std::integral_constant<int, 8192>(), d);
+        };
+        auto rd_b2 = [&](unsigned bb, auto s_c, auto i_c, FragSet& d) {
+            rd_frag(std::integral_constant<bool, BK>(), bb, b_tr, b_rd, s_c, i_c, std::integral_constant<int, 16384>(), d);
+        };
+        auto landed_set = [&](auto km_c, FragSet& d) {
+            if constexpr (decltype(km_c)::value)
+                asm volatile("" : "+v"(d.l[0]), "+v"(d.h[0]), "+v"(d.l[1]), "+v"(d.h[1]), "+v"(d.l[2]), "+v"(d.h[2]), "+v"(d.l[3]), "+v"(d.h[3]));
+            else
+                asm volatile("" : "+v"(d.f[0]), "+v"(d.f[1]), "+v"(d.f[2]), "+v"(d.f[3]));
+        };
+        auto keep_set = [&](auto km_c, const FragSet& d) {
+            if constexpr (decltype(km_c)::value)
+                asm volatile("" ::"v"(d.l[0]), "v"(d.h[0]), "v"(d.l[1]), "v"(d.h[1]), "v"(d.l[2]), "v"(d.h[2]), "v"(d.l[3]), "v"(d.h[3]));
+            else
+                asm volatile("" ::"v"(d.f[0]), "v"(d.f[1]), "v"(d.f[2]), "v"(d.f[3]));
+        };
+        auto frag_a = [&](const FragSet& d, int i) { if constexpr (AK) return __builtin_shufflevector(d.l[i], d.h[i], 0, 1, 2, 3, 4, 5, 6, 7); else return d.f[i]; };
+        auto frag_b = [&](const FragSet& d, int j) { if constexpr (BK) return __builtin_shufflevector(d.l[j], d.h[j], 0, 1, 2, 3, 4, 5, 6, 7); else return d.f[j]; };
+        std::integral_constant<bool, AK> akc;
+        std::integral_constant<bool, BK> bkc;
+        auto kstep_pp2 = [&](const int t, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
+            const bool n1 = TAIL ? (t + 1 < nk) : true, n2 = TAIL ? (t + 2 < nk) : true;
+            const int so_a1 = ka + da, so_a2 = ka + 2 * da, so_b2 = kb + 2 * db;
+            const unsigned oa_next = oa ^ (2u * V3_APART);
+            const unsigned ob1 = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+            const unsigned lbase = (unsigned)(uintptr_t)(ldsb_t)lds;
+            const unsigned bb = lbase + 4 * V3_APART + ob, bb_next = lbase + 4 * V3_APART + ob1;
+            auto phase = [&](auto P_c) {
+                constexpr int P = decltype(P_c)::value;
+                const unsigned ba = lbase + oa + P * V3_APART;
+                auto piece = [&](int k) {
+                    if constexpr (P == 0) {
+                        if (k == 0 && n1) dma_a_at(oa_next, so_a1, c1, c0);
+                        if (k == 1 && n1) dma_a_at(oa_next, so_a1, c1, c1);
+                        if (k == 2 && n2) dma_b_at(ob2, so_b2, c0);
+                        if (k == 3 && n2) dma_b_at(ob2, so_b2, c1);
+                    } else {
+                        if (k == 0 && n2) dma_a_at(oa, so_a2, c0, c0);
+                        if (k == 1 && n2) dma_a_at(oa, so_a2, c0, c1);
+                        if (k == 2 && n2) dma_b_at(ob2, so_b2, c2);
+                        if (k == 3 && n2) dma_b_at(ob2, so_b2, c3);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // ---------------- M cluster: the k-half-1 fragments, a piece behind every two (phase 1: every one) of them
+                V3_PST(0);
+                if constexpr (P == 0) {
+                    rd_b2(bb, c1, c0, B1); rd_b2(bb, c1, c1, B1); __builtin_amdgcn_sched_barrier(0); piece(0);
+                    rd_b2(bb, c1, c2, B1); rd_b2(bb, c1, c3, B1); __builtin_amdgcn_sched_barrier(0); piece(1);
+                    rd_a2(ba, c1, c0, A1); rd_a2(ba, c1, c1, A1); __builtin_amdgcn_sched_barrier(0); piece(2);
+                    rd_a2(ba, c1, c2, A1); rd_a2(ba, c1, c3, A1); __builtin_amdgcn_sched_barrier(0); piece(3);
+                    if (TAIL && !n1) v2_wait_barrier<0>(); else if (TAIL && !n2) v2_wait_barrier<2>(); else V3_PST_WAIT_BARRIER(4);
+                    landed_set(bkc, B1); landed_set(bkc, B0);
+                } else {
+                    rd_a2(ba, c1, c0, A1); __builtin_amdgcn_sched_barrier(0); piece(0);
+                    rd_a2(ba, c1, c1, A1); __builtin_amdgcn_sched_barrier(0); piece(1);
+                    rd_a2(ba, c1, c2, A1); __builtin_amdgcn_sched_barrier(0); piece(2);
+                    rd_a2(ba, c1, c3, A1); __builtin_amdgcn_sched_barrier(0); piece(3);
+                    if (TAIL && !n2) v2_wait_barrier<0>(); else V3_PST_WAIT_BARRIER(6);
+                }
+                landed_set(akc, A1); landed_set(akc, A0);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---------------- C cluster
+                V3_PST(2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[4 * P + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_a(A0, i), frag_b(B0, j), acc[4 * P + i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the last 16 MFMAs (k-half 1), the NEXT phase's k-half-0 fragments read between them into A0 (and B0): their registers'
+                // last MFMAs are at least two MFMAs back, and A1 / B1 stay allocated to the end of the cluster (keep_set)
+                const unsigned ba_nx = P == 0 ? lbase + oa + V3_APART : lbase + oa_next;
+                const bool nx = P == 0 ? true : n1;
+                auto early = [&](auto i_c) {
+                    constexpr int I = decltype(i_c)::value;
+                    if (nx) {
+                        rd_a2(ba_nx, c0, i_c, A0);
+                        if constexpr (P == 1) rd_b2(bb_next, c0, i_c, B0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[4 * P + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_a(A1, i), frag_b(B1, j), acc[4 * P + i][j], 0, 0, 0);
+                        if (j == 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (i == 0) early(c0);
+                            if (i == 1) early(c1);
+                            if (i == 2) early(c2);
+                            if (i == 3) early(c3);
+                        }
+                    }
+                }
+                keep_set(akc, A1); keep_set(bkc, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                V3_PST(3);
+                V3_PST_ACC();
+                asm volatile("s_barrier" ::: "memory");
+            };
+            phase(c0);
+            phase(c1);
+            oa = oa_next;
+            ob = ob1;
             ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
             ka += da; kb += db;
         };
@@ -513,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 asm volatile("" : "+v"(c.bl[1][0]), "+v"(c.bh[1][0]), "+v"(c.bl[1][1]), "+v"(c.bh[1][1]), "+v"(c.bl[1][2]), "+v"(c.bh[1][2]),
                                   "+v"(c.bl[1][3]), "+v"(c.bh[1][3])::"memory");
             };
-            auto step = [&](const int t, Ahead& c, Ahead& n, auto last_c) {        // last_c: the pass's final step (nothing to read ahead)
+            auto step = [&](const int t, Ahead& c, Ahead& n) {
                 const bool n3 = t + 3 < nk;
                 const int so_a3 = ka + 3 * da, so_b3 = kb + 3 * db;
                 const unsigned oa3 = (oa4 + 3u * V3_APART) & (4u * V3_APART - 1u);
@@ -559,7 +913,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 tr_issue2_keep(ba + a_tr[2], ba + a_tr[3], std::integral_constant<int, 8192>(), std::integral_constant<int, 8192 + 1024>(), g3, g1, g2);
                 mfma8(g2, c1, c0);
                 tr_wait2(g3);
-                if constexpr (!decltype(last_c)::value) { if (t + 1 < nk) read_ahead(n, oa1, ob1, g2, g3); }     // next step's set: under this step's last eight MFMAs
+                if (t + 1 < nk) read_ahead(n, oa1, ob1, g2, g3);     // next step's set: under this step's last eight MFMAs
                 mfma8(g3, c1, c2);
                 keep_frags(bf[0]); keep_frags(bf[1]);
                 oa4 = oa1;
@@ -573,20 +927,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
                 read_ahead(X, 0u, 0u, z, z);
             }
             int t = 0;
-            for (; t + 1 < nk; t += 2) { step(t, X, Y, std::false_type()); step(t + 1, Y, X, std::false_type()); }
-            if (t < nk) step(t, X, Y, std::true_type());
+            for (; t + 1 < nk; t += 2) { step(t, X, Y); step(t + 1, Y, X); }
+            if (t < nk) step(t, X, Y);
             return;
         }
-        // every wave: the pieces of (0, 0) have landed, for everybody behind the barrier; then the late half's extra barrier, which
-        // the early half answers with one more at the end (every wave passes 2 + 4 nk barriers)
         int t = 0;
-        if (nk > 1) v2_wait_barrier<8>(); else v2_wait_barrier<2>();
-        V3_ST(13);
-        if (wave >= 4) asm volatile("s_barrier" ::: "memory");
-        for (; t + 2 < nk; ++t) kstep_pp(t, std::false_type());
-        for (; t < nk; ++t) kstep_pp(t, std::true_type());
-        if (wave < 4) asm volatile("s_barrier" ::: "memory");
-        V3_ST(14);
+        if constexpr (V3_PP == 2) {
+            // every wave: the pieces of (0, 0) AND of A(0, 1) have landed (the fill's first eight), for everybody behind the barrier; the late
+            // half's extra barrier; then the k-half-0 fragments of (0, 0), which in the steady state the C cluster before has read
+            if (nk > 1) v2_wait_barrier<6>(); else v2_wait_barrier<0>();
+            V3_PST_PASS_BEGIN();
+            if (wave >= 4) asm volatile("s_barrier" ::: "memory");
+            {
+                const unsigned lbase = (unsigned)(uintptr_t)(ldsb_t)lds;
+                rd_b2(lbase + 4 * V3_APART, c0, c0, B0); rd_b2(lbase + 4 * V3_APART, c0, c1, B0); rd_b2(lbase + 4 * V3_APART, c0, c2, B0); rd_b2(lbase + 4 * V3_APART, c0, c3, B0);
+                rd_a2(lbase, c0, c0, A0); rd_a2(lbase, c0, c1, A0); rd_a2(lbase, c0, c2, A0); rd_a2(lbase, c0, c3, A0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; t + 2 < nk; ++t) kstep_pp2(t, std::false_type());
+            for (; t < nk; ++t) kstep_pp2(t, std::true_type());
+            if (wave < 4) asm volatile("s_barrier" ::: "memory");
+            V3_PST_PASS_END();
+            V3_PST_FLUSH(wave, lane);
+            return;
+        }
+        if constexpr (V3_PP != 0) {
+            // every wave: the pieces of (0, 0) have landed, for everybody behind the barrier; then the late half's extra barrier
+            if (nk > 1) v2_wait_barrier<8>(); else v2_wait_barrier<2>();
+            V3_PST_PASS_BEGIN();
+            if (wave >= 4) asm volatile("s_barrier" ::: "memory");
+            for (; t + 2 < nk; ++t) kstep_pp(t, std::false_type());
+            for (; t < nk; ++t) kstep_pp(t, std::true_type());
+            if (wave < 4) asm volatile("s_barrier" ::: "memory");
+            V3_PST_PASS_END();
+            V3_PST_FLUSH(wave, lane);
+            return;
+        }
+        for (; t + 2 < nk; ++t) kstep(t, std::false_type());
+        for (; t < nk; ++t) kstep(t, std::true_type());
     };
 
     // ---- epilogue: the LDS re-layout of gemm_v2.h, one QUARTER of the wave tile (64 m x 32 n) at a time -- a whole

@@ -26,13 +26,21 @@ torch.cuda.synchronize()
 lib = L.lib()
 for tu in ("gemm_fwd", "gemm_dx", "gemm_dw"):
     fn = getattr(lib, "vbnn_lab_pst_" + tu)
-    buf = (C.c_ulonglong * 64)()
+    buf = (C.c_ulonglong * 256)()
     rc = fn(buf)
     print(f"{tu}: rc {rc}")
     for w in range(8):
-        a0, a1, a2, tot, n = buf[w * 8:w * 8 + 5]
+        a0, a1, a2, tot, n, a4, a5 = buf[w * 8:w * 8 + 7]
         if n == 0:
             continue
         # s_memtime counts at a constant 100 MHz?  no: it is the shader clock here -- report raw counts per phase
-        print(f"  wave {w}: phases {n:4d}  M issue {a0 / n:7.1f}  wait+barrier {a1 / n:7.1f}  C {a2 / n:7.1f}  C barrier+rest {(tot - a0 - a1 - a2) / n:7.1f}  "
+        print(f"  wave {w}: phases {n:4d}  M start -> C start {a1 / n:7.1f} (M start -> LDS reads back {a4 / n:6.1f}, then pieces landed {a5 / n:6.1f})  C {a2 / n:7.1f}  C barrier+rest {(tot - a0 - a1 - a2) / n:7.1f}  "
               f"pass/phase {tot / n:7.1f}")
+    raw = [[buf[64 + w * 16 + k] for k in range(12)] for w in range(8)]
+    t00 = min(r[0] for r in raw if r[0])
+    print("  one K step (phase 0 then phase 1), cycles from the first wave's M start: M start, (M start), reads back, pieces landed, C start, C end")
+    for w in range(8):
+        print(f"  wave {w}: " + "  ".join(f"{(v - t00):6d}" for v in raw[w][:6]) + "   |   " + "  ".join(f"{(v - t00):6d}" for v in raw[w][6:]))
+    print("  phase 0's M cluster, cycles from its start, after: B k0 reads, piece 0, B k1 reads, piece 1, A k0 reads, piece 2, A k1 reads, piece 3")
+    for w in range(8):
+        print(f"  wave {w}: " + "  ".join(f"{buf[192 + w * 8 + k]:5d}" for k in range(8)))
