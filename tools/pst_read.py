@@ -2,8 +2,8 @@
 """LAB: read the cluster stamps of a tools/lab/pst.h build (see that header):
     VBNN_HIP_LIB=$PWD/vbnn_amd/lib/pst/libvbnn_hip.so python tools/pst_read.py
 One wide training step, then per translation unit (gemm_fwd / gemm_dx / gemm_dw: the LAST gemm_nt_v3 launch of each) and per wave of
-workgroup 8: cycles per PHASE spent issuing the M cluster (reads + pieces), between that and the start of the C cluster (counted wait
-+ barrier), in the C cluster's MFMAs -- and the whole pass per phase (the rest is the barrier behind the C cluster)."""
+workgroup 8: cycles per PHASE in the M cluster (reads + pieces + its closing wait and barrier) and in the C cluster's MFMAs, the whole
+pass per phase (the rest is the barrier behind the C cluster), and one K step's stamps as they are."""
 import ctypes as C
 import os
 import sys
@@ -26,21 +26,17 @@ torch.cuda.synchronize()
 lib = L.lib()
 for tu in ("gemm_fwd", "gemm_dx", "gemm_dw"):
     fn = getattr(lib, "vbnn_lab_pst_" + tu)
-    buf = (C.c_ulonglong * 256)()
+    buf = (C.c_ulonglong * 192)()
     rc = fn(buf)
-    print(f"{tu}: rc {rc}")
+    print(f"{tu}: rc {rc}   (cycles per phase = one M cluster + one C cluster of a wave; a K step is two phases = four slots)")
     for w in range(8):
-        a0, a1, a2, tot, n, a4, a5 = buf[w * 8:w * 8 + 7]
-        if n == 0:
+        am, ac, ap, n = buf[w * 8:w * 8 + 4]
+        if n < 2:
             continue
-        # s_memtime counts at a constant 100 MHz?  no: it is the shader clock here -- report raw counts per phase
-        print(f"  wave {w}: phases {n:4d}  M start -> C start {a1 / n:7.1f} (M start -> LDS reads back {a4 / n:6.1f}, then pieces landed {a5 / n:6.1f})  C {a2 / n:7.1f}  C barrier+rest {(tot - a0 - a1 - a2) / n:7.1f}  "
-              f"pass/phase {tot / n:7.1f}")
-    raw = [[buf[64 + w * 16 + k] for k in range(12)] for w in range(8)]
+        print(f"  wave {w}: phases {n:4d}  M cluster (start -> C start, with its closing wait and barrier) {am / (n - 1):7.1f}   C cluster (32 MFMAs issued) {ac / (n - 1):7.1f}"
+              f"   passes / phases {ap / n:7.1f}")
+    raw = [[buf[64 + w * 16 + k] for k in range(6)] for w in range(8)]
     t00 = min(r[0] for r in raw if r[0])
-    print("  one K step (phase 0 then phase 1), cycles from the first wave's M start: M start, (M start), reads back, pieces landed, C start, C end")
+    print("  one K step, cycles from the first wave's M start: phase 0: M start, C start, C end | phase 1: M start, C start, C end")
     for w in range(8):
-        print(f"  wave {w}: " + "  ".join(f"{(v - t00):6d}" for v in raw[w][:6]) + "   |   " + "  ".join(f"{(v - t00):6d}" for v in raw[w][6:]))
-    print("  phase 0's M cluster, cycles from its start, after: B k0 reads, piece 0, B k1 reads, piece 1, A k0 reads, piece 2, A k1 reads, piece 3")
-    for w in range(8):
-        print(f"  wave {w}: " + "  ".join(f"{buf[192 + w * 8 + k]:5d}" for k in range(8)))
+        print(f"  wave {w}: " + "  ".join(f"{(v - t00):6d}" for v in raw[w][:3]) + "   |   " + "  ".join(f"{(v - t00):6d}" for v in raw[w][3:]))

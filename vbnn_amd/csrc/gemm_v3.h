@@ -41,6 +41,9 @@ inline int g_v3_min_k = 704;        // shortest K the shape selection gives to t
 #ifndef V3_ST
 #define V3_ST(k) do { } while (0)
 #endif
+#ifndef V3_HM_PP
+#define V3_HM_PP 1                  // the half-height loop as alternating clusters (step_pp); 0: r03's read-one-step-ahead form
+#endif
 
 
 // AK / BK: the operand is stored K-MAJOR -- element (row, k) at X[k * ld + row], i.e. the untransposed activation /
@@ -326,6 +329,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             dma_b(2, 2, c2); dma_b(2, 2, c3);
         }
     };
+    // (V3_HM_PP) the fill in the order the alternating half-height step issues its pieces -- A three steps ahead, B two: A(0), A(1),
+    // B(0), A(2), B(1) -- so that its counted waits hold from the first step on
+    auto prologue_hm_pp = [&]() {
+        dma_a_at(0u, 0, c0, c0); dma_a_at(0u, 0, c0, c1);
+        if (nk > 1) { dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c0); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c1); }
+        dma_b(0, 0, c0); dma_b(0, 0, c1); dma_b(0, 0, c2); dma_b(0, 0, c3);
+        if (nk > 2) { dma_a_at(2u * V3_APART, 4 * a_kstep, c0, c0); dma_a_at(2u * V3_APART, 4 * a_kstep, c0, c1); }
+        if (nk > 1) { dma_b(1, 1, c0); dma_b(1, 1, c1); dma_b(1, 1, c2); dma_b(1, 1, c3); }
+    };
     auto run_pass = [&]() {
         // loop-carried scalars of step t: LDS offset of A part (t & 1) * 2, of B slots t % 3 and (t + 2) % 3, and the
         // operands' byte offsets of step t (see dma_a_at)
@@ -471,6 +483,91 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
             ka += da; kb += db;
         };
+        if constexpr (HM && V3_HM_PP != 0) {
+            // ---- the half-height form as alternating clusters (r04), one phase per K step on the wave's 64 x 64 tile (acc[0..3][]):
+            //   M(t)  the step's 16 fragments (32 transpose reads) with its six pieces -- A(t + 3) into part (t + 3) & 3, B(t + 2) into slot
+            //         (t + 2) % 3, both last read during step t - 1 -- between them, then s_waitcnt vmcnt(6) lgkmcnt(0) + s_barrier
+            //   C(t)  32 MFMAs, then s_barrier
+            // waves 4-7 one barrier behind waves 0-3, exactly as kstep_pp. RAW: the wait that closes M(t) leaves only M(t)'s own six pieces
+            // in flight, i.e. A(t + 1) and B(t + 1) have landed, one barrier before the other half reads them. WAR: a buffer read in M(t)
+            // (by the late half one slot after the early half) is refilled from M(t + 1) on. MFMA order per accumulator as before.
+            bf16x4 al[2][4], ah[2][4], bl[2][4], bh[2][4];
+            unsigned oa4 = 0;                                       // A part of step t: (t & 3) * V3_APART
+            const unsigned lbase = (unsigned)(uintptr_t)(ldsb_t)lds;
+            auto tr2 = [&](unsigned a0, unsigned a1, auto lo_c, auto hi_c, bf16x4& l0, bf16x4& h0, bf16x4& l1, bf16x4& h1) {
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+                asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
+                             "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
+                             : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1) : "v"(a0), "v"(a1), "n"(LO), "n"(HI) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto landed4 = [&](bf16x4 (&l)[4], bf16x4 (&h)[4]) {
+                asm volatile("" : "+v"(l[0]), "+v"(h[0]), "+v"(l[1]), "+v"(h[1]), "+v"(l[2]), "+v"(h[2]), "+v"(l[3]), "+v"(h[3])::"memory");
+            };
+            auto step_pp = [&](const int t, auto tail_c) {
+                constexpr bool TAIL = decltype(tail_c)::value;
+                const bool n2 = TAIL ? (t + 2 < nk) : true, n3 = TAIL ? (t + 3 < nk) : true;
+                const unsigned oa3 = (oa4 + 3u * V3_APART) & (4u * V3_APART - 1u);
+                const int so_a3 = ka + 3 * da, so_b2 = kb + 2 * db;
+                const unsigned ba = lbase + oa4, bb = lbase + 4 * V3_APART + ob;
+                auto piece = [&](int k) {
+                    if (k == 0 && n3) dma_a_at(oa3, so_a3, c0, c0);
+                    if (k == 1 && n3) dma_a_at(oa3, so_a3, c0, c1);
+                    if (k == 2 && n2) dma_b_at(ob2, so_b2, c0);
+                    if (k == 3 && n2) dma_b_at(ob2, so_b2, c1);
+                    if (k == 4 && n2) dma_b_at(ob2, so_b2, c2);
+                    if (k == 5 && n2) dma_b_at(ob2, so_b2, c3);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                std::integral_constant<int, 1024> a1k; std::integral_constant<int, 8192> a2k; std::integral_constant<int, 8192 + 1024> a3k;
+                std::integral_constant<int, 2048> b1k; std::integral_constant<int, 16384> b2k; std::integral_constant<int, 16384 + 2048> b3k;
+                // ---------------- M cluster: two fragments (four reads), a piece, ...
+                V3_ST(10);
+                tr2(bb + b_tr[0], bb + b_tr[1], c0, b1k, bl[0][0], bh[0][0], bl[0][1], bh[0][1]); piece(0);
+                tr2(bb + b_tr[2], bb + b_tr[3], c0, b1k, bl[0][2], bh[0][2], bl[0][3], bh[0][3]); piece(1);
+                tr2(ba + a_tr[0], ba + a_tr[1], c0, a1k, al[0][0], ah[0][0], al[0][1], ah[0][1]); piece(2);
+                tr2(ba + a_tr[2], ba + a_tr[3], c0, a1k, al[0][2], ah[0][2], al[0][3], ah[0][3]); piece(3);
+                tr2(bb + b_tr[0], bb + b_tr[1], b2k, b3k, bl[1][0], bh[1][0], bl[1][1], bh[1][1]); piece(4);
+                tr2(bb + b_tr[2], bb + b_tr[3], b2k, b3k, bl[1][2], bh[1][2], bl[1][3], bh[1][3]); piece(5);
+                tr2(ba + a_tr[0], ba + a_tr[1], a2k, a3k, al[1][0], ah[1][0], al[1][1], ah[1][1]);
+                tr2(ba + a_tr[2], ba + a_tr[3], a2k, a3k, al[1][2], ah[1][2], al[1][3], ah[1][3]);
+                if constexpr (TAIL) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (reads retired in front of the run-time choice: kstep_pp)
+                    if (n3) v2_wait_barrier<6>(); else if (n2) v2_wait_barrier<4>(); else v2_wait_barrier<0>();
+                } else {
+                    v2_wait_barrier<6>();
+                }
+                landed4(bl[0], bh[0]); landed4(bl[1], bh[1]); landed4(al[0], ah[0]); landed4(al[1], ah[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---------------- C cluster
+                V3_ST(11);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(al[s2][i], ah[s2][i], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                               __builtin_shufflevector(bl[s2][j], bh[s2][j], 0, 1, 2, 3, 4, 5, 6, 7), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                V3_ST(12);
+                asm volatile("s_barrier" ::: "memory");
+                oa4 = (oa4 + V3_APART) & (4u * V3_APART - 1u);
+                ob = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
+                ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
+                ka += da; kb += db;
+            };
+            // every wave: A(0), B(0) have landed (what the fill issued behind them may fly), for everybody behind the barrier
+            if (nk > 2) v2_wait_barrier<6>(); else if (nk > 1) v2_wait_barrier<4>(); else v2_wait_barrier<0>();
+            V3_ST(13);
+            if (wave >= 4) asm volatile("s_barrier" ::: "memory");
+            int t = 0;
+            for (; t + 3 < nk; ++t) step_pp(t, std::false_type());
+            for (; t < nk; ++t) step_pp(t, std::true_type());
+            if (wave < 4) asm volatile("s_barrier" ::: "memory");
+            V3_ST(14);
+            return;
+        }
         if constexpr (HM) {
             // ---- the half-height form, fragments read ONE STEP AHEAD: one phase per K step on the wave's 64 x 64 tile
             // (acc[0..3][]). The step's B fragments (both k-halves) and its first A pair are read from LDS at the END of the
@@ -790,7 +887,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         run_pass();
     } else {
         zero_acc();
-        if constexpr (HM) prologue_hm(); else prologue();
+        if constexpr (HM) { if constexpr (V3_HM_PP != 0) prologue_hm_pp(); else prologue_hm(); } else prologue();
         run_pass();
     }
     __syncthreads();
