@@ -80,6 +80,17 @@ def test_no_lds_read_is_outstanding_at_a_barrier_of_the_shipped_kernels(tmp_path
     assert chk.returncode == 0, chk.stdout[-4000:]
 
 
+def test_nothing_touches_a_transpose_reads_destination_before_its_wait_in_the_shipped_kernels(tmp_path):
+    """The K-major operands' fragments come from ds_read_b64_tr_b16 issued by one inline-asm statement and handed to the compiler by a
+    later one, behind the s_waitcnt that retires them: in between hipcc knows nothing of the load in flight, so no instruction may read
+    or write its destination registers (a copy or a spill there moves garbage). tools/audit_tr_reads.py holds that on the generated
+    code of every such kernel of the library as built (r04: the alternating K steps carry fragment registers across a barrier)."""
+    dis = _device_disassembly(tmp_path)
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_tr_reads.py"), "--dis", dis], capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stdout[-4000:]
+    assert chk.stdout.count("transpose reads") >= 6 and "gemm_nt_v3ILb1ELb1ELb1E5EpiDw" in chk.stdout, chk.stdout[-2000:]
+
+
 def test_the_barrier_checker_flags_r02s_code_shape(tmp_path):
     """The checker on the instruction shape hipcc generated in r02 (reads issued, barrier, refill DMA, then the wait) in
     both input formats, through a loop's back edge, and silent once the wait precedes the barrier."""

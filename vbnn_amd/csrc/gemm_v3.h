@@ -41,9 +41,6 @@ inline int g_v3_min_k = 704;        // shortest K the shape selection gives to t
 #ifndef V3_ST
 #define V3_ST(k) do { } while (0)
 #endif
-#ifndef V3_HM_PP
-#define V3_HM_PP 1                  // the half-height loop as alternating clusters (step_pp); 0: r03's read-one-step-ahead form
-#endif
 
 
 // AK / BK: the operand is stored K-MAJOR -- element (row, k) at X[k * ld + row], i.e. the untransposed activation /
@@ -228,75 +225,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         a_tr[i] = (8 * q + trq) * 256 + (((wr * 8 + 2 * i + (trp >> 1)) ^ thx) * 16) + (trp & 1) * 8;
         b_tr[i] = (8 * q + trq) * 512 + (((wc * 8 + 2 * i + (trp >> 1)) ^ thx) * 16) + (trp & 1) * 8;
     }
-    // The four fragments of one k-half. K-major: eight transpose reads and their wait in ONE asm statement -- through the
-    // builtin hipcc cannot tell that the read does not alias the LDS-DMA writes in flight and drains vmcnt(0) in front
-    // of every group (the whole pipeline, every half phase: 245 vs 191 us at 4096^3); inline asm is outside that
-    // bookkeeping, and the DMA -> read ordering is this kernel's own counted vmcnt + barrier, as for the plain reads.
+    // The fragments. K-major operands: transpose reads through INLINE ASM -- through the builtin hipcc cannot tell that the read
+    // does not alias the LDS-DMA writes in flight and drains vmcnt(0) in front of every group (the whole pipeline, every half phase:
+    // 245 vs 191 us at 4096^3); inline asm is outside that bookkeeping, and the DMA -> read ordering is this kernel's own counted
+    // vmcnt + barrier, as for the plain reads. The reads are ISSUED by one asm statement and handed to the compiler by a later,
+    // empty one that names their registers ("+v": landed4 in the K steps), behind the s_waitcnt lgkmcnt(0) that closes the cluster;
+    // tools/audit_tr_reads.py checks on the generated code that nothing touches a register in between.
+    // (r01-r03's loops issued such reads BETWEEN MFMAs and had to keep them out of the registers of the wave's last eight MFMAs -- a
+    // lab build that did not computed wrong products, differently from launch to launch; tools/lab/gemm_v3_r04.h keeps that form. In
+    // the alternating K steps every read sits behind a barrier that follows the cluster's last MFMA: tools/check_lds_war.py.)
     typedef __attribute__((address_space(3))) unsigned char* ldsb_t;
-    auto tr_load4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x8 (&f)[4]) {
-        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
-        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
-                     "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
-                     "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
-                     "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
-                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI)
-                     : "memory");
-        f[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
-        f[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-        f[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
-        f[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    // Transpose reads of the half-height loop, two fragments (four reads) at a time: a pair is ISSUED by one asm statement and waited
-    // for by a later one that names its registers ("+v": every use comes after that wait), so the reads fly under the MFMAs before.
-    struct TrPair { bf16x4 l0, h0, l1, h1; };
-    // Issued while `keep` (the pair in use) still feeds MFMAs: `keep` is an INPUT and the outputs are
-    // early-clobber, so the reads cannot land in its registers. Found with a lab build that issued eight such reads
-    // behind eight MFMAs into the just-used fragment registers: the last four MFMAs' products were wrong, differently from
-    // launch to launch -- as if a wave's MFMAs, queued behind the partner wave's, read their A / B operands after a later
-    // LDS read had already returned into them (mechanism not isolated further; hipcc's own ds_read_b128 into just-used
-    // operand registers, which its hazard logic sees, never misbehaved). Through inline asm hipcc sees none of this: to the
-    // compiler a fragment is dead once its MFMAs are emitted, and it did hand its registers to the next pair's reads.
-    auto tr_issue2_keep = [&](unsigned a0, unsigned a1, auto lo_c, auto hi_c, TrPair& o, const TrPair& keep, const TrPair& keep2) {
-        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
-                     "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
-                     : "=&v"(o.l0), "=&v"(o.h0), "=&v"(o.l1), "=&v"(o.h1)
-                     : "v"(a0), "v"(a1), "n"(LO), "n"(HI), "v"(keep.l0), "v"(keep.h0), "v"(keep.l1), "v"(keep.h1),
-                       "v"(keep2.l0), "v"(keep2.h0), "v"(keep2.l1), "v"(keep2.h1)
-                     : "memory");
-    };
-    auto tr_wait2 = [&](TrPair& o) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.l0), "+v"(o.h0), "+v"(o.l1), "+v"(o.h1)::"memory");
-    };
-    // ... and the B fragments stay allocated to the end of the phase that reads them last (an empty asm that names them):
-    // phase 1 otherwise gives the k-half-0 fragments' registers to its A pairs two MFMAs after their last use.
-    auto keep_frags = [&](const bf16x8 (&f)[4]) {
-        asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]));
-    };
-    auto load_a = [&](const unsigned char* sa, auto s_c, bf16x8 (&f)[4]) {
+    auto load_a = [&](const unsigned char* sa, auto s_c, bf16x8 (&f)[4]) {          // K-contiguous operands: four ds_read_b128
         constexpr int S = decltype(s_c)::value;
-        if constexpr (AK) {
-            const unsigned base = (unsigned)(uintptr_t)(ldsb_t)sa;
-            tr_load4(base + a_tr[0], base + a_tr[1], base + a_tr[2], base + a_tr[3], std::integral_constant<int, S * 8192>(),
-                     std::integral_constant<int, S * 8192 + 1024>(), f);
-        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[S] + i * 2048);
-        }
+        for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const bf16x8*>(sa + a_rd[S] + i * 2048);
     };
     auto load_b = [&](const unsigned char* sb, auto s_c, bf16x8 (&f)[4]) {
         constexpr int S = decltype(s_c)::value;
-        if constexpr (BK) {
-            const unsigned base = (unsigned)(uintptr_t)(ldsb_t)sb;
-            tr_load4(base + b_tr[0], base + b_tr[1], base + b_tr[2], base + b_tr[3], std::integral_constant<int, S * 16384>(),
-                     std::integral_constant<int, S * 16384 + 2048>(), f);
-        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) f[j] = *reinterpret_cast<const bf16x8*>(sb + b_rd[S] + j * 2048);
-        }
+        for (int j = 0; j < 4; ++j) f[j] = *reinterpret_cast<const bf16x8*>(sb + b_rd[S] + j * 2048);
     };
 
     f32x4 acc[8][4];
@@ -317,19 +264,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             dma_b(1, 1, c2); dma_b(1, 1, c3);
         }
     };
-    auto prologue_hm = [&]() {          // HM: the six pieces of step 0, then of step 1 (A parts 0 and 1 of the ring of four)
-        dma_b(0, 0, c0); dma_b(0, 0, c1); dma_a_at(0u, 0, c0, c0); dma_a_at(0u, 0, c0, c1);
-        dma_b(0, 0, c2); dma_b(0, 0, c3);
-        if (nk > 1) {
-            dma_b(1, 1, c0); dma_b(1, 1, c1); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c0); dma_a_at((unsigned)V3_APART, 2 * a_kstep, c0, c1);
-            dma_b(1, 1, c2); dma_b(1, 1, c3);
-        }
-        if (nk > 2) {                   // ... and of step 2: the pieces run three steps ahead of the MFMAs (run_pass)
-            dma_b(2, 2, c0); dma_b(2, 2, c1); dma_a_at(2u * V3_APART, 4 * a_kstep, c0, c0); dma_a_at(2u * V3_APART, 4 * a_kstep, c0, c1);
-            dma_b(2, 2, c2); dma_b(2, 2, c3);
-        }
-    };
-    // (V3_HM_PP) the fill in the order the alternating half-height step issues its pieces -- A three steps ahead, B two: A(0), A(1),
+    // the half-height loop's fill, in the order its step issues the pieces -- A three steps ahead, B two: A(0), A(1),
     // B(0), A(2), B(1) -- so that its counted waits hold from the first step on
     auto prologue_hm_pp = [&]() {
         dma_a_at(0u, 0, c0, c0); dma_a_at(0u, 0, c0, c1);
@@ -483,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             ob2 = ob2 == 2 * V3_BTILE ? 0 : ob2 + V3_BTILE;
             ka += da; kb += db;
         };
-        if constexpr (HM && V3_HM_PP != 0) {
+        if constexpr (HM) {
             // ---- the half-height form as alternating clusters (r04), one phase per K step on the wave's 64 x 64 tile (acc[0..3][]):
             //   M(t)  the step's 16 fragments (32 transpose reads) with its six pieces -- A(t + 3) into part (t + 3) & 3, B(t + 2) into slot
             //         (t + 2) % 3, both last read during step t - 1 -- between them, then s_waitcnt vmcnt(6) lgkmcnt(0) + s_barrier
@@ -566,112 +501,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             for (; t < nk; ++t) step_pp(t, std::true_type());
             if (wave < 4) asm volatile("s_barrier" ::: "memory");
             V3_ST(14);
-            return;
-        }
-        if constexpr (HM) {
-            // ---- the half-height form, fragments read ONE STEP AHEAD: one phase per K step on the wave's 64 x 64 tile
-            // (acc[0..3][]). The step's B fragments (both k-halves) and its first A pair are read from LDS at the END of the
-            // step before -- into the second of two register sets (the tile leaves ~110 registers free) -- so a step opens
-            // with MFMAs instead of two dependent LDS round trips behind its barrier; A pairs 1..3 stay pipelined under the
-            // MFMAs as in the full-height loop. For that the pieces run THREE steps ahead: at barrier t every wave has waited
-            // for its pieces of step t + 1 (vmcnt(6): only step t + 2's six may be in flight), during step t it issues step
-            // t + 3's: A into part (t + 3) & 3 (last read during step t - 1), B into slot t % 3 (read completely at the end of
-            // step t - 1: that is why BOTH B k-halves are read ahead).
-            struct Ahead { bf16x4 bl[2][4], bh[2][4]; TrPair p0; };
-            Ahead X, Y;
-            TrPair g1, g2, g3;                                      // A pairs 1..3 of the step at hand (named across steps: see the keeps)
-            g3 = TrPair{bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}};
-            unsigned oa4 = 0;                                       // A part of step t: (t & 3) * V3_APART
-            // eight transpose reads of a B k-half, issued only (the next barrier's lgkmcnt(0) retires them)
-            auto tr_issue4_keep = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x4 (&l)[4], bf16x4 (&h)[4],
-                                      const TrPair& keep, const TrPair& keep2) {
-                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-                asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
-                             "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
-                             "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
-                             "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
-                             : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
-                             : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI), "v"(keep.l0), "v"(keep.h0), "v"(keep.l1), "v"(keep.h1),
-                               "v"(keep2.l0), "v"(keep2.h0), "v"(keep2.l1), "v"(keep2.h1)
-                             : "memory");
-            };
-            auto read_ahead = [&](Ahead& n, unsigned oa_n, unsigned ob_n, const TrPair& keep, const TrPair& keep2) {
-                const unsigned bb = (unsigned)(uintptr_t)(ldsb_t)(lds + 4 * V3_APART + ob_n);
-                const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)(lds + oa_n);
-                tr_issue4_keep(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], c0, std::integral_constant<int, 2048>(), n.bl[0], n.bh[0], keep, keep2);
-                tr_issue4_keep(bb + b_tr[0], bb + b_tr[1], bb + b_tr[2], bb + b_tr[3], std::integral_constant<int, 16384>(),
-                               std::integral_constant<int, 16384 + 2048>(), n.bl[1], n.bh[1], keep, keep2);
-                tr_issue2_keep(ba + a_tr[0], ba + a_tr[1], c0, std::integral_constant<int, 1024>(), n.p0, keep, keep2);
-            };
-            // the set's registers are DEFINED here for the compiler: behind the barrier whose lgkmcnt(0) retired the reads
-            auto landed = [&](Ahead& c) {
-                asm volatile("" : "+v"(c.bl[0][0]), "+v"(c.bh[0][0]), "+v"(c.bl[0][1]), "+v"(c.bh[0][1]), "+v"(c.bl[0][2]), "+v"(c.bh[0][2]),
-                                  "+v"(c.bl[0][3]), "+v"(c.bh[0][3]), "+v"(c.p0.l0), "+v"(c.p0.h0), "+v"(c.p0.l1), "+v"(c.p0.h1)::"memory");
-                asm volatile("" : "+v"(c.bl[1][0]), "+v"(c.bh[1][0]), "+v"(c.bl[1][1]), "+v"(c.bh[1][1]), "+v"(c.bl[1][2]), "+v"(c.bh[1][2]),
-                                  "+v"(c.bl[1][3]), "+v"(c.bh[1][3])::"memory");
-            };
-            auto step = [&](const int t, Ahead& c, Ahead& n, auto last_c) {        // last_c: the pass's final step (nothing to read ahead)
-                const bool n3 = t + 3 < nk;
-                const int so_a3 = ka + 3 * da, so_b3 = kb + 3 * db;
-                const unsigned oa3 = (oa4 + 3u * V3_APART) & (4u * V3_APART - 1u);
-                const unsigned oa1 = (oa4 + V3_APART) & (4u * V3_APART - 1u);
-                const unsigned ob1 = ob == 2 * V3_BTILE ? 0 : ob + V3_BTILE;
-                if (t + 2 < nk) v2_wait_barrier<6>(); else v2_wait_barrier<0>();
-                landed(c);
-                auto dma_slot = [&](int k) {
-                    if (!n3) return;
-                    if (k == 0) dma_a_at(oa3, so_a3, c0, c0);
-                    if (k == 1) dma_a_at(oa3, so_a3, c0, c1);
-                    if (k == 2) dma_b_at(ob, so_b3, c0);             // slot t % 3: B of step t is in registers
-                    if (k == 3) dma_b_at(ob, so_b3, c1);
-                    if (k == 4) dma_b_at(ob, so_b3, c2);
-                    if (k == 5) dma_b_at(ob, so_b3, c3);
-                };
-                const unsigned ba = (unsigned)(uintptr_t)(ldsb_t)(lds + oa4);
-                bf16x8 bf[2][4];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bf[s2][j] = __builtin_shufflevector(c.bl[s2][j], c.bh[s2][j], 0, 1, 2, 3, 4, 5, 6, 7);
-                auto mfma8 = [&](const TrPair& p, auto s_c, auto f_c) {
-                    constexpr int S = decltype(s_c)::value, F = decltype(f_c)::value;
-                    const bf16x8 f0 = __builtin_shufflevector(p.l0, p.h0, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const bf16x8 f1 = __builtin_shufflevector(p.l1, p.h1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[F][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, bf[S][j], acc[F][j], 0, 0, 0);
-                    if constexpr (S == 0) { dma_slot(F); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[F + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, bf[S][j], acc[F + 1][j], 0, 0, 0);
-                    dma_slot(S == 0 ? F + 1 : 4 + F / 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                // pair 1 (k-half 0, fragments 2, 3) flies under pair 0's MFMAs, and so on; a read never lands in a pair whose
-                // MFMAs are among the wave's last eight (kept: that pair and the one before)
-                tr_issue2_keep(ba + a_tr[2], ba + a_tr[3], c0, std::integral_constant<int, 1024>(), g1, g3, g3);   // (g3: the step before's last eight)
-                mfma8(c.p0, c0, c0);
-                tr_wait2(g1);
-                tr_issue2_keep(ba + a_tr[0], ba + a_tr[1], std::integral_constant<int, 8192>(), std::integral_constant<int, 8192 + 1024>(), g2, c.p0, g1);
-                mfma8(g1, c0, c2);
-                tr_wait2(g2);
-                tr_issue2_keep(ba + a_tr[2], ba + a_tr[3], std::integral_constant<int, 8192>(), std::integral_constant<int, 8192 + 1024>(), g3, g1, g2);
-                mfma8(g2, c1, c0);
-                tr_wait2(g3);
-                if constexpr (!decltype(last_c)::value) { if (t + 1 < nk) read_ahead(n, oa1, ob1, g2, g3); }     // next step's set: under this step's last eight MFMAs
-                mfma8(g3, c1, c2);
-                keep_frags(bf[0]); keep_frags(bf[1]);
-                oa4 = oa1;
-                ob = ob1;
-                ka += da; kb += db;
-            };
-            // the first step's set: its pieces (the first six of the fill) have landed for every wave behind this barrier
-            if (nk > 2) v2_wait_barrier<12>(); else if (nk > 1) v2_wait_barrier<6>(); else v2_wait_barrier<0>();
-            {
-                TrPair z{bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}, bf16x4{0, 0, 0, 0}};
-                read_ahead(X, 0u, 0u, z, z);
-            }
-            int t = 0;
-            for (; t + 1 < nk; t += 2) { step(t, X, Y, std::false_type()); step(t + 1, Y, X, std::false_type()); }
-            if (t < nk) step(t, X, Y, std::true_type());
             return;
         }
         // every wave: the pieces of (0, 0) have landed, for everybody behind the barrier; then the late half's extra barrier, which
@@ -829,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             // as rows and stored as whole 128-byte (2-byte ST) row segments. Free LDS while pass 2's fill is in flight:
             // B slot 2 and A part 3 (the first K step refills them only behind its barrier, which every wave reaches after
             // its fold). LDS accesses go through inline asm: beside LDS-DMAs in flight hipcc would drain vmcnt(0) -- and
-            // with it this fold's own stores -- in front of every plain LDS read (see tr_load4).
+            // with it this fold's own stores -- in front of every plain LDS read (see the fragment reads above).
             typedef typename Epi::fold_st_t ST;
             static_assert(sizeof(ST) == 2, "staging tile geometry: 64 m x 2 bytes = one 128-byte row segment");
             constexpr int PITCH = 64 * (int)sizeof(ST) + 16;                   // bytes; 16 rows x 144 B = 2304 B per wave
@@ -887,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
         run_pass();
     } else {
         zero_acc();
-        if constexpr (HM) { if constexpr (V3_HM_PP != 0) prologue_hm_pp(); else prologue_hm(); } else prologue();
+        if constexpr (HM) prologue_hm_pp(); else prologue();
         run_pass();
     }
     __syncthreads();
