@@ -555,7 +555,9 @@ def test_engine_bf16_against_rounding_emulation(oracle, nnmod, gemm_kernel, hidd
 
 @pytest.mark.parametrize("hidden,I0,N", [([256, 512], 100, 256),      # layer 1: ragged M with the ones row (101 of 256); layer 2: whole tiles
                                          ([512, 256], 260, 384),      # two M tiles, the second ragged (261 of 512); 3 K steps per half
-                                         ([256, 256], 252, 128)])     # the ones row is the LAST row of the quad before a tile edge
+                                         ([256, 256], 252, 128),      # the ones row is the LAST row of the quad before a tile edge
+                                         ([256, 256], 100, 64), ([256, 256], 100, 192), ([256, 512], 100, 320)])
+                                         # the last three: 1, 3 and 5 K steps (r04: the alternating half-height step's fill and its guarded last three steps)
 def test_split_two_pass_gradient_against_rounding_emulation(oracle, nnmod, hidden, I0, N):
     """accGradParameters on gemm_v3's pair-split HALF-HEIGHT launch (forced: debug key 8), the launch of the 784 x 4096 gradient:
     128-row tiles, every workgroup walks all of K; ragged output rows, the bias gradient from the ones row."""

@@ -943,7 +943,7 @@ inline int g_v3_split = -1;         // -1 by shape, 0 never, 1 whenever possible
 // shape part: M rows of output (the ones row included) on N columns, K deep. Wanted when the pair split over 256 x 128 tiles
 // (gemm_v2.h) would leave half the CUs idle and this form's 128-row tiles x 2 make ONE round that fills at least 5/8 of them.
 static inline bool gemm_v3_split_shape_ok(int64_t M, int64_t N, int64_t K) {
-    if (g_v3_split == 0 || N % V3_BN || K % (2 * V2_BK)) return false;
+    if (g_v3_split == 0 || N % V3_BN || K % V2_BK) return false;       // (whole K steps; r02-r03 asked for an even number of them: two K halves)
     if (g_v3_split == 1) return true;
     const int64_t tiles = ((M + V3_BM - 1) / V3_BM) * (N / V3_BN);
     const int64_t blocks = ((M + V3_BM / 2 - 1) / (V3_BM / 2)) * (N / V3_BN) * 2;
