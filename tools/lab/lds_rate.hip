@@ -220,7 +220,11 @@ __global__ __launch_bounds__(512) void k_pp(unsigned long long* out, float* sink
         if constexpr (PIECES == 3) { if ((m & 7) == 3) piece_c(m >> 3); }
     };
     auto piece = [&](int k) {
-        if constexpr (PIECES == 1) {
+        // PIECES 5 / 6: as 1, with two more scalar (s_nop) / vector (v_mov) instructions per piece in the M cluster: what does an
+        // INSTRUCTION cost the wave that issues it beside a streaming partner, whatever it does?
+        if constexpr (PIECES == 5) { asm volatile("s_nop 0\n\ts_nop 0" ::: "memory"); }
+        if constexpr (PIECES == 6) { int d0, d1; asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(d0), "=v"(d1)); asm volatile("" ::"v"(d0), "v"(d1)); }
+        if constexpr (PIECES == 1 || PIECES == 5 || PIECES == 6 || PIECES == 7 || PIECES == 8) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr3_t)(lds + 65536 + ((slot + k) % 12) * 8192 + wave * 1024), 16, voff, so + k * 8192, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -280,7 +284,10 @@ __global__ __launch_bounds__(512) void k_pp(unsigned long long* out, float* sink
     if (wave >= 4) asm volatile("s_barrier" ::: "memory");
     for (int it = 0; it < rounds; ++it) {
         const unsigned base = (it & 1) * 32768;
-        // M(t, 0)
+        // M(t, 0)   (PIECES 7 / 8: wave r of the half starts its M cluster 32 r / 48 r cycles late, so the four waves' pieces reach the
+        //            texture path one after the other instead of at the same moment)
+        if constexpr (PIECES == 7) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+        if constexpr (PIECES == 8) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
         if constexpr (PIECES == 4) m0_rot(base);
         else { rd4(base, o0, bf[0], a); piece(0); rd4(base, o1, bf[1], a); piece(1); rd4(base + 16384, o0, af[0], a); piece(2); rd4(base + 16384, o1, af[1], a); piece(3); }
         asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -290,6 +297,8 @@ __global__ __launch_bounds__(512) void k_pp(unsigned long long* out, float* sink
         asm volatile("s_barrier" ::: "memory");
         slot += 4; so += 32768;
         // M(t, 1)
+        if constexpr (PIECES == 7) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+        if constexpr (PIECES == 8) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
         if constexpr (PIECES == 4) m1_rot(base);
         else { rd4(base + 16384, o0, af[0], a); piece(0); piece(1); rd4(base + 16384, o1, af[1], a); piece(2); piece(3); }
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -367,6 +376,11 @@ int main() {
     if (run_pp<0, 1, 1>("  + pieces (streamed source)", d_out, r2, big)) return 1;
     if (run_pp<1, 1, 0>("  + b128 reads + pieces (L2-resident)", d_out, r2, big)) return 1;
     if (run_pp<1, 1, 1>("  + b128 reads + pieces (streamed)", d_out, r2, big)) return 1;
+    if (run_pp<1, 5, 1>("  + b128 reads + pieces + 8 s_nop per M cluster", d_out, r2, big)) return 1;
+    if (run_pp<1, 6, 1>("  + b128 reads + pieces + 8 v_mov per M cluster", d_out, r2, big)) return 1;
+    if (run_pp<1, 7, 1>("  + b128 reads + pieces, wave r of a half 32 r cycles late", d_out, r2, big)) return 1;
+    if (run_pp<1, 8, 1>("  + b128 reads + pieces, wave r of a half 48 r cycles late", d_out, r2, big)) return 1;
+    if (run_pp<2, 7, 1>("  + tr reads + pieces, wave r of a half 32 r cycles late", d_out, r2, big)) return 1;
     if (run_pp<1, 4, 1>("  + b128 reads, pieces in M ROTATED by wave (one per read)", d_out, r2, big)) return 1;
     if (run_pp<1, 3, 1>("  + b128 reads, pieces in C, all waves at once", d_out, r2, big)) return 1;
     if (run_pp<2, 0, 0>("  + tr reads", d_out, r2, big)) return 1;
