@@ -574,6 +574,20 @@ def test_split_two_pass_gradient_against_rounding_emulation(oracle, nnmod, hidde
         L.check(L.lib().vbnn_debug_set(8, -1))
 
 
+def test_wide_training_steps_repeat_bit_for_bit(nnmod):
+    """The race screen of the pipelined kernels at bench size: two engines from the same seed run the same three training steps of the
+    wide configuration (every timed launch: two-pass 256 x 256 forward / gradInput / accGradParameters with their alternating K steps,
+    the half-height launch, the fused head, the update sweep) and must leave the same bits in the gradient arena, the operand shadows
+    and the loss after every step (tools/step_bits.py: the same hashes also compare two BUILDS of the library)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("step_bits", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "step_bits.py"))
+    sb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sb)
+    reps = sb.run("wide", 3, 2, out=lambda *a, **k: None)
+    assert reps[0] == reps[1] and len(reps[0]) == 3
+    assert len({line.split()[3] for line in reps[0]}) == 3          # the gradients do change from step to step
+
+
 def eng_x(eng, oracle, N, I0):
     return dev(oracle.fill_normal(N, I0, SEED, 4, 0, 0))
 
