@@ -36,8 +36,8 @@ constexpr int V3_LDS = 4 * V3_APART + 3 * V3_BTILE;  // 163840: all of the CU's 
 
 inline int g_v3_min_k = 704;        // shortest K the shape selection gives to this kernel (vbnn_debug_set key 4)
 
-// Stamp hook: a build that wants in-kernel time stamps defines V3_ST(k) before including this file (tools/lab/ has r03's); the
-// library does not.
+// Stamp hook: a build that wants in-kernel time stamps defines V3_ST(k) before including this file (tools/lab/pst.h: the K step's
+// clusters; tools/lab/ also has r03's); the library does not.
 #ifndef V3_ST
 #define V3_ST(k) do { } while (0)
 #endif
