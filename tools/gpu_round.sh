@@ -9,6 +9,8 @@ root=$(pwd)
 mkdir -p gpurun_out
 echo "== tests"; timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/${tag}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${tag}_tests.log
 cp gpurun_out/test_durations.txt gpurun_out/${tag}_test_durations.txt 2>/dev/null   # (tests/conftest.py: torch import time, tests > 1 s, every child process waited for)
+echo "== bit-for-bit repeatability of the training step (tools/step_bits.py: the race screen of the pipelined kernels at bench size)"
+timeout -k 10 300 python3 tools/step_bits.py wide 10 2 > gpurun_out/${tag}_step_bits_wide.txt 2>&1; tail -1 gpurun_out/${tag}_step_bits_wide.txt
 echo "== bench"
 timeout -k 10 400 python3 bench.py > gpurun_out/${tag}_bench_wide.json 2> gpurun_out/${tag}_bench.err; echo "wide rc=$?"
 timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_wide_driver.json 2>> gpurun_out/${tag}_bench.err; echo "driver-protocol rc=$?"
