@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512) void k_pp(unsigned long long* out, float* sink
     };
     const int rot = wave & 3;
     auto piece_c = [&](int k) {
-        if constexpr (PIECES >= 2) {
+        if constexpr (PIECES == 2 || PIECES == 3 || PIECES == 9 || PIECES == 10) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr3_t)(lds + 65536 + ((slot + k) % 12) * 8192 + wave * 1024), 16, voff, so + k * 8192, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -243,11 +243,15 @@ __global__ __launch_bounds__(512) void k_pp(unsigned long long* out, float* sink
                     constexpr int dummy = 0; (void)dummy;
                     const int m = s2 * 16 + i * 4 + j;
                     if constexpr (PIECES == 2) { if ((m & 7) == 2 * ROT + 1) { __builtin_amdgcn_sched_barrier(0); piece_c(m >> 3); } }
-                    if constexpr (PIECES == 3) { if ((m & 7) == 3) { __builtin_amdgcn_sched_barrier(0); piece_c(m >> 3); } }
+                    if constexpr (PIECES == 3 || PIECES == 9 || PIECES == 10) { if ((m & 7) == 3) { __builtin_amdgcn_sched_barrier(0); piece_c(m >> 3); } }
                 }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto ccluster = [&](auto i0_c) {
+        // PIECES 9 / 10: the pieces among the C cluster's MFMAs at the same places for every wave, but wave r of the half starts the
+        // cluster 16 r / 32 r cycles late (its partner is in an M cluster then: the s_nops cost what they say)
+        if constexpr (PIECES == 9) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15" ::: "memory"); }
+        if constexpr (PIECES == 10) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
         if constexpr (PIECES == 2) {
             if (rot == 0) cbody(i0_c, std::integral_constant<int, 0>());
             else if (rot == 1) cbody(i0_c, std::integral_constant<int, 1>());
@@ -378,6 +382,10 @@ int main() {
     if (run_pp<1, 1, 1>("  + b128 reads + pieces (streamed)", d_out, r2, big)) return 1;
     if (run_pp<1, 5, 1>("  + b128 reads + pieces + 8 s_nop per M cluster", d_out, r2, big)) return 1;
     if (run_pp<1, 6, 1>("  + b128 reads + pieces + 8 v_mov per M cluster", d_out, r2, big)) return 1;
+    if (run_pp<1, 9, 1>("  + b128 reads, pieces in C, wave r starts C 16 r late", d_out, r2, big)) return 1;
+    if (run_pp<1, 10, 1>("  + b128 reads, pieces in C, wave r starts C 32 r late", d_out, r2, big)) return 1;
+    if (run_pp<2, 9, 1>("  + tr reads, pieces in C, wave r starts C 16 r late", d_out, r2, big)) return 1;
+    if (run_pp<2, 3, 1>("  + tr reads, pieces in C, all waves at once", d_out, r2, big)) return 1;
     if (run_pp<1, 7, 1>("  + b128 reads + pieces, wave r of a half 32 r cycles late", d_out, r2, big)) return 1;
     if (run_pp<1, 8, 1>("  + b128 reads + pieces, wave r of a half 48 r cycles late", d_out, r2, big)) return 1;
     if (run_pp<2, 7, 1>("  + tr reads + pieces, wave r of a half 32 r cycles late", d_out, r2, big)) return 1;
