@@ -283,6 +283,41 @@ __global__ __launch_bounds__(512) void k_pp(unsigned long long* out, float* sink
         for (int i = 0; i < 4; ++i) one(a[i] + base + 16384, o0, af[0][i]);
         for (int i = 0; i < 4; ++i) one(a[i] + base + 16384, o1, af[1][i]);
     };
+    // PIECES 11: NO per-wave code path -- every wave runs the same 16 piece instructions per M cluster, one behind every read, with EXEC
+    // all ones on the four whose slot number is its own (slot & 3 == wave & 3) and ZERO on the other twelve: at any one read only one of the
+    // half's four waves offers the texture path a real piece. (Inline asm: M0, EXEC and the load in one statement, EXEC restored in it.)
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    const unsigned long long sp = (unsigned long long)src;
+    const i32x4 rsv = {(int)(unsigned)sp, (int)((unsigned)(sp >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+    const int em0 = __builtin_amdgcn_readfirstlane(rot == 0 ? -1 : 0), em1 = __builtin_amdgcn_readfirstlane(rot == 1 ? -1 : 0);
+    const int em2 = __builtin_amdgcn_readfirstlane(rot == 2 ? -1 : 0), em3 = __builtin_amdgcn_readfirstlane(rot == 3 ? -1 : 0);
+    auto piece_x = [&](auto j_c) {
+        constexpr int J = decltype(j_c)::value;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr3_t)(lds + 65536 + ((slot + (J >> 2)) % 12) * 8192 + wave * 1024));
+        const int soff = __builtin_amdgcn_readfirstlane(so + (J >> 2) * 8192);
+        const int em = __builtin_amdgcn_readfirstlane((J & 3) == 0 ? em0 : (J & 3) == 1 ? em1 : (J & 3) == 2 ? em2 : em3);
+        const int voff_ = voff;                    // (operands of an asm statement inside a generic lambda are not captured by themselves)
+        const i32x4 rsv_ = rsv;
+        asm volatile("s_mov_b32 m0, %0\n\ts_mov_b32 exec_lo, %1\n\ts_mov_b32 exec_hi, %1\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b64 exec, -1"
+                     ::"s"(dst), "s"(em), "v"(voff_), "s"(rsv_), "s"(soff) : "memory");
+    };
+#define LAB_IC(n) std::integral_constant<int, n>()
+    auto m0_mask = [&](unsigned base) {
+        rd1(a[0] + base, o0, bf[0][0]); piece_x(LAB_IC(0)); rd1(a[1] + base, o0, bf[0][1]); piece_x(LAB_IC(1));
+        rd1(a[2] + base, o0, bf[0][2]); piece_x(LAB_IC(2)); rd1(a[3] + base, o0, bf[0][3]); piece_x(LAB_IC(3));
+        rd1(a[0] + base, o1, bf[1][0]); piece_x(LAB_IC(4)); rd1(a[1] + base, o1, bf[1][1]); piece_x(LAB_IC(5));
+        rd1(a[2] + base, o1, bf[1][2]); piece_x(LAB_IC(6)); rd1(a[3] + base, o1, bf[1][3]); piece_x(LAB_IC(7));
+        rd1(a[0] + base + 16384, o0, af[0][0]); piece_x(LAB_IC(8)); rd1(a[1] + base + 16384, o0, af[0][1]); piece_x(LAB_IC(9));
+        rd1(a[2] + base + 16384, o0, af[0][2]); piece_x(LAB_IC(10)); rd1(a[3] + base + 16384, o0, af[0][3]); piece_x(LAB_IC(11));
+        rd1(a[0] + base + 16384, o1, af[1][0]); piece_x(LAB_IC(12)); rd1(a[1] + base + 16384, o1, af[1][1]); piece_x(LAB_IC(13));
+        rd1(a[2] + base + 16384, o1, af[1][2]); piece_x(LAB_IC(14)); rd1(a[3] + base + 16384, o1, af[1][3]); piece_x(LAB_IC(15));
+    };
+    auto m1_mask = [&](unsigned base) {
+        rd1(a[0] + base + 16384, o0, af[0][0]); piece_x(LAB_IC(0)); piece_x(LAB_IC(1)); rd1(a[1] + base + 16384, o0, af[0][1]); piece_x(LAB_IC(2)); piece_x(LAB_IC(3));
+        rd1(a[2] + base + 16384, o0, af[0][2]); piece_x(LAB_IC(4)); piece_x(LAB_IC(5)); rd1(a[3] + base + 16384, o0, af[0][3]); piece_x(LAB_IC(6)); piece_x(LAB_IC(7));
+        rd1(a[0] + base + 16384, o1, af[1][0]); piece_x(LAB_IC(8)); piece_x(LAB_IC(9)); rd1(a[1] + base + 16384, o1, af[1][1]); piece_x(LAB_IC(10)); piece_x(LAB_IC(11));
+        rd1(a[2] + base + 16384, o1, af[1][2]); piece_x(LAB_IC(12)); piece_x(LAB_IC(13)); rd1(a[3] + base + 16384, o1, af[1][3]); piece_x(LAB_IC(14)); piece_x(LAB_IC(15));
+    };
     auto landed = [&](bf16x8 (&f)[4]) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); };
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     if (wave >= 4) asm volatile("s_barrier" ::: "memory");
@@ -293,6 +328,7 @@ __global__ __launch_bounds__(512) void k_pp(unsigned long long* out, float* sink
         if constexpr (PIECES == 7) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
         if constexpr (PIECES == 8) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
         if constexpr (PIECES == 4) m0_rot(base);
+        else if constexpr (PIECES == 11) m0_mask(base);
         else { rd4(base, o0, bf[0], a); piece(0); rd4(base, o1, bf[1], a); piece(1); rd4(base + 16384, o0, af[0], a); piece(2); rd4(base + 16384, o1, af[1], a); piece(3); }
         asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         landed(af[0]); landed(af[1]); landed(bf[0]); landed(bf[1]);
@@ -304,6 +340,7 @@ __global__ __launch_bounds__(512) void k_pp(unsigned long long* out, float* sink
         if constexpr (PIECES == 7) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
         if constexpr (PIECES == 8) { for (int i = 0; i < rot; ++i) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
         if constexpr (PIECES == 4) m1_rot(base);
+        else if constexpr (PIECES == 11) m1_mask(base);
         else { rd4(base + 16384, o0, af[0], a); piece(0); piece(1); rd4(base + 16384, o1, af[1], a); piece(2); piece(3); }
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         landed(af[0]); landed(af[1]);
@@ -382,6 +419,7 @@ int main() {
     if (run_pp<1, 1, 1>("  + b128 reads + pieces (streamed)", d_out, r2, big)) return 1;
     if (run_pp<1, 5, 1>("  + b128 reads + pieces + 8 s_nop per M cluster", d_out, r2, big)) return 1;
     if (run_pp<1, 6, 1>("  + b128 reads + pieces + 8 v_mov per M cluster", d_out, r2, big)) return 1;
+    if (run_pp<1, 11, 1>("  + b128 reads, 16 piece slots per wave, EXEC zero on 12", d_out, r2, big)) return 1;
     if (run_pp<1, 9, 1>("  + b128 reads, pieces in C, wave r starts C 16 r late", d_out, r2, big)) return 1;
     if (run_pp<1, 10, 1>("  + b128 reads, pieces in C, wave r starts C 32 r late", d_out, r2, big)) return 1;
     if (run_pp<2, 9, 1>("  + tr reads, pieces in C, wave r starts C 16 r late", d_out, r2, big)) return 1;
