@@ -8,6 +8,8 @@ from vbnn_amd import _lib as L
 from vbnn_amd.engine import FusedMLP
 from vbnn_amd.nn import fill_normal
 
+if os.environ.get("VBNN_AB_KERNEL"):                     # force a GEMM kernel family BEFORE the engine asks the library what it offers
+    L.check(L.lib().vbnn_debug_set(0, int(os.environ["VBNN_AB_KERNEL"])))     # (vbnn_debug_set key 0: 2 = gemm_nt_v2, 3 = gemm_nt_v3)
 opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype="bf16", seed=3, input_size=784, hidden=[4096, 4096], n_classes=10, keep_transposes=True)
 eng = FusedMLP(opt)
 N = 4096
@@ -31,6 +33,7 @@ def run(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 scheds = [int(a) for a in sys.argv[1:]] or [0, 2]
+
 res = {}
 for rnd in range(5):
     for s in scheds:

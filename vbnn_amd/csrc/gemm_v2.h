@@ -19,7 +19,8 @@
 //               and again on the ds_read_b128 address (rule 21: both sides or neither). With it the
 //               16 rows x 1 chunk a lane group reads fall on 16 distinct 16-byte bank slots
 //               (SQ_LDS_BANK_CONFLICT = 0 measured).
-//   per tile    s_waitcnt vmcnt(G) lgkmcnt(0) -> this wave's G DMAs of tile u have landed (tile u+1's may fly) and its
+//   per tile    (schedules 0 / 2; schedule 4: step_pp below)
+//               s_waitcnt vmcnt(G) lgkmcnt(0) -> this wave's G DMAs of tile u have landed (tile u+1's may fly) and its
 //                                     LDS reads of tile u-1 have RETURNED (v2_wait_barrier: one asm with the barrier)
 //               s_barrier           -> everybody's have; everybody is done reading tile u-1
 //               16 ds_read_b128 + 32 MFMA on tile u, with the G DMAs of tile u+2 (into the buffer tile
@@ -42,9 +43,11 @@ constexpr int v2_stage(int WM) { return v2_a_bytes(WM) + V2_B_BYTES; }
 // LDS per workgroup: the ring, or the epilogue's 18 KiB-per-wave staging if that is larger (2 stages, 4 waves)
 constexpr int v2_lds(int WM, int ST) { return (v2_stage(WM) * ST > 2 * WM * 18432 ? v2_stage(WM) * ST : 2 * WM * 18432) + 16; }   // 147456 / 98304 / 73728 (+ 16 spare)
 
-// DMA schedule: 0 = burst after the barrier; 2 = interleaved with the MFMAs; 4 = 2 with the SIMD partners' DMA slots
-// skewed (measured: no better than 2); -1 = auto: 2 for the 8-wave 256 x 128 tile (+8 % over 0), 0 for the 4-wave
-// 128 x 128 tile (one wave per SIMD has no partner to cover an interleaved DMA issue: 0 is 8 % faster there).
+// Schedule (vbnn_debug_set key 1): 0 = the tile's DMAs in a burst after the barrier; 2 = interleaved with its MFMAs; 4 (r04) = the tile
+// step as ALTERNATING clusters, the workgroup's halves one cluster apart (step_pp: gemm_v3.h's K step on this ring -- at 4096^3 forward
+// 217.7 -> 200.6 us, gradInput 227.6 -> 216.0, accGradParameters 223.9 -> 214.8, bitwise equal); -1 = auto: 4 for the 8-wave 256 x 128
+// tile, 0 for the 4-wave 128 x 128 tile (one wave per SIMD has no partner: no clusters to alternate, and a burst is 8 % faster than
+// interleaving there).
 inline int g_v2_sched = -1;
 inline int g_v2_tile = 0;         // 0: pick 256 x 128 or 128 x 128 by shape; 128 / 256: force (vbnn_debug_set key 2)
 inline int g_v2_psplit = -1;      // pair split of the 256 x 128 tiling: -1 by shape, 0 never, 1 whenever the functor allows (key 5)
@@ -307,11 +310,12 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
 
     std::integral_constant<int, 0> c0;
     std::integral_constant<int, 1> c1;
-    // SCHED 4: the two waves of a SIMD (w and w + 4, MI355X_MICROARCH.md "Two waves per SIMD") put their DMAs on
-    // opposite sides of each four-MFMA group, so one wave's ~80-cycle DMA issue sits beside the other's MFMAs
-    // instead of both stalling together.
-    const bool late = (WM == 4) && (__builtin_amdgcn_readfirstlane(wave) >= 4);
-    (void)late;
+    // SCHED 4 (r04; the 8-wave tiles only): the tile step as ALTERNATING clusters, the workgroup's halves one cluster apart -- gemm_v3.h's
+    // kstep_pp on this kernel's ring: M(u) = tile u's 16 fragment reads with tile u + 2's G pieces between the read groups, closed by
+    // s_waitcnt vmcnt(G) lgkmcnt(0) + s_barrier; C(u) = 32 MFMAs, closed by s_barrier. Waves 4-7 (the SIMD partners of waves 0-3) enter
+    // the stream one barrier late and waves 0-3 leave it one barrier late. Same pieces in the same order, same MFMA order: same bits.
+    constexpr bool PP = SCHED == 4 && WM == 4 && ST == 3;
+    static_assert(SCHED != 4 || PP, "the alternating schedule exists for the 8-wave tile with the three-stage ring");
 
     // ---- prologue: ST - 1 tiles in flight
     issue(0, c0);
@@ -320,6 +324,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     // tile u + LA (LA = ST - 1 tiles of lookahead) is issued while tile u is computed; its operand pair is the pair
     // of tile u when LA = 2 and the other pair when LA = 1 (DUAL alternates pairs tile by tile)
     constexpr int LA = ST - 1;
+    constexpr int LA_ = LA;
     la_stage = (unsigned)(LA % ST) * STAGE;
     {
         const int kidx = DUAL ? (LA >> 1) : LA;
@@ -328,6 +333,85 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
     }
     const int la_dka = 2 * V2_BK * (KM ? (int)lda : 1), la_dkb = 2 * V2_BK * (KM ? (int)ldb : 1);
     // ALWAYS: tile u + LA exists (every step but the last LA): its DMAs are unconditional and the waits constant
+    // eight transpose reads (four fragments of one k-half), issued only; landed4 hands them to the compiler behind the cluster's wait
+    auto tr_issue4 = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, auto lo_c, auto hi_c, bf16x4 (&l)[4], bf16x4 (&h)[4]) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\tds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %2, %9 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %4, %10 offset:%12\n\tds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+                     "ds_read_b64_tr_b16 %6, %11 offset:%12\n\tds_read_b64_tr_b16 %7, %11 offset:%13"
+                     : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(LO), "n"(HI)
+                     : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto landed4 = [&](bf16x4 (&l)[4], bf16x4 (&h)[4]) {
+        asm volatile("" : "+v"(l[0]), "+v"(h[0]), "+v"(l[1]), "+v"(h[1]), "+v"(l[2]), "+v"(h[2]), "+v"(l[3]), "+v"(h[3])::"memory");
+    };
+    auto step_pp = [&](int u, auto pair_c, f32x4 (&acc)[4][4], auto always_c) {
+        constexpr bool ALWAYS = decltype(always_c)::value;
+        const bool more = ALWAYS ? true : (u + LA_ < U);
+        const unsigned char* stage = lds + (u % ST) * STAGE;
+        bf16x8 af[2][4], bf[2][4];
+        bf16x4 al[2][4], ah[2][4], bl[2][4], bh[2][4];
+        auto piece = [&](auto idx_c) { if (more) issue_one_at(pair_c, idx_c); __builtin_amdgcn_sched_barrier(0); };
+        auto rd = [&](auto s_c) {                        // the A, then the B fragments of k-half S
+            constexpr int S = decltype(s_c)::value;
+            if constexpr (KM) {
+                const unsigned sb = (unsigned)(uintptr_t)(ldsb_t)stage;
+                tr_issue4(sb + a_tr[0], sb + a_tr[1], sb + a_tr[2], sb + a_tr[3], std::integral_constant<int, S * 16384>(),
+                          std::integral_constant<int, S * 16384 + 2048>(), al[S], ah[S]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[S][i] = *reinterpret_cast<const bf16x8*>(stage + a_off[S] + i * 16 * 128);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto rdb = [&](auto s_c) {
+            constexpr int S = decltype(s_c)::value;
+            if constexpr (KM) {
+                const unsigned sb = (unsigned)(uintptr_t)(ldsb_t)stage;
+                tr_issue4(sb + b_tr[0], sb + b_tr[1], sb + b_tr[2], sb + b_tr[3], std::integral_constant<int, S * 8192>(),
+                          std::integral_constant<int, S * 8192 + 1024>(), bl[S], bh[S]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[S][j] = *reinterpret_cast<const bf16x8*>(stage + b_off[S] + j * 16 * 128);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // ---------------- M cluster: a read group, a piece (two after the last two groups when the tile has eight pieces)
+        rd(c0); piece(std::integral_constant<int, 0>()); piece(std::integral_constant<int, 1>());
+        rdb(c0); piece(std::integral_constant<int, 2>()); piece(std::integral_constant<int, 3>());
+        rd(c1); piece(std::integral_constant<int, 4>());
+        rdb(c1); piece(std::integral_constant<int, 5>());
+        if constexpr (G == 8) { piece(std::integral_constant<int, 6>()); piece(std::integral_constant<int, 7>()); }
+        // tile u + 1's pieces have landed (tile u + 2's, issued just now, may fly); this cluster's reads are back
+        if constexpr (ALWAYS) v2_wait_barrier<G>();
+        else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (more) v2_wait_barrier<G>(); else v2_wait_barrier<0>(); }
+        if constexpr (KM) {
+            landed4(al[0], ah[0]); landed4(al[1], ah[1]); landed4(bl[0], bh[0]); landed4(bl[1], bh[1]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[s2][i] = __builtin_shufflevector(al[s2][i], ah[s2][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf[s2][i] = __builtin_shufflevector(bl[s2][i], bh[s2][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- C cluster
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], bf[s2][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        la_stage = la_stage == (unsigned)(ST - 1) * STAGE ? 0u : la_stage + STAGE;       // tile u + 1 + LA
+        if constexpr (!DUAL || decltype(pair_c)::value == 1) { la_ka += la_dka; la_kb += la_dkb; }
+    };
     auto step = [&](int u, auto pair_c, auto next_c, f32x4 (&acc)[4][4], auto always_c) {
         constexpr bool ALWAYS = decltype(always_c)::value;
         auto la_c = std::conditional_t<ST == 3, decltype(pair_c), decltype(next_c)>();
@@ -379,15 +463,11 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
             };
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (SCHED == 4) {                        // late waves issue their DMA AHEAD of the four MFMAs ...
-                    if (more && late) slot(sidx, i);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                if (SCHED == 2 || SCHED == 4) {          // ... early waves BEHIND them: one DMA per four MFMAs either way
-                    if (more && (SCHED == 2 || !late)) slot(sidx, i);
+                if (SCHED == 2) {                        // one DMA behind every four MFMAs
+                    if (more) slot(sidx, i);
                     __builtin_amdgcn_sched_barrier(0);   // keep each DMA where it was put
                 }
             }
@@ -395,7 +475,21 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_nt_v2(const bf16_t* __restri
         la_stage = la_stage == (unsigned)(ST - 1) * STAGE ? 0u : la_stage + STAGE;       // tile u + 1 + LA
         if constexpr (!DUAL || decltype(la_c)::value == 1) { la_ka += la_dka; la_kb += la_dkb; }
     };
-    if (DUAL) {
+    if constexpr (PP) {
+        // every wave: tile 0 has landed, for everybody behind the barrier; then the late half's extra barrier, answered by the early half's at
+        // the end of the stream
+        if (U > 1) v2_wait_barrier<G>(); else v2_wait_barrier<0>();
+        if (wave >= 4) asm volatile("s_barrier" ::: "memory");
+        int u = 0;
+        if (DUAL) {
+            for (; u + 1 + LA < U; u += 2) { step_pp(u, c0, acc1, std::true_type()); step_pp(u + 1, c1, acc2, std::true_type()); }
+            for (; u < U; u += 2) { step_pp(u, c0, acc1, std::false_type()); step_pp(u + 1, c1, acc2, std::false_type()); }
+        } else {
+            for (; u + LA < U; ++u) step_pp(u, c0, acc1, std::true_type());
+            for (; u < U; ++u) step_pp(u, c0, acc1, std::false_type());
+        }
+        if (wave < 4) asm volatile("s_barrier" ::: "memory");
+    } else if (DUAL) {
         int u = 0;
         for (; u + 1 + LA < U; u += 2) { step(u, c0, c1, acc1, std::true_type()); step(u + 1, c1, c0, acc2, std::true_type()); }
         for (; u < U; u += 2) { step(u, c0, c1, acc1, std::false_type()); step(u + 1, c1, c0, acc2, std::false_type()); }
@@ -571,7 +665,9 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
             psplit = !pairs && g_v2_tile != 128 && gemm_v2_psplit_by_shape(M, N, K);
         if (kmajor && !psplit) return VBNN_ERR_UNSUPPORTED;
         const bool small = !psplit && (pairs || g_v2_tile == 128 || (g_v2_tile == 0 && t256 < 192 && t128 > t256));
-        const int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small && !pairs ? 0 : 2);
+        // (4, the alternating clusters, needs two waves per SIMD: the four-wave tiles keep 0 / 2 whatever the key says)
+        int sched = (g_v2_sched == 0 || g_v2_sched == 2 || g_v2_sched == 4) ? g_v2_sched : (small && !pairs ? 0 : 4);
+        if ((small || pairs) && sched == 4) sched = 2;
         const int vi0 = pairs ? 2 : small ? 1 : 0;       // variant: 256 x 128 / 128 x 128 / 128 x 128 co-resident / pair split
         const int si = sched >> 1;                       // 0, 1, 2
         const void* kern;
@@ -584,7 +680,7 @@ static int launch_gemm_v2(vbnn_ctx* ctx, const T* A, const T* A2, int64_t lda, c
             threads = 256; lds_bytes = v2_lds(2, 3); bm = 128;
         } else if (psplit) {                             // the single-accumulator instantiations, two blocks per tile
             if (kmajor)
-                kern = (const void*)gemm_nt_v2<false, 2, 4, 3, Epi, true>;
+                kern = sched == 4 ? (const void*)gemm_nt_v2<false, 4, 4, 3, Epi, true> : (const void*)gemm_nt_v2<false, 2, 4, 3, Epi, true>;
             else
                 kern = sched == 0 ? (const void*)gemm_nt_v2<false, 0, 4, 3, Epi>
                      : sched == 2 ? (const void*)gemm_nt_v2<false, 2, 4, 3, Epi> : (const void*)gemm_nt_v2<false, 4, 4, 3, Epi>;
