@@ -55,8 +55,9 @@ const char* vbnn_last_error(void);
  * kernel, 2 = the pipelined bf16 kernel whenever the operands allow it, 3 = its two-pass 256 x 256 variant
  * whenever the shape and outputs allow it (whole tiles, the fused configuration). */
 #define VBNN_DEBUG_GEMM_KERNEL 0
-#define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel DMA schedule: -1 = by tile (default), 0 = burst after the barrier,
-                                      2 = interleaved with the MFMAs, 4 = 2 with skewed SIMD partners (gemm_v2.h) */
+#define VBNN_DEBUG_V2_SCHEDULE 1   /* pipelined kernel schedule: -1 = by tile (default), 0 = DMAs in a burst after the barrier,
+                                      2 = interleaved with the MFMAs, 4 = alternating read / MFMA clusters, the workgroup's
+                                      halves one cluster apart (8-wave tiles only; the same results whichever: gemm_v2.h) */
 #define VBNN_DEBUG_V2_TILE 2       /* pipelined kernel block tile: 0 = by shape (default), 256 = 256 x 128, 128 = 128 x 128,
                                       64 = 128 x 128 with a 2-stage ring, two workgroups per CU */
 #define VBNN_DEBUG_V3_MIN_K 4      /* shortest K for which shape selection picks the two-pass 256 x 256 kernel (default 704) */

@@ -34,8 +34,8 @@ int vbnn_fill_normal(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int6
                      uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
                      float scale);
 int vbnn_fill_normal_hw(vbnn_ctx* ctx, float* out, int64_t rows, int64_t cols, int64_t ld,
-                     uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
-                     float scale);
+                        uint64_t seed, uint32_t stream, uint32_t layer, uint32_t draw, int64_t row0,
+                        float scale);
 int vbnn_box_muller_forms(vbnn_ctx* ctx, const uint32_t* x0, const uint32_t* x1, float* z_exact, float* z_hw, int64_t n);
 int vbnn_compute_prior(vbnn_ctx* ctx, const float* means, const float* lvars, int64_t W,
                        float* vars, float* stdv, float* mu_sqe, double* stats);
@@ -187,13 +187,13 @@ int vbnn_mse_forward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* t
                      float inv_nd, float* g, int64_t ld_g, int accumulate, double* loss_sum_dev);
 int vbnn_mse_backward(vbnn_ctx* ctx, const float* y, int64_t ld_y, const float* target, int64_t ld_t, int64_t N, int64_t D,
                       float inv_nd, float* g, int64_t ld_g);
-int vbnn_head_forward_slots(vbnn_ctx* ctx, const float* slots, int64_t n_slots, const float* bias, const int32_t* target,
-                            int64_t N, int64_t C, float inv_n, float* logits, float* out, float* g_logits, int accumulate,
-                            double* loss_sum_dev, int32_t* correct_dev, int64_t rows_per_draw);
 int vbnn_head_forward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                       const float* bias, const int32_t* target, int64_t N, int64_t H, int64_t C, float inv_n,
                       float* logits, float* out, float* g_logits, int accumulate, double* loss_sum_dev,
                       int32_t* correct_dev, int64_t rows_per_draw);
+int vbnn_head_forward_slots(vbnn_ctx* ctx, const float* slots, int64_t n_slots, const float* bias, const int32_t* target,
+                            int64_t N, int64_t C, float inv_n, float* logits, float* out, float* g_logits, int accumulate,
+                            double* loss_sum_dev, int32_t* correct_dev, int64_t rows_per_draw);
 int vbnn_head_backward(vbnn_ctx* ctx, int dtype, const void* h, int64_t ld_h, const void* w3, int64_t ld_w,
                        const float* g_logits, int64_t N, int64_t H, int64_t C, int accumulate, float* gradWeight,
                        float* gradBias, float* gradBias_prev, int relu_mask, const void* r_prev, int64_t ld_r_prev,
