@@ -117,6 +117,19 @@ def measured_traffic(kernel_name, cfg_name):
         return None
 
 
+def box_calibration(L, ctx_handle):
+    """Two fixed probes of THIS box, run in this process (vbnn_box_calibrate, csrc/calib.hip; ~40 ms): a register-only MFMA loop
+    on every SIMD -> the clock the chip holds under a pure matrix load and the MFMA rate it reaches there; a 512 MiB -> 512 MiB
+    copy -> the HBM rate. The boxes of a pool differ by 5-7 % on one binary: with these a round-to-round delta of the line
+    can be read as code or as box."""
+    import ctypes as C
+    info = L.BoxInfo()
+    L.check(L.lib().vbnn_box_calibrate(ctx_handle, C.byref(info)))
+    return {"mfma_clock_ghz": round(info.mfma_clock_ghz, 4), "mfma_tflops": round(info.mfma_tflops, 1),
+            "mfma_frac_of_dense_peak": round(info.mfma_tflops / PEAK_TFLOPS["bf16"], 4), "mfma_probe_ms": round(info.mfma_ms, 4),
+            "hbm_TBps": round(info.hbm_TBps, 3), "hbm_probe_ms": round(info.hbm_ms, 4), "hbm_probe_bytes": int(info.hbm_bytes), "cus": int(info.cus)}
+
+
 def cpu_baseline(cfg, budget_s=25.0):
     """The reference's op sequence on the host cores (oracle/ref_numpy.py), bounded sample: once with every core the
     BLAS pool has (`value`, `cores`) and once at the reference's own default of 8 threads (config.lua:5 `threads = 8`,
@@ -481,6 +494,7 @@ def main():
     ap.add_argument("--prepare-each-step", action="store_true", help="round 1's protocol: the parameter sweep inside every step")
     ap.add_argument("--with-update", action="store_true", help="(default since r04: on) also time step + optimiser update, reported beside the metric as train_step")
     ap.add_argument("--no-train-step", action="store_true", help="skip the train_step entry (step + FusedMLP.update)")
+    ap.add_argument("--no-box", action="store_true", help="skip the box block (vbnn_box_calibrate: the MFMA clock / rate and the HBM rate this device holds)")
     ap.add_argument("--no-deep-config", action="store_true", help="skip the deep_config entry (BASELINE configs[4] measured beside the headline)")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
     ap.add_argument("--backward-order", default="auto", choices=["auto", "dx-first", "layerwise"], help="A/B: every updateGradInput first "
@@ -630,6 +644,17 @@ def main():
     eng.prepare()                                        # once: afterwards the update kernel maintains shadows + statistics
     for _ in range(args.warmup):
         step()
+    # the box's own speed, measured here and now (rank 0's device; every rank runs it so the ranks stay in step): after the
+    # warm-up -- the clock has ramped -- and before the timed blocks; once more behind them (`after_timed_blocks`)
+    box = None
+    if not args.no_box:
+        try:
+            torch.cuda.synchronize()
+            box = box_calibration(L, eng.ctx.h)
+            for _ in range(3):
+                step()                                   # (the probes' last launches are a different load: back into the step's regime)
+        except Exception as e:                           # noqa: BLE001 -- never at the price of the headline
+            box = {"error": f"{type(e).__name__}: {e}"[:300]}
     if use_graph:
         torch.cuda.synchronize()
         graph = eng.capture_step(issue)                   # the same calls, recorded once; every replay draws its own noise
@@ -648,6 +673,11 @@ def main():
         sys.exit(3)
     loss, correct = eng.loss_and_accuracy()
     ms = sorted(wall)[len(wall) // 2]
+    if box is not None and "error" not in box:
+        try:
+            box["after_timed_blocks"] = {k: v for k, v in box_calibration(L, eng.ctx.h).items() if k in ("mfma_clock_ghz", "mfma_tflops", "hbm_TBps")}
+        except Exception as e:                           # noqa: BLE001
+            box["after_timed_blocks"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     # the SAME step (same launch order, same two-launch accGradParameters) with the collective calls left out: what the
     # exchange costs beyond the compute it overlaps with = ms - this
     noex = None
@@ -805,6 +835,16 @@ def main():
                          "timed_region_kernels_ms": {k: round(v_, 4) for k, v_ in live.items()},
                          "isolated_kernels_ms": kall},
         }
+        if box is not None:
+            out["box"] = box
+            ghz = box.get("mfma_clock_ghz")
+            if ghz:
+                # 2.5 PFLOP/s (157.3 TFLOP/s fp32) is the dense peak at 2.4 GHz; at the clock this box holds under a pure matrix load the
+                # ceiling is peak x ghz / 2.4 -- the same kernel time against THAT ceiling
+                out["roofline"]["held_clock_ghz"] = ghz
+                out["roofline"]["peak_at_held_clock"] = round(peak * ghz / 2.4, 1)
+                out["roofline"]["frac_at_held_clock"] = round(achieved / (peak * ghz / 2.4), 4)
+                out["config"]["step_frac_of_mfma_peak_at_held_clock"] = round(fps * N / (ms * 1e-3) / 1e12 / (peak * ghz / 2.4), 4)
         if floor_us is not None and graph is not None:
             out["roofline"]["launch_floor"] = {"us_per_graph_node": round(floor_us, 3), "kernel_nodes": graph.kernel_nodes,
                                                "ms_per_step": round(floor_us * graph.kernel_nodes * 1e-3, 4),

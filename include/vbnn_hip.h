@@ -34,7 +34,7 @@ extern "C" {
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
 #endif
 
-#define VBNN_ABI_VERSION 5
+#define VBNN_ABI_VERSION 6
 #define VBNN_KPAD 64            /* packed leading dimensions are multiples of this */
 
 enum { VBNN_OK = 0, VBNN_ERR_INVALID = 1, VBNN_ERR_HIP = 2, VBNN_ERR_NOMEM = 3, VBNN_ERR_UNSUPPORTED = 4 };
@@ -480,6 +480,29 @@ int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up);
 int vbnn_p2p_set_timeout(vbnn_p2p* p, double seconds);
 int vbnn_p2p_clear_status(vbnn_p2p* p);
 int vbnn_p2p_destroy(vbnn_p2p* p);
+/* (ABI 6) The data kernels are built to CO-RESIDE with the GEMM launches they overlap -- no LDS, at most 48 VGPRs (what two
+ * 226-register GEMM waves leave of a SIMD's file), `world` loads in flight per lane -- so their grids are small:
+ * vbnn_p2p_set_grid(reduce-scatter workgroups, all-gather workgroups PER PEER; 0 = keep; defaults 128 and 16, or
+ * VBNN_P2P_RS_BLOCKS / VBNN_P2P_AG_BLOCKS at create). vbnn_p2p_standin (LAB, world == 1 only): vbnn_p2p_allreduce then runs what one
+ * rank of a sim_world-rank exchange runs -- same barriers, kernels, grids, stream, event -- against this arena standing in for its
+ * peers', each phase paced to the wall time `inbound_GBps` of link bandwidth would need (0: unpaced): what the exchange costs the
+ * launches beside it, priced on ONE GPU (tools/overlap_standin.py). The arena holds nothing meaningful afterwards. 0 switches off. */
+int vbnn_p2p_set_grid(vbnn_p2p* p, int rs_blocks, int ag_blocks_per_peer);
+int vbnn_p2p_standin(vbnn_p2p* p, int sim_world, double inbound_GBps);
+
+/* ---- (ABI 6) what THIS device holds, measured in the run that reports a throughput (bench.py's `box` block) ------------------
+ * The boxes of a pool differ by 5-7 % on one binary (the clock a power-bound chip holds); the reference's only timing hook is a
+ * commented-out sys.clock() (main.lua:20). vbnn_box_calibrate runs two fixed probes on the context's stream and BLOCKS until
+ * they are done (~40 ms; 1 GiB of scratch, freed again): a register-only MFMA loop on every SIMD (2 waves x 2^15
+ * v_mfma_f32_16x16x32_bf16, live operands) -- mfma_clock_ghz = median over workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz,
+ * mfma_tflops = its flops / its time -- and a 512 MiB -> 512 MiB copy: hbm_TBps (bytes read + written per second). */
+typedef struct vbnn_box_info {
+    double mfma_clock_ghz, mfma_tflops, mfma_ms;
+    double hbm_TBps, hbm_ms;
+    int64_t hbm_bytes;
+    int cus, reserved;
+} vbnn_box_info;
+int vbnn_box_calibrate(vbnn_ctx* ctx, vbnn_box_info* out);
 
 /* ---- a whole step as ONE graph launch (launch-bound configurations: BASELINE configs[1], the reference's own batch-1
  * S = 30 operating point, config.lua:11,32) ----------------------------------------------------------------------------

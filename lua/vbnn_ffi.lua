@@ -171,6 +171,15 @@ int vbnn_p2p_status(vbnn_p2p* p, int* rank, int* world, unsigned* gave_up);
 int vbnn_p2p_set_timeout(vbnn_p2p* p, double seconds);
 int vbnn_p2p_clear_status(vbnn_p2p* p);
 int vbnn_p2p_destroy(vbnn_p2p* p);
+int vbnn_p2p_set_grid(vbnn_p2p* p, int rs_blocks, int ag_blocks_per_peer);
+int vbnn_p2p_standin(vbnn_p2p* p, int sim_world, double inbound_GBps);
+typedef struct vbnn_box_info {
+    double mfma_clock_ghz, mfma_tflops, mfma_ms;
+    double hbm_TBps, hbm_ms;
+    int64_t hbm_bytes;
+    int cus, reserved;
+} vbnn_box_info;
+int vbnn_box_calibrate(vbnn_ctx* ctx, vbnn_box_info* out);
 int vbnn_sample(vbnn_ctx* ctx, uint32_t* draw_dev, uint32_t by);
 typedef struct vbnn_graph vbnn_graph;
 int vbnn_capture_begin(vbnn_ctx* ctx);

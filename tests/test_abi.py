@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes table covers exactly the header
     assert sorted(L.exported_symbols()) == names
     L.lib()
-    assert L.lib().vbnn_abi_version() == 5
+    assert L.lib().vbnn_abi_version() == 6
 
 
 def test_no_gpu_is_an_error_not_a_fallback():
@@ -63,7 +63,7 @@ def test_ctypes_structs_match_the_header():
     from vbnn_amd import _lib as L
     structs = {"vbnn_fwd_args": L.FwdArgs, "vbnn_dx_args": L.DxArgs, "vbnn_dw_args": L.DwArgs,
                "vbnn_prep_desc": L.PrepDesc, "vbnn_pack_desc": L.PackDesc, "vbnn_adam_cfg": L.AdamCfg,
-               "vbnn_update_desc": L.UpdateDesc, "vbnn_head_args": L.HeadArgs}
+               "vbnn_update_desc": L.UpdateDesc, "vbnn_head_args": L.HeadArgs, "vbnn_box_info": L.BoxInfo}
     cfield = lambda f: f.rstrip("_")                       # `lambda` is a Python keyword: the mirror calls it lambda_
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():

@@ -121,3 +121,25 @@ def test_the_barrier_checker_flags_r02s_code_shape(tmp_path):
         f.write_text(text)
         res = subprocess.run([sys.executable, chk, str(f)], capture_output=True, text=True)
         assert res.returncode == want, (name, res.stdout)
+
+
+def test_exchange_kernels_fit_beside_the_gemm_workgroups_they_overlap():
+    """Co-residency, held on the SHIPPED code objects (r05): the data-parallel exchange's data kernels run
+    WHILE the backward's two-pass GEMM launches hold every CU -- one 512-thread workgroup per CU, all 160 KiB of LDS, two waves per
+    SIMD. A SIMD's register file is 512 VGPRs per lane, allocated in granules of 8: what two GEMM waves leave must hold an
+    exchange wave, or the exchange waits for a CU to drain and the next 256-tile launch finds a CU short (two rounds). So: every
+    gemm_nt_v3 instantiation allocates at most 232 registers and spills nothing, every k_p2p data kernel at most 48, no LDS, no
+    scratch (tools/kernel_regs.py reads the ELF notes)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_regs
+    ks = kernel_regs.kernels()
+    gran = lambda v: (int(v) + 7) // 8 * 8
+    v3 = [k for k in ks if "gemm_nt_v3" in k["name"]]
+    p2p = [k for k in ks if "k_p2p_reduce_scatter" in k["name"] or "k_p2p_all_gather" in k["name"]]
+    assert len(v3) >= 10 and len(p2p) >= 8, (len(v3), len(p2p))
+    worst = max(gran(k["vgpr"]) + gran(k["agpr"]) for k in v3)
+    assert worst <= 232, f"a two-pass GEMM allocates {worst} registers: two waves leave {512 - 2 * worst} per SIMD"
+    assert all(int(k["spill"]) == 0 and int(k["scratch"]) == 0 for k in v3), [k["name"][:60] for k in v3 if int(k["spill"]) or int(k["scratch"])]
+    for k in p2p:
+        assert gran(k["vgpr"]) + gran(k["agpr"]) <= 512 - 2 * worst, (k["name"][:80], k["vgpr"])
+        assert int(k["lds"]) == 0 and int(k["scratch"]) == 0 and int(k["spill"]) == 0, k

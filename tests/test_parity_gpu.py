@@ -574,6 +574,42 @@ def test_split_two_pass_gradient_against_rounding_emulation(oracle, nnmod, hidde
         L.check(L.lib().vbnn_debug_set(8, -1))
 
 
+def test_nan_in_the_backward_shows_in_the_loss_and_the_layers_gradients_but_not_below_the_two_pass_gradinput(nnmod):
+    """The one place where the bf16 path is NOT NaN-transparent, pinned. gemm_v3's
+    updateGradInput carries the ReLU mask of the module in between through its second pass as a quiet NaN in the accumulator and
+    reads it back as `a != a` (csrc/epilogues.h, EpiDx::fold / apply_folded): a GENUINE NaN arriving in gradOutput -- a diverged
+    run -- is zeroed in g_prev with it, where the reference's model:backward (mlp.lua:79) would carry it into every layer below.
+    What still shows it, and what a host must therefore look at before update(): the loss, and the gradients of the layer the
+    NaN arrived at. Here: one NaN planted in the final Linear's weight -> NaN logits for every row -> the loss is NaN, the last
+    VB layer's d/dmeans and the final Linear's gradWeight are NaN; below the two-pass gradInput launch g / gv are finite (zeros)
+    and the first layer's gradients are finite. (train.py raises on the non-finite loss; INTEGRATION.md, error behaviour.)"""
+    from vbnn_amd import _lib as L
+    from vbnn_amd.engine import FusedMLP
+    I0, N, hidden = 64, 256, [256, 256]
+    L.check(L.lib().vbnn_debug_set(0, 3))                # the two-pass 256 x 256 kernel wherever the shape allows (the wide configuration's kernel)
+    try:
+        opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True)
+        eng = FusedMLP(opt)
+        x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
+        nnmod.fill_normal(x, SEED, 4, 0, 0)
+        t = eng_t(N)
+        eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t)
+        loss0, _ = eng.loss_and_accuracy()
+        assert eng.vb[1].dx_km, "layer 2's gradInput must run on the two-pass kernel for this test to test anything"
+        assert np.isfinite(loss0) and bool(torch.isfinite(eng.grads).all())
+        assert float(eng.vb[0].g_s.t.float().abs().max()) > 0.0
+        eng.weight3[3, 17] = float("nan")
+        eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t)
+        loss, _ = eng.loss_and_accuracy()
+        assert np.isnan(loss), loss                                                     # the criterion shows it
+        assert bool(torch.isnan(eng.gradWeight3).any()) and bool(torch.isnan(eng.vb[1].gradWeight).any())   # and so do the gradients above
+        g_below = eng.vb[0].g_s.t.float()
+        assert bool(torch.isfinite(g_below).all()) and float(g_below.abs().max()) == 0.0, "the quirk: g below the two-pass gradInput is zeroed, not NaN"
+        assert bool(torch.isfinite(eng.vb[0].gradWeight).all()) and bool(torch.isfinite(eng.vb[0].gradSum).all())
+    finally:
+        L.check(L.lib().vbnn_debug_set(0, 0))
+
+
 def test_wide_training_steps_repeat_bit_for_bit(nnmod):
     """The race screen of the pipelined kernels at bench size: two engines from the same seed run the same three training steps of the
     wide configuration (every timed launch: two-pass 256 x 256 forward / gradInput / accGradParameters with their alternating K steps,
@@ -939,6 +975,11 @@ def test_head_logits_from_the_forward_tiles_equal_the_heads_own_pass_over_h(orac
         opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True, **extra)
         eng = FusedMLP(opt)
         eng.bias3.copy_(torch.linspace(-0.5, 0.5, 10, device="cuda"))
+        # NON-ZERO VB biases: what every layer holds after its first SGD step. The single-GEMM launch of a
+        # MAP / weight-noise pass has W x in its accumulators, not W x + b: with the biases at their initial zero the logits
+        # taken from relu(W x) passed this test.
+        for v in eng.vb:
+            v.bias.copy_(torch.linspace(-0.4, 0.6, v.O, device="cuda"))
         runs = []
         for rep in range(2):
             eng.draw = 0
@@ -967,6 +1008,27 @@ def test_head_logits_from_the_forward_tiles_equal_the_heads_own_pass_over_h(orac
     assert abs(a[4] - b[4]) <= 1e-6 * abs(b[4])
     rel = np.linalg.norm(a[3] - b[3]) / np.linalg.norm(b[3])
     assert rel <= 1e-4, f"gradient arenas of the two head forms: relative Frobenius {rel:.3e}"
+    # weight-noise mode (the reference's own estimator, VBLinear.lua:49-64): every forward is the single-GEMM launch, with backward
+    wn = {}
+    for name, extra in (("slots", {}), ("from_h", dict(head_from_h=True))):
+        opt = opt_for("wn", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True, **extra)
+        eng = FusedMLP(opt)
+        eng.bias3.copy_(torch.linspace(-0.5, 0.5, 10, device="cuda"))
+        for v in eng.vb:
+            v.bias.copy_(torch.linspace(-0.4, 0.6, v.O, device="cuda"))
+        eng.resetGradients(); eng.prepare(); eng.sample(); eng.run(x, t)
+        loss, hits = eng.loss_and_accuracy()
+        assert (eng.n_head_slots > 0) == (name == "slots"), (name, eng.n_head_slots)
+        h = host(eng.h_s.t[:, :hidden[-1]].float()).astype(np.float64)
+        w3 = host(eng.w3_s.t[:, :hidden[-1]].float()).astype(np.float64)
+        want = h @ w3.T + host(eng.bias3).astype(np.float64)
+        err = np.abs(host(eng.logits) - want)
+        assert (err <= 4e-6 * (np.abs(h) @ np.abs(w3).T) + 1e-6).all(), f"wn {name}: max {err.max():.3e}"
+        wn[name] = (loss, hits, host(eng.grads).copy())
+    a, b = wn["slots"], wn["from_h"]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]) and abs(a[1] - b[1]) <= 2, (a[0], b[0], a[1], b[1])
+    rel = np.linalg.norm(a[2] - b[2]) / np.linalg.norm(b[2])
+    assert rel <= 1e-4, f"weight-noise gradient arenas of the two head forms: relative Frobenius {rel:.3e}"
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -74,6 +74,11 @@ class DwArgs(C.Structure):
                 ("mu_s", _vp), ("var_s", _vp), ("ld_w", _i64), ("part", _i), ("draw_dev", _vp)]
 
 
+class BoxInfo(C.Structure):           # vbnn_box_info
+    _fields_ = [("mfma_clock_ghz", C.c_double), ("mfma_tflops", C.c_double), ("mfma_ms", C.c_double), ("hbm_TBps", C.c_double),
+                ("hbm_ms", C.c_double), ("hbm_bytes", _i64), ("cus", _i), ("reserved", _i)]
+
+
 class HeadArgs(C.Structure):          # vbnn_head_args
     _fields_ = [("h", _vp), ("ld_h", _i64), ("w3", _vp), ("ld_w", _i64), ("bias", _vp), ("target", _vp),
                 ("N", _i64), ("H", _i64), ("C", _i64), ("rows_per_draw", _i64), ("inv_n", _f), ("accumulate", _i),
@@ -147,6 +152,9 @@ _SIGS = {
     "vbnn_p2p_set_timeout": ([_vp, C.c_double], _i),
     "vbnn_p2p_clear_status": ([_vp], _i),
     "vbnn_p2p_destroy": ([_vp], _i),
+    "vbnn_p2p_set_grid": ([_vp, _i, _i], _i),
+    "vbnn_p2p_standin": ([_vp, _i, C.c_double], _i),
+    "vbnn_box_calibrate": ([_vp, C.POINTER(BoxInfo)], _i),
     "vbnn_sample": ([_vp, _vp, _u32], _i),
     "vbnn_capture_begin": ([_vp], _i),
     "vbnn_capture_end": ([_vp, C.POINTER(_vp)], _i),

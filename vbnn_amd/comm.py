@@ -31,15 +31,28 @@ class TorchExchange:
         for w in self.works:
             w.wait()
         self.works = []
+        for piece in getattr(self, "_poison", []):             # (reduce_scatter: what this rank was not given)
+            piece.fill_(float("nan"))
+        self._poison = []
         for dst, src in getattr(self, "_copyback", []):        # (all_gather: pieces gathered into temporaries)
             dst.copy_(src)
         self._copyback = []
 
-    # the two halves as calls of their own (sharded-update exchange). The rehearsal transport has no in-place reduce-scatter:
-    # an all-reduce of the region leaves every rank's slice with the same sums a reduce-scatter would (and the rest too).
+    # the two halves as calls of their own (sharded-update exchange), with the C ABI's in-place slicing
+    # (vbnn_comm_reduce_scatter: recvbuff = buf + rank * n_per_rank; the other slices are undefined afterwards): slice r is
+    # REDUCED to rank r alone -- one dist.reduce per slice, the offset arithmetic of the product path -- and every slice this
+    # rank does not own is then POISONED (NaN), so that host logic which reads a sum it was not given fails a rehearsal or a
+    # CPU test instead of passing on an all-reduce's leftovers.
     def reduce_scatter(self, buf, n_per_rank):
-        assert buf.numel() == n_per_rank * self.dist.get_world_size(self.pg)
-        self.allreduce(buf)
+        world, rank = self.dist.get_world_size(self.pg), self.dist.get_rank(self.pg)
+        flat = buf.reshape(-1)
+        assert flat.data_ptr() == buf.data_ptr() and flat.numel() == n_per_rank * world
+        for r in range(world):
+            self.works.append(self.dist.reduce(flat[r * n_per_rank:(r + 1) * n_per_rank], dst=self.dist.get_global_rank(self.pg, r) if self.pg is not None else r,
+                                               op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        if not hasattr(self, "_poison"):
+            self._poison = []
+        self._poison += [flat[r * n_per_rank:(r + 1) * n_per_rank] for r in range(world) if r != rank]
 
     def all_gather(self, buf):
         world, rank = self.dist.get_world_size(self.pg), self.dist.get_rank(self.pg)
@@ -185,6 +198,16 @@ class P2PExchange:
         off, n = self._region(buf)
         assert n % self.world == 0
         L.check(L.lib().vbnn_p2p_all_gather(self.h, off, n // self.world))
+
+    def set_grid(self, rs_blocks=0, ag_blocks_per_peer=0):
+        """Workgroups of the reduce-scatter / of the all-gather per peer (0: keep). The data kernels co-reside with the GEMMs they
+        overlap (no LDS, <= 48 VGPRs): small grids, csrc/p2p.hip."""
+        L.check(L.lib().vbnn_p2p_set_grid(self.h, int(rs_blocks), int(ag_blocks_per_peer)))
+
+    def standin(self, sim_world, inbound_GBps=0.0):
+        """LAB, one rank: allreduce() runs what a rank of a sim_world-rank exchange runs, paced to `inbound_GBps` of link bandwidth
+        (tools/overlap_standin.py). The arena holds nothing meaningful afterwards; 0 switches it off."""
+        L.check(L.lib().vbnn_p2p_standin(self.h, int(sim_world), float(inbound_GBps)))
 
     def gave_up(self):
         """Blocks until the exchange stream is idle; the epoch of a barrier that timed out waiting for a peer, or 0."""

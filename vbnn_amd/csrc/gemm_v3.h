@@ -741,12 +741,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_v3(const bf16_t* __restrict__ 
             }
             const bool relu = epi.relu != 0;
             float* const sl = epi.head_slots + ((int64_t)(tm * 2 + wr) * epi.N + (n0 + wc * 64)) * 16 + hc16 * 16 + 4 * hq4;
+            // The SINGLE-GEMM launch (MAP / weight-noise forward: zero_acc, then one pass) holds W x WITHOUT the bias -- there
+            // apply_fast adds it only when it stores h (the logits came from relu(W x), wrong as soon as a VB bias
+            // is non-zero, i.e. after the first SGD step). The lane's 32 bias values, added exactly as apply_fast adds them.
+            f32x4 hbias[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hbias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!DUAL) {
+                const float* bp = epi.fold_bias_ptr();
+                if (bp) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) hbias[i] = *reinterpret_cast<const f32x4*>(bp + (m0 + wr * 128) + 16 * i + 4 * hq4);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
-                    const f32x4 a0 = acc[2 * pr][j], a1 = acc[2 * pr + 1][j];
+                    f32x4 a0 = acc[2 * pr][j], a1 = acc[2 * pr + 1][j];
+                    if constexpr (!DUAL) { a0 += hbias[2 * pr]; a1 += hbias[2 * pr + 1]; }
                     bf16x8 hb;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {

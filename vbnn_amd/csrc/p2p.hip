@@ -78,36 +78,75 @@ __device__ __forceinline__ bool p2p_dead(const unsigned* status) {
     return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
 }
 
-// out[i] = sum over ranks p = 0 .. world - 1 of arena_p[base + i], i in [0, n): into this rank's own arena
-__global__ __launch_bounds__(256) void k_p2p_reduce_scatter(P2PArenas peers, int rank, int world, size_t base, int64_t n, int vec,
-                                                            const unsigned* status) {
+// ---- the data kernels. What they must be ("the exchange kernels are sized to fill the chip, the GEMMs they must overlap
+// leave no room for them"): the launches they run beside are one 512-thread workgroup per CU with ALL 160 KiB of LDS and 209-226
+// VGPRs at two waves per SIMD -- 2 x 232 of a SIMD's 512 registers -- so what is left on every SIMD is 48 registers, no LDS and
+// six wave slots. A data kernel that wants to CO-RESIDE with such a workgroup (instead of waiting for a CU to drain and then
+// keeping a GEMM tile off it: a 256-tile launch with one CU missing is two rounds) therefore uses no LDS and at most 48 VGPRs
+// (__attribute__((amdgpu_num_vgpr(48))): the compiler would spill before it crossed that line; tools/kernel_regs.py shows 40-44),
+// and gets its bandwidth from loads IN FLIGHT rather than from waves: the world is a template parameter, a lane issues the W
+// 16-byte loads of an element group before it adds anything (rank order: ((a0 + a1) + a2) + ..., the bits r03's rolled loop gave),
+// so ~100 workgroups keep seven links busy where the rolled loop (one dependent load at a time) needed a thousand.
+// PACED (the one-GPU STAND-IN only, vbnn_p2p_standin): iteration k of a workgroup does not start before k / iters of the phase's
+// wall-time budget has passed (s_memrealtime, s_sleep between looks) -- a wave that waits for a link looks to its CU like a wave
+// that sleeps: it holds its slot and registers and issues nothing.
+__device__ __forceinline__ void p2p_pace(unsigned long long t0, unsigned long long ticks, int64_t k, int64_t iters) {
+    const unsigned long long due = t0 + (unsigned long long)((double)ticks * (double)k / (double)(iters > 0 ? iters : 1));
+    while (__builtin_amdgcn_s_memrealtime() < due) __builtin_amdgcn_s_sleep(16);
+}
+
+// out[i] = sum over ranks p = 0 .. W - 1 of arena_p[base + i], i in [0, n): into this rank's own arena
+template <int W, bool PACED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48)))
+void k_p2p_reduce_scatter(P2PArenas peers, int rank, size_t base, int64_t n, int vec, const unsigned* status, unsigned long long pace_ticks) {
     if (p2p_dead(status)) return;
     float* out = peers.a[rank] + base;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long t0 = 0;
+    if constexpr (PACED) t0 = __builtin_amdgcn_s_memrealtime();
     if (vec) {
         const int64_t n4 = n >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-            f32x4 s = reinterpret_cast<const f32x4*>(peers.a[0] + base)[i];
-            for (int p = 1; p < world; ++p) s += reinterpret_cast<const f32x4*>(peers.a[p] + base)[i];
+        const int64_t iters = (n4 + stride - 1) / stride;
+        int64_t k = 0;
+        for (int64_t i = first; i < n4; i += stride, ++k) {
+            if constexpr (PACED) p2p_pace(t0, pace_ticks, k, iters);
+            // four peers' loads in flight at a time (48 registers is all a wave gets beside two GEMM waves: see above); the
+            // adds stay in rank order across the batches
+            f32x4 s;
+#pragma unroll
+            for (int p0 = 0; p0 < W; p0 += 4) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p0 + u < W) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(peers.a[p0 + u] + base) + i);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p0 + u < W) { if (p0 + u == 0) s = v[u]; else s += v[u]; }
+                __builtin_amdgcn_sched_barrier(0);            // (or the scheduler hoists the next batch's loads above these adds)
+            }
             reinterpret_cast<f32x4*>(out)[i] = s;
         }
-        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        for (int64_t i = (n4 << 2) + first; i < n; i += stride) {
             float s = peers.a[0][base + i];
-            for (int p = 1; p < world; ++p) s += peers.a[p][base + i];
+#pragma unroll
+            for (int p = 1; p < W; ++p) s += peers.a[p][base + i];
             out[i] = s;
         }
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        for (int64_t i = first; i < n; i += stride) {
             float s = peers.a[0][base + i];
-            for (int p = 1; p < world; ++p) s += peers.a[p][base + i];
+#pragma unroll
+            for (int p = 1; p < W; ++p) s += peers.a[p][base + i];
             out[i] = s;
         }
     }
 }
 
-// mine[base_q + i] = arena_q[base_q + i] for every peer chunk q != rank (blockIdx.y = q)
-__global__ __launch_bounds__(256) void k_p2p_all_gather(P2PArenas peers, int rank, size_t off, int64_t n, int64_t cs, int vec,
-                                                        const unsigned* status) {
+// mine[base_q + i] = arena_q[base_q + i] for every peer chunk q != rank (blockIdx.y = q); four 16-byte loads in flight per lane
+template <bool PACED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(48)))
+void k_p2p_all_gather(P2PArenas peers, int rank, size_t off, int64_t n, int64_t cs, int vec, const unsigned* status, unsigned long long pace_ticks) {
     const int q = blockIdx.y;
     if (q == rank || p2p_dead(status)) return;
     const int64_t c0 = (int64_t)q * cs;
@@ -116,13 +155,26 @@ __global__ __launch_bounds__(256) void k_p2p_all_gather(P2PArenas peers, int ran
     const float* src = peers.a[q] + off + c0;
     float* dst = peers.a[rank] + off + c0;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long t0 = 0;
+    if constexpr (PACED) t0 = __builtin_amdgcn_s_memrealtime();
     if (vec) {
         const int64_t n4 = cn >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
-            reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
-        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < cn; i += stride) dst[i] = src[i];
+        const int64_t iters = (n4 + 4 * stride - 1) / (4 * stride);
+        int64_t k = 0;
+        for (int64_t i = first; i < n4; i += 4 * stride, ++k) {
+            if constexpr (PACED) p2p_pace(t0, pace_ticks, k, iters);
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * stride < n4) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + i + u * stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u * stride < n4) reinterpret_cast<f32x4*>(dst)[i + u * stride] = v[u];
+        }
+        for (int64_t i = (n4 << 2) + first; i < cn; i += stride) dst[i] = src[i];
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cn; i += stride) dst[i] = src[i];
+        for (int64_t i = first; i < cn; i += stride) dst[i] = src[i];
     }
 }
 
@@ -141,7 +193,45 @@ struct vbnn_p2p {
     unsigned epoch;
     unsigned long long timeout_ticks;
     bool have_stream, have_ready, have_done;
+    int rs_blocks, ag_blocks;        // grids of the data kernels (vbnn_p2p_set_grid): workgroups of the reduce-scatter, of the all-gather PER PEER
+    int sim_world;                   // > 1 (world == 1 only, vbnn_p2p_standin): the one-GPU stand-in of a sim_world-rank exchange
+    double sim_GBps;                 // its pacing: inbound bytes per second a rank's links would deliver (0: unpaced)
 };
+
+// Default grids (r05, from the one-GPU stand-in, profiles/r05_overlap_standin.json): enough waves in flight to
+// keep seven links busy (W x 16 B x 256 lanes per workgroup and iteration), few enough that every one of them finds its 48
+// registers beside a resident GEMM workgroup at once. VBNN_P2P_RS_BLOCKS / VBNN_P2P_AG_BLOCKS override at create.
+constexpr int P2P_DEFAULT_RS_BLOCKS = 128, P2P_DEFAULT_AG_BLOCKS = 16;
+
+template <bool PACED>
+static void p2p_launch_rs(vbnn_p2p* p, const P2PArenas& t, int rank, int W, size_t base, int64_t n, int vec, unsigned long long pace) {
+    const int64_t want = ((n + 3) / 4 + 255) / 256;
+    const unsigned nb = (unsigned)(want < p->rs_blocks ? (want > 0 ? want : 1) : p->rs_blocks);
+#define VBNN_RS(Wc) case Wc: hipLaunchKernelGGL((k_p2p_reduce_scatter<Wc, PACED>), dim3(nb), dim3(256), 0, p->stream, t, rank, base, n, vec, p->status, pace); break;
+    switch (W) { VBNN_RS(2) VBNN_RS(3) VBNN_RS(4) VBNN_RS(5) VBNN_RS(6) VBNN_RS(7) VBNN_RS(8) default: break; }
+#undef VBNN_RS
+}
+template <bool PACED>
+static void p2p_launch_ag(vbnn_p2p* p, const P2PArenas& t, int rank, int W, size_t off, int64_t n, int64_t cs, int vec, unsigned long long pace) {
+    const int64_t want = ((cs + 3) / 4 + 1023) / 1024;          // (four 16-byte loads in flight per lane)
+    const unsigned nb = (unsigned)(want < p->ag_blocks ? (want > 0 ? want : 1) : p->ag_blocks);
+    hipLaunchKernelGGL((k_p2p_all_gather<PACED>), dim3(nb, W), dim3(256), 0, p->stream, t, rank, off, n, cs, vec, p->status, pace);
+}
+// the stand-in's pointer tables: "peer q's arena" is THIS arena shifted by whole chunks, so that the bytes this device's memory
+// serves and takes per phase are a real rank's -- reduce-scatter: the whole bucket read once (a real rank reads its own chunk and
+// its seven peers read theirs from it), an eighth written; all-gather: seven chunks read, seven written
+static P2PArenas p2p_standin_table(const vbnn_p2p* p, int64_t cs, bool gather) {
+    P2PArenas t;
+    for (int q = 0; q < P2P_MAX_WORLD; ++q) t.a[q] = nullptr;
+    const int W = p->sim_world;
+    // (gather: chunk q is filled from chunk q - 1, which is always a full one -- no read runs past a short last chunk)
+    for (int q = 0; q < W; ++q) t.a[q] = gather ? p->arena + (int64_t)(((q + W - 1) % W) - q) * cs : p->arena + (int64_t)q * cs;
+    if (gather) t.a[0] = p->arena;                                // (rank 0 = this rank: the destination)
+    return t;
+}
+static unsigned long long p2p_standin_ticks(const vbnn_p2p* p, double bytes_received) {
+    return p->sim_GBps > 0.0 ? (unsigned long long)(bytes_received / (p->sim_GBps * 1e9) * P2P_TICKS_PER_S) : 0ull;
+}
 
 static void p2p_release(vbnn_p2p* p) {           // everything create / connect may have made, in any state of completion
     for (int q = 0; q < p->world; ++q) {
@@ -169,6 +259,9 @@ extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_
     vbnn_p2p* p = new vbnn_p2p();
     p->ctx = ctx; p->rank = rank; p->world = world; p->arena_floats = arena_floats; p->pending = 0; p->epoch = 0; p->connected = world == 1;
     p->arena = nullptr; p->flags = nullptr; p->have_stream = p->have_ready = p->have_done = false;
+    p->rs_blocks = P2P_DEFAULT_RS_BLOCKS; p->ag_blocks = P2P_DEFAULT_AG_BLOCKS; p->sim_world = 0; p->sim_GBps = 0.0;
+    if (const char* e = getenv("VBNN_P2P_RS_BLOCKS")) { const int v = atoi(e); if (v > 0 && v <= 4096) p->rs_blocks = v; }
+    if (const char* e = getenv("VBNN_P2P_AG_BLOCKS")) { const int v = atoi(e); if (v > 0 && v <= 4096) p->ag_blocks = v; }
     for (int q = 0; q < P2P_MAX_WORLD; ++q) { p->arenas.a[q] = nullptr; p->pages.page[q] = nullptr; }
     {
         double secs = P2P_DEFAULT_TIMEOUT_S;
@@ -252,23 +345,25 @@ extern "C" int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n) 
     VBNN_CHECK_HIP(hipEventRecord(p->ready, p->ctx->stream));
     VBNN_CHECK_HIP(hipStreamWaitEvent(p->stream, p->ready, 0));
     p->pending += 1;
-    if (p->world == 1) return VBNN_OK;                            // the sum over one rank (still ordered: finish waits for the stream)
-    const int W = p->world;
+    if (p->world == 1 && p->sim_world <= 1) return VBNN_OK;       // the sum over one rank (still ordered: finish waits for the stream)
+    const bool sim = p->world == 1;                               // the one-GPU stand-in of a sim_world-rank exchange (vbnn_p2p_standin)
+    const int W = sim ? p->sim_world : p->world;
     const int64_t cs = ((n + W - 1) / W + 3) / 4 * 4;             // chunk length: a multiple of 4 floats
     const int vec = (offset_floats % 4 == 0) ? 1 : 0;             // (hipMalloc bases are 256-byte aligned in every process)
     const int64_t c0 = (int64_t)p->rank * cs, cn = n - c0 < cs ? n - c0 : cs;
     int st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
-    if (cn > 0) {
-        const unsigned nb = (unsigned)(((cn + 3) / 4 + 255) / 256 < 1024 ? ((cn + 3) / 4 + 255) / 256 : 1024);
-        hipLaunchKernelGGL(k_p2p_reduce_scatter, dim3(nb ? nb : 1), dim3(256), 0, p->stream, p->arenas, p->rank, W, offset_floats + (size_t)c0, cn, vec, p->status);
+    if (sim) {
+        const int64_t last = n - (int64_t)(W - 1) * cs;           // the stand-in reads every chunk over the length of the shortest
+        if (last > 0)
+            p2p_launch_rs<true>(p, p2p_standin_table(p, cs, false), 0, W, offset_floats, last < cs ? last : cs, vec, p2p_standin_ticks(p, 4.0 * (double)cn * (W - 1)));
+    } else if (cn > 0) {
+        p2p_launch_rs<false>(p, p->arenas, p->rank, W, offset_floats + (size_t)c0, cn, vec, 0ull);
     }
     st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
-    {
-        const unsigned nb = (unsigned)(((cs + 3) / 4 + 255) / 256 < 256 ? ((cs + 3) / 4 + 255) / 256 : 256);
-        hipLaunchKernelGGL(k_p2p_all_gather, dim3(nb ? nb : 1, W), dim3(256), 0, p->stream, p->arenas, p->rank, offset_floats, n, cs, vec, p->status);
-    }
+    if (sim) p2p_launch_ag<true>(p, p2p_standin_table(p, cs, true), 0, W, offset_floats, n, cs, vec, p2p_standin_ticks(p, 4.0 * (double)cs * (W - 1)));
+    else p2p_launch_ag<false>(p, p->arenas, p->rank, W, offset_floats, n, cs, vec, 0ull);
     st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
     return vbnn_check_launch("vbnn_p2p_allreduce");
@@ -291,8 +386,7 @@ extern "C" int vbnn_p2p_reduce_scatter(vbnn_p2p* p, size_t offset_floats, int64_
     const int vec = (c0 % 4 == 0 && offset_floats % 4 == 0 && n_per_rank % 4 == 0) ? 1 : 0;
     int st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
-    const unsigned nb = (unsigned)(((n_per_rank + 3) / 4 + 255) / 256 < 1024 ? ((n_per_rank + 3) / 4 + 255) / 256 : 1024);
-    hipLaunchKernelGGL(k_p2p_reduce_scatter, dim3(nb ? nb : 1), dim3(256), 0, p->stream, p->arenas, p->rank, p->world, c0, n_per_rank, vec, p->status);
+    p2p_launch_rs<false>(p, p->arenas, p->rank, p->world, c0, n_per_rank, vec, 0ull);
     st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
     return vbnn_check_launch("vbnn_p2p_reduce_scatter");
@@ -310,12 +404,36 @@ extern "C" int vbnn_p2p_all_gather(vbnn_p2p* p, size_t offset_floats, int64_t n_
     const int vec = (offset_floats % 4 == 0 && n_per_rank % 4 == 0) ? 1 : 0;
     int st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
-    const unsigned nb = (unsigned)(((n_per_rank + 3) / 4 + 255) / 256 < 256 ? ((n_per_rank + 3) / 4 + 255) / 256 : 256);
-    hipLaunchKernelGGL(k_p2p_all_gather, dim3(nb ? nb : 1, p->world), dim3(256), 0, p->stream, p->arenas, p->rank, offset_floats,
-                       n_per_rank * (int64_t)p->world, n_per_rank, vec, p->status);
+    p2p_launch_ag<false>(p, p->arenas, p->rank, p->world, offset_floats, n_per_rank * (int64_t)p->world, n_per_rank, vec, 0ull);
     st = p2p_barrier(p);
     if (st != VBNN_OK) return st;
     return vbnn_check_launch("vbnn_p2p_all_gather");
+    VBNN_API_END
+}
+
+// grids of the data kernels: workgroups of the reduce-scatter, workgroups of the all-gather per peer (0: keep)
+extern "C" int vbnn_p2p_set_grid(vbnn_p2p* p, int rs_blocks, int ag_blocks_per_peer) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p && rs_blocks >= 0 && rs_blocks <= 4096 && ag_blocks_per_peer >= 0 && ag_blocks_per_peer <= 4096, "grid");
+    if (rs_blocks > 0) p->rs_blocks = rs_blocks;
+    if (ag_blocks_per_peer > 0) p->ag_blocks = ag_blocks_per_peer;
+    return VBNN_OK;
+    VBNN_API_END
+}
+
+// LAB, one rank only: from now on vbnn_p2p_allreduce runs what a rank of a `sim_world`-rank exchange would run -- the same three
+// barriers, the same two data kernels with the same grids and register footprint on the same high-priority stream behind the same
+// event -- against "peers" that are this arena itself, shifted by whole chunks (the bytes this device's memory serves and takes
+// per phase are a real rank's), each phase PACED to the wall time `inbound_GBps` of link bandwidth would need for the bytes a
+// rank receives in it (0: unpaced, i.e. at local-memory speed). The arena afterwards holds nothing meaningful: timing only
+// (tools/overlap_standin.py: what the exchange costs the launches it overlaps). sim_world = 0 switches it off.
+extern "C" int vbnn_p2p_standin(vbnn_p2p* p, int sim_world, double inbound_GBps) {
+    VBNN_API_BEGIN
+    VBNN_REQUIRE(p && p->world == 1, "the stand-in is a world-of-one lab mode");
+    VBNN_REQUIRE(sim_world == 0 || (sim_world >= 2 && sim_world <= P2P_MAX_WORLD), "sim_world: 0 (off) or 2 .. 8");
+    VBNN_REQUIRE(inbound_GBps >= 0.0, "inbound_GBps");
+    p->sim_world = sim_world; p->sim_GBps = inbound_GBps;
+    return VBNN_OK;
     VBNN_API_END
 }
 

@@ -404,8 +404,16 @@ class FusedMLP:
     @_ordered
     def prepare(self):
         lib = L.lib()
-        if self._params_stale:                                # sharded update: fetch the other ranks' fp32 rows first
-            self.gather_parameters()
+        if self._params_stale:
+            # after a sharded update: every rank already holds what this sweep would produce -- the gathered operand shadows, the
+            # combined prior statistics, the packed final weight (_update_sharded; "update leaves what prepare would" is a test)
+            # -- while the fp32 rows of other ranks are stale. No sweep, and NO collective hidden in here: only the
+            # transposed shadows of a layer that did not keep them so far are rebuilt, locally, from the gathered ones.
+            for v in self.vb:
+                if v.muT_s is not None and getattr(v, "use_muT", True):
+                    L.check(lib.vbnn_transpose_packed(self.ctx.h, self.code, v.mu_s.ptr, v.mu_s.ld, v.O, v.I, v.muT_s.ptr, v.muT_s.ld))
+                    L.check(lib.vbnn_transpose_packed(self.ctx.h, self.code, v.var_s.ptr, v.var_s.ld, v.O, v.I, v.varT_s.ptr, v.varT_s.ld))
+            return
         if self.mode == "lrt":                                # one call: a sweep per layer + ONE finish kernel
             descs = (L.PrepDesc * len(self.vb))()
             for k, v in enumerate(self.vb):
@@ -433,8 +441,10 @@ class FusedMLP:
 
     def _probed(self, name, li):
         import contextlib
-        if self.probe is None or self.probe[0] != li:
+        if self.probe is None or (self.probe[0] != li and self.probe[0] != "all"):
             return contextlib.nullcontext()
+        if self.probe[0] == "all":                       # lab (tools/overlap_standin.py): every layer's launches, keyed by layer
+            name = f"{name}[{li}]"
         eng = self
 
         class _Bracket:
@@ -448,6 +458,12 @@ class FusedMLP:
                 eng.probe[1].setdefault(name, []).append((self_inner.e0, self_inner.e1))
                 return False
         return _Bracket()
+
+    def _probed_part(self, name, li):
+        """The two launches of an early-message accGradParameters separately: only in the lab's all-layers probe."""
+        if self.probe is None or self.probe[0] != "all" or not self._early(self.vb[li], self._lrt()):
+            return _NULL_CM
+        return self._probed(name, li)
 
     # ---- VBLinear:clamp_to_map on every VB layer (mlp.lua:88-91): the forward uses the means as weights.
     @_ordered
@@ -769,13 +785,15 @@ class FusedMLP:
                         # two launches (vbnn_dw_args.part): the sigma^2 GEMM and d/dlvars first -- its exchange starts while the
                         # mu GEMM still runs
                         d.part = 2
-                        L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+                        with self._probed_part("accGradParameters.lv", li):
+                            L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
                         if self.sharded:
                             self._scatter(li, ("lv",))
                         else:
                             self._reduce(v.msg_early)
                         d.part = 1
-                    L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
+                    with self._probed_part("accGradParameters.mu", li):
+                        L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(d)))
                 # the fused head already summed the last layer's g columns; ones-row layers got theirs from the GEMM
                 if not (fused_head and li == nl - 1) and not v.bias_from_dw:
                     L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
@@ -891,23 +909,48 @@ class FusedMLP:
                 ex.reduce_scatter(self.grads[off:off + per * W], per)
 
     def gather_parameters(self):
-        """Sharded mode: bring every rank's fp32 means / lvars rows to every rank (checkpoints, prepare(), tests) -- over the
-        out-of-band process group, on the host's schedule: not a part of the step."""
+        """Sharded mode: bring every rank's fp32 means / lvars rows to every rank (checkpoints, calc_lc, tests). A COLLECTIVE --
+        every rank calls it at the same point of its program -- and never a hidden part of another call: prepare() / test() do
+        not need it (the sharded update leaves the gathered shadows and combined statistics they would produce), calc_lc() and
+        anything else that reads other ranks' fp32 rows RAISES while they are stale instead of gathering on one rank and
+        deadlocking the others. On the device wherever a device transport exists: the RCCL exchange's own in-place
+        all-gather (rank r's rows are its contribution), else the out-of-band group -- nccl: all_gather_into_tensor on the
+        device; gloo (rehearsals, CPU tests): through the host."""
         if not self.sharded or self.world == 1:
             self._params_stale = False
             return
         import torch.distributed as dist
-        torch.cuda.synchronize(self.device)
+        from .comm import RcclExchange
+        ex = self.exchange()
+        self.finish()
+        on_exchange = isinstance(ex, RcclExchange)
+        backend = dist.get_backend(self.pg)
+        if not on_exchange:
+            torch.cuda.synchronize(self.device)
         for v in self.vb:
             r0, nr = partition.layer_row_shard(v.O, self.world, self.rank)
             for t in (v.means, v.lvars):
-                mine = t[r0:r0 + nr].cpu()
-                pieces = [torch.empty_like(mine) for _ in range(self.world)]
-                dist.all_gather(pieces, mine, group=self.pg)
-                for r, pc in enumerate(pieces):
-                    if r != self.rank:
-                        t[r * nr:(r + 1) * nr].copy_(pc)
+                assert t.is_contiguous()
+                if on_exchange:
+                    ex.all_gather(t)
+                elif backend == "nccl":
+                    mine = t[r0:r0 + nr].clone()
+                    dist.all_gather_into_tensor(t.view(-1), mine.view(-1), group=self.pg)
+                else:
+                    mine = t[r0:r0 + nr].cpu()
+                    pieces = [torch.empty_like(mine) for _ in range(self.world)]
+                    dist.all_gather(pieces, mine, group=self.pg)
+                    for r, pc in enumerate(pieces):
+                        if r != self.rank:
+                            t[r * nr:(r + 1) * nr].copy_(pc)
+        if on_exchange:
+            ex.finish()
         self._params_stale = False
+
+    def _need_gathered_parameters(self, what):
+        if self._params_stale:
+            raise RuntimeError(f"{what}: the fp32 means / lvars of other ranks' rows are stale after a sharded update -- call "
+                               "gather_parameters() on EVERY rank first (a collective; it is never issued implicitly)")
 
     def _update_sharded(self, opt):
         """mlp:update / VBLinear:update with the parameters SHARDED by layer rows: the reduce-scatter left this rank the summed
@@ -1111,8 +1154,7 @@ class FusedMLP:
 
     @_ordered
     def calc_lc(self, opt=None):                                         # mlp.lua:109-115, fresh statistics
-        if self._params_stale:
-            self.gather_parameters()
+        self._need_gathered_parameters("calc_lc")
         lc = 0.0
         B = float((opt or self.opt).get("B", self.B))
         for v in self.vb:

@@ -79,6 +79,12 @@ class Main:
                     net.sample()
                     net.run(x, t)
             loss, correct = net.loss_and_accuracy()           # sums over the S draws (the criterion accumulates)
+            if not np.isfinite(loss):
+                # Divergence must be seen HERE: the bf16 gradInput epilogue carries the ReLU mask through its second pass as a
+                # NaN and zeroes every NaN it reads back (csrc/epilogues.h, EpiDx::apply_folded), so a genuine NaN above a layer
+                # does not reach the layers below it the way model:backward propagates it in the reference (mlp.lua:79) -- the
+                # loss and the last layer's gradients still show it (tests: test_nan_in_the_backward_...). No update on such a step.
+                raise FloatingPointError(f"minibatch {batch_index}: the loss is {loss} -- the run has diverged; no parameter was updated")
             error += loss * net.world / S
             accuracy += 100.0 * correct / (bs * S)
             log_update = bool(self.log and opt.get("log_update") and net.mode == "lrt")
@@ -119,6 +125,8 @@ class Main:
             trainAccuracy, trainError = self.train(trainSet)
             testAccuracy, testError = self.test(testSet)
             rec = {"devacc": testAccuracy, "trainacc": trainAccuracy, "deverr": testError, "trainerr": trainError}
+            if getattr(self.net, "sharded", False):
+                self.net.gather_parameters()              # collective (every rank runs this loop): calc_lc and save read fp32 rows
             if self.opt.get("type", "vb") == "vb":
                 rec["lc"] = self.net.calc_lc(self.opt)
             if self.log:
