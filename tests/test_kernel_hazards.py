@@ -2,7 +2,7 @@
 makes hipcc drain the LDS-DMA pipeline in front of every read, gemm_v3.h), so the compiler's own hazard and liveness
 logic does not know that such a read completes long after it is issued. A fragment register is dead to the compiler
 as soon as the MFMAs that read it are emitted, and it did hand such registers to the next reads; a lab build that
-issued eight reads behind eight MFMAs this way produced wrong products in the last four (r02). The kernels now
+issued eight reads behind eight MFMAs this way produced wrong products in the last four (r02, LAB_NOTES.md section 3). The kernels now
 keep the fragments of the last eight MFMAs as asm INPUTS of every such read. This test holds that property on the
 generated code: no ds_read_b64_tr_b16 may write a register that one of the preceding eight MFMAs (same wave, no barrier
 in between) reads as its A or B operand. CPU only: hipcc -S cross-compiles without a GPU."""

@@ -76,11 +76,17 @@ def main():
     ex.standin(0)
     arm("world of one (events and stream hand-offs only)")
     for gbps in (770.0, 0.0):
-        for rs, ag in ((1024, 256), (256, 37), (128, 16), (64, 8), (32, 4), (16, 2), (8, 1)):
+        for rs, ag in ((1024, 256), (256, 37), (128, 16), (64, 8), (32, 4), (16, 2), (8, 1)) if gbps else ((1024, 256), (256, 37), (64, 8), (16, 2)):
             ex.set_grid(rs, ag)
             ex.standin(8, gbps)
             arm(f"stand-in 8 ranks, grid rs {rs} / ag {ag} x 7 peers, " + (f"paced {gbps:.0f} GB/s inbound" if gbps else "unpaced (local-memory speed)"),
                 rs_blocks=rs, ag_blocks_per_peer=ag, inbound_GBps=gbps)
+    # the library's default grids at three link rates: what the prediction is worth if the links deliver less (or more) than 110 GB/s each
+    ex.set_grid(256, 32)
+    for gbps in (490.0, 770.0, 1050.0):
+        ex.standin(8, gbps)
+        arm(f"stand-in 8 ranks, default grid rs 256 / ag 32 x 7 peers, paced {gbps:.0f} GB/s inbound ({gbps / 7:.0f} GB/s per link)",
+            rs_blocks=256, ag_blocks_per_peer=32, inbound_GBps=gbps)
     ex.standin(0)
     base = res["arms"][0]["ms_per_step"]
     for a in res["arms"]:

@@ -198,10 +198,13 @@ struct vbnn_p2p {
     double sim_GBps;                 // its pacing: inbound bytes per second a rank's links would deliver (0: unpaced)
 };
 
-// Default grids (r05, from the one-GPU stand-in, profiles/r05_overlap_standin.json): enough waves in flight to
-// keep seven links busy (W x 16 B x 256 lanes per workgroup and iteration), few enough that every one of them finds its 48
-// registers beside a resident GEMM workgroup at once. VBNN_P2P_RS_BLOCKS / VBNN_P2P_AG_BLOCKS override at create.
-constexpr int P2P_DEFAULT_RS_BLOCKS = 128, P2P_DEFAULT_AG_BLOCKS = 16;
+// Default grids (r05, from the one-GPU stand-in, profiles/r05_overlap_standin.json): one reduce-scatter
+// workgroup per CU, 32 all-gather workgroups per peer. Paced to 770 GB/s of inbound link bandwidth the stand-in's step is within
+// noise for 128 .. 256 / 16 .. 37 (+0.133 .. 0.138 ms over the step without exchange calls, the overlapped GEMMs within 2 % of
+// their undisturbed times); 1024 / 256 costs 30 us more (its waves crowd the half-height launch); below 64 / 8 the kernels cannot
+// keep up with the links even from LOCAL memory (32 / 4: +0.38 ms). Remote latency is higher than local, so the larger of the
+// equal grids is the default. VBNN_P2P_RS_BLOCKS / VBNN_P2P_AG_BLOCKS override at create, vbnn_p2p_set_grid later.
+constexpr int P2P_DEFAULT_RS_BLOCKS = 256, P2P_DEFAULT_AG_BLOCKS = 32;
 
 template <bool PACED>
 static void p2p_launch_rs(vbnn_p2p* p, const P2PArenas& t, int rank, int W, size_t base, int64_t n, int vec, unsigned long long pace) {
