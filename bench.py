@@ -494,7 +494,6 @@ def main():
     ap.add_argument("--prepare-each-step", action="store_true", help="round 1's protocol: the parameter sweep inside every step")
     ap.add_argument("--with-update", action="store_true", help="(default since r04: on) also time step + optimiser update, reported beside the metric as train_step")
     ap.add_argument("--no-train-step", action="store_true", help="skip the train_step entry (step + FusedMLP.update)")
-    ap.add_argument("--serial-update", action="store_true", help="train_step: VBLinear:update after the whole backward, as main.lua:28-40 issues it (A/B; default: its sweeps overlapped with the backward)")
     ap.add_argument("--no-box", action="store_true", help="skip the box block (vbnn_box_calibrate: the MFMA clock / rate and the HBM rate this device holds)")
     ap.add_argument("--no-deep-config", action="store_true", help="skip the deep_config entry (BASELINE configs[4] measured beside the headline)")
     ap.add_argument("--debug-set", default="", help="A/B only: comma-separated key=value pairs for vbnn_debug_set")
@@ -610,20 +609,8 @@ def main():
     issue = step                                          # the step launch by launch (warm-up, capture, the probed block)
     graph = None
 
-    # the training step's update: overlapped with the backward where the engine can (run(.., fuse_update = True): the wide layer's sweep
-    # on a side stream beside updateGradInput and layer 1's accGradParameters, bitwise the serial step -- DESIGN.md section 8) unless
-    # --serial-update; S draws: the sweeps go out with the last one
-    fuse_update = args.mode == "lrt" and not use_dist and not args.serial_update and not (args.stack_draws and args.S > 1)
-
     def train_step():
-        if not fuse_update:
-            step()
-        else:
-            eng.resetGradients()
-            for k in range(args.S):
-                eng.sample()
-                eng.run(x, t, fuse_update=(k == args.S - 1))
-            eng.finish()
+        step()
         eng.update()
 
     def barrier():
@@ -768,20 +755,7 @@ def main():
         tw, te = timed_blocks(train_step, max(1, args.repeats) if args.with_update else min(3, max(1, args.repeats)))
         tms = sorted(tw)[len(tw) // 2]
         fps_t = algorithmic_flops_per_sample([cfg["input_size"]] + cfg["hidden"], cfg["n_classes"]) * args.S
-        serial_ms = None
-        if fuse_update and getattr(eng, "_upd_ctx", None) is not None:        # the A/B in the same run: the serial update
-            def serial_train_step():
-                step()
-                eng.update()
-            for _ in range(3):
-                serial_train_step()
-            sw, _ = timed_blocks(serial_train_step, min(3, max(1, args.repeats)))
-            serial_ms = round(sorted(sw)[len(sw) // 2], 4)
         train = {"ms_per_train_step": round(tms, 4), "samples_per_s": round(N * world * args.S / (tms * 1e-3), 1),
-                 "update": ("overlapped: each layer's sweep goes out when its gradients are final -- the widest layer's on a side stream, co-resident "
-                            "with updateGradInput and the input layer's accGradParameters (k_vb_update_cr), bitwise the serial step"
-                            if (fuse_update and getattr(eng, "_upd_ctx", None) is not None) else "serial: after the whole backward (main.lua:28-40)"),
-                 "ms_per_train_step_serial_update": serial_ms,
                  "repeats_wall_ms": [round(v, 4) for v in tw],
                  "step_frac_of_mfma_peak": round(fps_t * N / (tms * 1e-3) / 1e12 / PEAK_TFLOPS[cfg["dtype"]], 4),
                  "kl_gradient": ("exact: added by the update sweep from the fp32 means / lvars (vbnn_update_desc.kl_add, VBLinear.lua:91,96)"

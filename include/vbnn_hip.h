@@ -393,19 +393,6 @@ typedef struct vbnn_update_desc {
     float kl_add;
 } vbnn_update_desc;
 int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra);
-/* (ABI 6) The same update as calls of its own per layer, so that a host can put a layer's sweep BESIDE the backward launches that no
- * longer need that layer's gradients (main.lua:28-40 runs update after the whole backward; nothing in VBLinear:update of layer l
- * depends on the layers below it). vbnn_update_layer: the sweep of ONE layer on `ctx`'s stream; its partial sums are remembered in
- * `owner` under `slot` (= the layer's index in the vbnn_update_finish call that follows). coresident = 1 selects the form of the
- * sweep that fits beside a resident two-pass GEMM workgroup (no LDS, <= 64 VGPRs; flat walk: no transposed shadows, no log14,
- * I % 4 == 0 -- VBNN_ERR_UNSUPPORTED otherwise): `ctx` is then a second context on a side stream and the HOST orders it (events) behind
- * the accGradParameters launch that produced the layer's gradients, and orders every later reader of what the sweep writes --
- * means / lvars, the shadows in desc->mu_s / var_s (give it buffers nobody still reads: the layer's own updateGradInput may be
- * running), the Adam moments -- behind it. vbnn_update_finish(owner, ...): the ONE finish kernel (statistics, logged series, bias
- * SGD, the packed `extra`) on owner's stream, after the host has ordered every sweep in front of it. Parameters, moments, shadows
- * and statistics are BITWISE those of vbnn_update (which is exactly these calls with ctx = owner and coresident = 0). */
-int vbnn_update_layer(vbnn_ctx* ctx, vbnn_ctx* owner, int dtype, int slot, const vbnn_update_desc* layer, int coresident);
-int vbnn_update_finish(vbnn_ctx* owner, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra);
 
 /* ---- data-parallel exchange (north_star: "RCCL all-reduce over xGMI on the (mu, log sigma^2) gradients after
  * accGradParameters"; the reference itself is single-device, main.lua:142 sets BLAS threads only) ------------------

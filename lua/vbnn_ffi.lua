@@ -146,8 +146,6 @@ typedef struct vbnn_update_desc {
     float kl_add;
 } vbnn_update_desc;
 int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra);
-int vbnn_update_layer(vbnn_ctx* ctx, vbnn_ctx* owner, int dtype, int slot, const vbnn_update_desc* layer, int coresident);
-int vbnn_update_finish(vbnn_ctx* owner, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra);
 typedef struct vbnn_comm vbnn_comm;
 int vbnn_comm_unique_id(void* id_out );
 int vbnn_comm_create(vbnn_ctx* ctx, int rank, int world, const void* id, vbnn_comm** out);

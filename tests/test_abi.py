@@ -220,8 +220,6 @@ def test_lua_fused_mlp_structure():
     run = eng[eng.index("    def run(self, inputs, targets"):eng.index("            main, side, ctx2 =")]
     # (the head: the one-call form is what the Lua host issues; engine.py's two-call branch -- test path, opt.head_step = False -- is cut)
     run = run[:run.index("                if self._use_head_slots():\n                    L.check(lib.vbnn_head_forward_slots(")] + run[run.index("        # ---------------- backward: VB layers"):]
-    # (and the overlapped update of engine.py -- run(.., fuse_update = opt), a scheduling option the Lua / C hosts do not take)
-    run = run[:run.index("        if fused is not None:")] + run[run.index("        elif self.f32_direct and not self.overlap:"):]
     py_order = []
     for m in re.finditer(r"lib\.(vbnn_[a-z0-9_]+)\(|self\.(_reduce)\(", run):
         name = m.group(1) or "vbnn_allreduce_grads"

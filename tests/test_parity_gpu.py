@@ -1618,63 +1618,6 @@ def test_kl_gradient_added_in_the_update_is_the_fp32_form(oracle, nnmod, dtype):
             assert d_exact <= d_shadow + 1e-7, (k, d_exact, d_shadow)      # ... and the in-update form does not have it
 
 
-@pytest.mark.parametrize("hidden,I0,N,steps", [([4096, 4096], 784, 4096, 3), ([512, 256], 256, 512, 2)], ids=["wide-side-sweep", "small-no-side"])
-def test_update_overlapped_with_the_backward_is_bitwise_the_serial_training_step(nnmod, hidden, I0, N, steps):
-    """run(.., fuse_update = opt) issues VBLinear:update's sweeps INSIDE the backward -- the wide configuration's
-    4096 x 4096 layer on a side stream, in the co-resident form (k_vb_update_cr: no LDS, 64 registers, per-wave partial sums),
-    beside updateGradInput and layer 1's accGradParameters, writing the layer's ALTERNATE shadow buffers -- and update() completes
-    it. After every one of `steps` training steps: the gradient arena, fp32 means / lvars / biases, the Adam moments, the operand
-    shadows the next forward will read, the prior statistics, the final Linear and the loss are BITWISE those of an engine that
-    runs the serial step (run, then update) from the same seed. (The small configuration has no layer that qualifies for the
-    side stream: the fused path then equals the serial one by construction -- the plan and the per-layer calls are what is tested.)"""
-    from vbnn_amd.engine import FusedMLP
-    opt = opt_for("lrt", "bf16", input_size=I0, hidden=hidden, S=1, fuse_kl=True, B=50.0, state=dict(learningRate=1e-3),
-                  meanState=dict(learningRate=1e-4), varState=dict(learningRate=5e-2))
-    x = torch.empty(N, I0, dtype=torch.float32, device="cuda")
-    nnmod.fill_normal(x, SEED, 4, 0, 0)
-    t = eng_t(N)
-    engs = {}
-    for name in ("serial", "fused"):
-        eng = FusedMLP(dict(opt))
-        for v in eng.vb:                    # posterior variances away from the prior's: a KL gradient that matters
-            v.lvars.add_(0.7 * torch.sin(torch.arange(v.lvars.numel(), device="cuda", dtype=torch.float32)).view_as(v.lvars))
-        eng.prepare()
-        engs[name] = eng
-    for s in range(steps):
-        snap = {}
-        for name, eng in engs.items():
-            eng.resetGradients(); eng.sample()
-            if name == "fused":
-                eng.run(x, t, fuse_update=True)
-                assert eng._upd_issued is not None and (eng._upd_issued["side"] == ({1} if hidden[0] == 4096 else set()))
-            else:
-                eng.run(x, t)
-            eng.update()
-            loss, hits = eng.loss_and_accuracy()
-            torch.cuda.synchronize()
-            st = eng._opt_state
-            snap[name] = dict(loss=loss, hits=hits, grads=eng.grads.clone(), w3=eng.weight3.clone(), b3=eng.bias3.clone(),
-                              w3s=eng.w3_s.t.clone().view(torch.int16),
-                              **{f"{k}{li}": getattr(v, k).clone() for li, v in enumerate(eng.vb) for k in ("means", "lvars", "bias", "stats")},
-                              **{f"mu_s{li}": v.mu_s.t.clone().view(torch.int16) for li, v in enumerate(eng.vb)},
-                              **{f"var_s{li}": v.var_s.t.clone().view(torch.int16) for li, v in enumerate(eng.vb)},
-                              **{f"adam{li}{key}{mv}": st[(v.layer_id, key)][mv].clone() for li, v in enumerate(eng.vb) for key in ("mean", "var") for mv in ("m", "v")})
-        a, b = snap["serial"], snap["fused"]
-        assert a["loss"] == b["loss"] and a["hits"] == b["hits"], (s, a["loss"], b["loss"])
-        for k in a:
-            if k in ("loss", "hits"):
-                continue
-            av, bv = a[k], b[k]
-            same = torch.equal(av.view(torch.int32) if av.dtype == torch.float32 else (av.view(torch.int64) if av.dtype == torch.float64 else av),
-                               bv.view(torch.int32) if bv.dtype == torch.float32 else (bv.view(torch.int64) if bv.dtype == torch.float64 else bv))
-            assert same, f"step {s}: {k} differs between the serial and the overlapped training step"
-    # a forward-only pass afterwards reads the flipped shadow buffers through fresh argument blocks
-    for eng in engs.values():
-        eng.resetGradients(); eng.clamp_to_map(); eng.run(x, t, backward=False)
-    la, lb = engs["serial"].loss_and_accuracy(), engs["fused"].loss_and_accuracy()
-    assert la == lb, (la, lb)
-
-
 def test_update_leaves_what_prepare_would_and_logs_the_14_series(oracle, nnmod):
     """vbnn_update = VBLinear:update + the next minibatch's parameter sweep in one pass. After two minibatches with
     updates (Adam state carried): (1) the operand shadows it wrote are BITWISE what vbnn_prepare writes from the updated

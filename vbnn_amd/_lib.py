@@ -129,8 +129,6 @@ _SIGS = {
     "vbnn_adam_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _vp], _i),
     "vbnn_sgd_step": ([_vp, _vp, _vp, _i64, _f], _i),
     "vbnn_update": ([_vp, _i, _i, _vp, _vp], _i),
-    "vbnn_update_layer": ([_vp, _vp, _i, _i, _vp, _i], _i),
-    "vbnn_update_finish": ([_vp, _i, _i, _vp, _vp], _i),
     "vbnn_comm_unique_id": ([_vp], _i),
     "vbnn_comm_create": ([_vp, _i, _i, _vp, C.POINTER(_vp)], _i),
     "vbnn_comm_destroy": ([_vp], _i),

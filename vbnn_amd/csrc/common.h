@@ -58,9 +58,6 @@ struct vbnn_ctx {
     size_t scratch_doubles;
     unsigned* counters;    // arrival tickets of the in-launch second stages (vbnn_last_arriver); zero between launches
     int cu_budget = 0;     // > 0: the stream is CU-masked to this many compute units (vbnn_ctx_create_cu_budget)
-    int upd_nb[8] = {};    // vbnn_update_layer -> vbnn_update_finish: workgroups of each slot's sweep (0: none issued)
-    unsigned char upd_cr[8] = {};   // ... whether its partials are per wave (the co-resident form)
-    const double* upd_partial[8] = {};   // ... and where they are (the launching context's scratch)
 };
 // ticket slots
 constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TILES = 16, VBNN_CNT_TILES_MAX = 1008, VBNN_CNT_TOTAL = 1024;   // [16, 1024): one ticket per column tile of the head's in-launch finish

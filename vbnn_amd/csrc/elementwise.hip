@@ -973,90 +973,9 @@ __global__ __launch_bounds__(256) void k_vb_update(UpdLayer a) {
     upd_block_reduce(acc, a.partial + (size_t)blockIdx.x * UPD_NSUM, sh);
 }
 
-// ---- the CO-RESIDENT form of the flat sweep (r05, vbnn_update_layer(.., coresident = 1)): the same walk, the same arithmetic, the same
-// thread -> element map and the same reduction tree as k_vb_update's FLAT form -- so the same bits in every parameter, moment, shadow
-// and statistic -- as a kernel that fits BESIDE a resident two-pass GEMM workgroup: no LDS (the GEMM holds all 160 KiB: the block
-// reduction's four wave sums go to global memory instead, k_update_finish adds them ((w0 + w1) + w2) + w3 as the LDS form does) and
-// few enough registers for what two 217..226-register GEMM waves leave of a SIMD's 512 (48..64; tools/kernel_regs.py). It runs on a
-// side stream while the backward's remaining GEMM launches hold every CU: the update sweep is pure HBM streaming, those launches
-// are MFMA-bound and use under half of the memory bandwidth. Only the two prior sums are formed (no logged series: LOG builds
-// keep the serial kernel).
-template <typename T>
-__global__ __launch_bounds__(256) void k_vb_update_cr(UpdLayer a) {
-    const int64_t I = a.I, total = a.O * a.I;
-    T* mu_s = (T*)a.mu_s; T* var_s = (T*)a.var_s;
-    const float var_hat = (float)a.stats[2];
-    const float k_mu = 1.0f / (a.B * var_hat), k_lv = 1.0f / (2.0f * a.B), inv_vh = 1.0f / var_hat;
-    double acc0 = 0.0, acc1 = 0.0;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    // 32-bit element indices (the launcher checks O x I < 2^30): every stream is (uniform base) + (one 32-bit lane offset)
-    const unsigned total32 = (unsigned)total, I32 = (unsigned)I, ldw = (unsigned)a.ld_w, step = gridDim.x * 1024u;
-    for (unsigned base = (blockIdx.x * 256u + threadIdx.x) * 4u; base < total32; base += step) {
-        const unsigned r = (ldw == I32) ? 0u : base / I32, c = (ldw == I32) ? base : base - r * I32;
-        // the thread's four weights as two halves of two (8-byte loads: sixteen registers of operands in flight instead of
-        // thirty-two -- the register budget beside two GEMM waves), in element order: the sums add up in k_vb_update's order
-#pragma unroll 1
-        for (unsigned hh = 0; hh < 2; ++hh) {          // (rolled: unrolled, the two halves' store addresses are CSE'd into 64-bit register pairs)
-            const unsigned ob = (base + 2u * hh) * 4u;            // BYTE offset, 32 bits: (uniform base) + (lane offset) addressing
-            f32x2 m = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.means) + ob));
-            f32x2 l = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.lvars) + ob));
-            f32x2 gm = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.g_mu) + ob));
-            f32x2 gl = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.g_lv) + ob));
-            f32x2 mm = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.m_mu) + ob));
-            f32x2 vm = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.v_mu) + ob));
-            f32x2 ml = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.m_lv) + ob));
-            f32x2 vl = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(a.v_lv) + ob));
-            f32x2 v;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                // (exactly k_vb_update's elem4, the logged sums left out; this file is compiled with -ffp-contract=off)
-                const float mlc = k_mu * m[e], vlc = k_lv * fmaf(expf(l[e]), inv_vh, -1.0f);
-                if (a.kl_add != 0.f) {
-                    gm[e] = fmaf(a.kl_add, mlc, gm[e]);
-                    gl[e] = fmaf(a.kl_add, vlc, gl[e]);
-                }
-                mm[e] = a.b1_mu * mm[e] + (1.0f - a.b1_mu) * gm[e];
-                vm[e] = a.b2_mu * vm[e] + (1.0f - a.b2_mu) * gm[e] * gm[e];
-                const float um = a.step_mu * mm[e] / (sqrtf(vm[e]) + a.eps_mu);
-                m[e] -= um;
-                ml[e] = a.b1_lv * ml[e] + (1.0f - a.b1_lv) * gl[e];
-                vl[e] = a.b2_lv * vl[e] + (1.0f - a.b2_lv) * gl[e] * gl[e];
-                const float ul = a.step_lv * ml[e] / (sqrtf(vl[e]) + a.eps_lv);
-                l[e] -= ul;
-                v[e] = expf(l[e]);
-                acc0 += (double)__fadd_rn(v[e], __fmul_rn(m[e], m[e])); acc1 += (double)l[e];
-                __builtin_amdgcn_sched_barrier(0);            // one element's temporaries at a time (the register budget)
-            }
-            __builtin_nontemporal_store(m, reinterpret_cast<f32x2*>(reinterpret_cast<char*>(a.means) + ob));
-            __builtin_nontemporal_store(l, reinterpret_cast<f32x2*>(reinterpret_cast<char*>(a.lvars) + ob));
-            __builtin_nontemporal_store(mm, reinterpret_cast<f32x2*>(reinterpret_cast<char*>(a.m_mu) + ob));
-            __builtin_nontemporal_store(vm, reinterpret_cast<f32x2*>(reinterpret_cast<char*>(a.v_mu) + ob));
-            __builtin_nontemporal_store(ml, reinterpret_cast<f32x2*>(reinterpret_cast<char*>(a.m_lv) + ob));
-            __builtin_nontemporal_store(vl, reinterpret_cast<f32x2*>(reinterpret_cast<char*>(a.v_lv) + ob));
-            if constexpr (sizeof(T) == 2) {
-                const unsigned sb = (r * ldw + c + 2u * hh) * 2u;
-                *reinterpret_cast<bf16x2*>(reinterpret_cast<char*>(mu_s) + sb) = bf16x2{(bf16_t)m[0], (bf16_t)m[1]};
-                *reinterpret_cast<bf16x2*>(reinterpret_cast<char*>(var_s) + sb) = bf16x2{(bf16_t)v[0], (bf16_t)v[1]};
-            } else {
-                const unsigned sb = (r * ldw + c + 2u * hh) * 4u;
-                *reinterpret_cast<f32x2*>(reinterpret_cast<char*>(mu_s) + sb) = m;
-                *reinterpret_cast<f32x2*>(reinterpret_cast<char*>(var_s) + sb) = v;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    const double s0 = wave_sum(acc0), s1 = wave_sum(acc1);
-    if ((threadIdx.x & 63) == 0) {
-        double* out = a.partial + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * UPD_NSUM;
-        out[0] = s0; out[1] = s1;
-    }
-}
-
 struct UpdFinishArgs {
     const double* partial[8]; int nb[8]; int64_t W[8]; double* stats[8]; double* log14[8];
     float* bias[8]; const float* grad_bias[8]; int64_t O[8]; float lr_bias[8]; int n;
-    int cr[8];            // 1: the layer's partials are PER WAVE (k_vb_update_cr: [block][4 waves][UPD_NSUM], sums 0 and 1 only)
     const float* src; int64_t rows, cols, ld_src; void* dst; int64_t ld_dst; void* dstT; int64_t ld_dstT;
 };
 template <typename T>
@@ -1068,14 +987,6 @@ __global__ __launch_bounds__(256) void k_update_finish(UpdFinishArgs a) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) acc[k] = 0.0;
         acc[12] = acc[14] = 1e300; acc[13] = acc[15] = -1e300;
-        if (a.cr[l]) {
-            // the co-resident sweep left its four wave sums per block: the block's sum as upd_block_reduce forms it, ((w0 + w1) + w2) + w3
-            for (int b = threadIdx.x; b < a.nb[l]; b += 256) {
-                const double* p = a.partial[l] + (size_t)b * 4 * UPD_NSUM;
-                acc[0] += p[0] + p[UPD_NSUM] + p[2 * UPD_NSUM] + p[3 * UPD_NSUM];
-                acc[1] += p[1] + p[UPD_NSUM + 1] + p[2 * UPD_NSUM + 1] + p[3 * UPD_NSUM + 1];
-            }
-        } else
         for (int b = threadIdx.x; b < a.nb[l]; b += 256) {
             const double* p = a.partial[l] + (size_t)b * UPD_NSUM;
 #pragma unroll
@@ -1123,84 +1034,42 @@ static inline float adam_step_size(const vbnn_adam_cfg& c, float* b1_out) {
     return (float)((double)c.lr * sqrt(bc2) / bc1);
 }
 
-constexpr int UPD_MAXB = 2048;
-static int upd_check_layer(const vbnn_update_desc& d) {
-    VBNN_REQUIRE(d.means && d.lvars && d.mu_s && d.var_s && d.stats, "null layer argument");
-    VBNN_REQUIRE(d.grad_mu && d.grad_lv && d.m_mu && d.v_mu && d.m_lv && d.v_lv, "null gradient / Adam state");
-    VBNN_REQUIRE((d.muT_s == nullptr) == (d.varT_s == nullptr), "muT_s and varT_s go together");
-    VBNN_REQUIRE(d.O > 0 && d.I > 0 && d.ld_w >= d.I && (!d.muT_s || d.ld_wT >= d.O), "layer shape");
-    VBNN_REQUIRE((d.bias == nullptr) == (d.grad_bias == nullptr), "bias and grad_bias go together");
-    VBNN_REQUIRE(d.B > 0, "B");
-    for (const vbnn_adam_cfg* c : {&d.mu, &d.lv})
-        VBNN_REQUIRE(c->t >= 1 && c->beta1 >= 0 && c->beta1 < 1 && c->beta2 >= 0 && c->beta2 < 1 && c->lr >= 0 && c->eps >= 0 &&
-                     c->lambda > 0 && c->lambda <= 1, "Adam hyper-parameters (t counts from 1)");
-    return VBNN_OK;
-}
-
-// The sweep of ONE layer as a launch of its own (include/vbnn_hip.h): on `ctx`'s stream, its partial sums in slot `slot` of `owner`'s
-// scratch, where vbnn_update_finish(owner, ..) -- issued by the host once every layer's sweep is ordered in front of owner's stream
-// -- finds them. coresident = 1: the LDS-free, low-register form (k_vb_update_cr) that fits beside a resident two-pass GEMM workgroup.
-extern "C" int vbnn_update_layer(vbnn_ctx* ctx, vbnn_ctx* owner, int dtype, int slot, const vbnn_update_desc* layer, int coresident) {
+extern "C" int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra) {
     VBNN_API_BEGIN
-    VBNN_REQUIRE(ctx && owner && layer, "null argument");
-    VBNN_REQUIRE(slot >= 0 && slot < 8, "slot (0..7)");
-    VBNN_REQUIRE(dtype == VBNN_F32 || dtype == VBNN_BF16, "dtype");
-    VBNN_REQUIRE((size_t)8 * UPD_MAXB * 4 * UPD_NSUM <= ctx->scratch_doubles, "scratch");
-    const vbnn_update_desc& d = *layer;
-    int st = upd_check_layer(d);
-    if (st != VBNN_OK) return st;
-    const int64_t ntiles = ((d.O + 63) / 64) * ((d.I + 63) / 64);
-    const int nb = (int)(ntiles < UPD_MAXB ? ntiles : UPD_MAXB);
-    UpdLayer a{};
-    a.means = d.means; a.lvars = d.lvars; a.O = d.O; a.I = d.I;
-    a.mu_s = d.mu_s; a.var_s = d.var_s; a.ld_w = d.ld_w; a.muT_s = d.muT_s; a.varT_s = d.varT_s; a.ld_wT = d.ld_wT;
-    a.stats = d.stats; a.g_mu = d.grad_mu; a.g_lv = d.grad_lv;
-    a.m_mu = d.m_mu; a.v_mu = d.v_mu; a.m_lv = d.m_lv; a.v_lv = d.v_lv;
-    a.step_mu = adam_step_size(d.mu, &a.b1_mu); a.b2_mu = d.mu.beta2; a.eps_mu = d.mu.eps;
-    a.step_lv = adam_step_size(d.lv, &a.b1_lv); a.b2_lv = d.lv.beta2; a.eps_lv = d.lv.eps;
-    a.B = d.B;
-    a.kl_add = d.kl_add;
-    // the partials go to the LAUNCHING context's scratch (a side-stream sweep must not share reduction scratch with whatever the
-    // owner's stream runs meanwhile); slots are 4 x UPD_MAXB rows apart: room for the co-resident form's per-wave partials
-    a.partial = ctx->scratch + (size_t)slot * UPD_MAXB * 4 * UPD_NSUM;
-    if (coresident) {
-        const bool vec_in = ((d.I & 3) == 0) && ((((uintptr_t)d.means | (uintptr_t)d.lvars | (uintptr_t)d.grad_mu | (uintptr_t)d.grad_lv |
-                                                   (uintptr_t)d.m_mu | (uintptr_t)d.v_mu | (uintptr_t)d.m_lv | (uintptr_t)d.v_lv) & 15u) == 0);
-        if (d.muT_s || d.log14 || !vec_in || (int64_t)nb * 1024 > d.O * d.I || (d.ld_w & 3) != 0 || d.O * d.ld_w >= (1ll << 30)) {
-            vbnn_set_error("vbnn_update_layer: the co-resident form is the FLAT sweep without logged series (no transposed shadows, I %% 4 == 0, "
-                           "16-byte aligned streams, at least 1024 weights per workgroup)");
-            return VBNN_ERR_UNSUPPORTED;
-        }
-        if (dtype == VBNN_F32) hipLaunchKernelGGL(k_vb_update_cr<float>, dim3(nb), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_vb_update_cr<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, a);
-    } else {
-        if (dtype == VBNN_F32) hipLaunchKernelGGL(k_vb_update<float>, dim3(nb), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_vb_update<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, a);
-    }
-    owner->upd_nb[slot] = nb; owner->upd_cr[slot] = coresident ? 1 : 0; owner->upd_partial[slot] = a.partial;
-    return vbnn_check_launch("vbnn_update_layer");
-    VBNN_API_END
-}
-
-// The ONE finish kernel of an update whose layers were swept by vbnn_update_layer(.., owner, slot = l, ..): the layers' new prior
-// statistics (and logged series) from the partial sums, optim.sgd on the biases, the packed final weight.
-extern "C" int vbnn_update_finish(vbnn_ctx* owner, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra) {
-    VBNN_API_BEGIN
-    VBNN_REQUIRE(owner && (layers || n_layers == 0), "null argument");
+    VBNN_REQUIRE(ctx && (layers || n_layers == 0), "null argument");
     VBNN_REQUIRE(n_layers >= 0 && n_layers <= 8, "n_layers (0..8)");
     VBNN_REQUIRE(dtype == VBNN_F32 || dtype == VBNN_BF16, "dtype");
+    constexpr int MAXB = 2048;
+    VBNN_REQUIRE((size_t)n_layers * MAXB * UPD_NSUM <= ctx->scratch_doubles, "scratch");
     UpdFinishArgs fa{};
     fa.n = n_layers;
     for (int l = 0; l < n_layers; ++l) {
         const vbnn_update_desc& d = layers[l];
-        VBNN_REQUIRE(d.stats && d.O > 0 && d.I > 0, "layer");
+        VBNN_REQUIRE(d.means && d.lvars && d.mu_s && d.var_s && d.stats, "null layer argument");
+        VBNN_REQUIRE(d.grad_mu && d.grad_lv && d.m_mu && d.v_mu && d.m_lv && d.v_lv, "null gradient / Adam state");
+        VBNN_REQUIRE((d.muT_s == nullptr) == (d.varT_s == nullptr), "muT_s and varT_s go together");
+        VBNN_REQUIRE(d.O > 0 && d.I > 0 && d.ld_w >= d.I && (!d.muT_s || d.ld_wT >= d.O), "layer shape");
         VBNN_REQUIRE((d.bias == nullptr) == (d.grad_bias == nullptr), "bias and grad_bias go together");
-        VBNN_REQUIRE(owner->upd_nb[l] > 0, "vbnn_update_finish: no vbnn_update_layer was issued for this slot");
-        VBNN_REQUIRE(!(owner->upd_cr[l] && d.log14), "the co-resident sweep forms no logged series");
-        fa.partial[l] = owner->upd_partial[l]; fa.nb[l] = owner->upd_nb[l]; fa.cr[l] = owner->upd_cr[l];
-        fa.W[l] = d.O * d.I; fa.stats[l] = d.stats; fa.log14[l] = d.log14;
+        VBNN_REQUIRE(d.B > 0, "B");
+        for (const vbnn_adam_cfg* c : {&d.mu, &d.lv})
+            VBNN_REQUIRE(c->t >= 1 && c->beta1 >= 0 && c->beta1 < 1 && c->beta2 >= 0 && c->beta2 < 1 && c->lr >= 0 && c->eps >= 0 &&
+                         c->lambda > 0 && c->lambda <= 1, "Adam hyper-parameters (t counts from 1)");
+        const int64_t ntiles = ((d.O + 63) / 64) * ((d.I + 63) / 64);
+        const int nb = (int)(ntiles < MAXB ? ntiles : MAXB);
+        UpdLayer a{};
+        a.means = d.means; a.lvars = d.lvars; a.O = d.O; a.I = d.I;
+        a.mu_s = d.mu_s; a.var_s = d.var_s; a.ld_w = d.ld_w; a.muT_s = d.muT_s; a.varT_s = d.varT_s; a.ld_wT = d.ld_wT;
+        a.stats = d.stats; a.g_mu = d.grad_mu; a.g_lv = d.grad_lv;
+        a.m_mu = d.m_mu; a.v_mu = d.v_mu; a.m_lv = d.m_lv; a.v_lv = d.v_lv;
+        a.step_mu = adam_step_size(d.mu, &a.b1_mu); a.b2_mu = d.mu.beta2; a.eps_mu = d.mu.eps;
+        a.step_lv = adam_step_size(d.lv, &a.b1_lv); a.b2_lv = d.lv.beta2; a.eps_lv = d.lv.eps;
+        a.B = d.B;
+        a.kl_add = d.kl_add;
+        a.partial = ctx->scratch + (size_t)l * MAXB * UPD_NSUM;
+        if (dtype == VBNN_F32) hipLaunchKernelGGL(k_vb_update<float>, dim3(nb), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_vb_update<bf16_t>, dim3(nb), dim3(256), 0, ctx->stream, a);
+        fa.partial[l] = a.partial; fa.nb[l] = nb; fa.W[l] = d.O * d.I; fa.stats[l] = d.stats; fa.log14[l] = d.log14;
         fa.bias[l] = d.bias; fa.grad_bias[l] = d.grad_bias; fa.O[l] = d.O; fa.lr_bias[l] = d.lr_bias;
-        owner->upd_nb[l] = 0;
     }
     int pack_blocks = 0;
     if (extra) {
@@ -1212,21 +1081,11 @@ extern "C" int vbnn_update_finish(vbnn_ctx* owner, int dtype, int n_layers, cons
         pack_blocks = grid_for(extra->rows * extra->cols, 1024);
     }
     if (n_layers + pack_blocks > 0) {
-        if (dtype == VBNN_F32) hipLaunchKernelGGL(k_update_finish<float>, dim3(n_layers + pack_blocks), dim3(256), 0, owner->stream, fa);
-        else hipLaunchKernelGGL(k_update_finish<bf16_t>, dim3(n_layers + pack_blocks), dim3(256), 0, owner->stream, fa);
+        if (dtype == VBNN_F32) hipLaunchKernelGGL(k_update_finish<float>, dim3(n_layers + pack_blocks), dim3(256), 0, ctx->stream, fa);
+        else hipLaunchKernelGGL(k_update_finish<bf16_t>, dim3(n_layers + pack_blocks), dim3(256), 0, ctx->stream, fa);
     }
-    return vbnn_check_launch("vbnn_update_finish");
+    return vbnn_check_launch("vbnn_update");
     VBNN_API_END
-}
-
-extern "C" int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* layers, const vbnn_pack_desc* extra) {
-    VBNN_REQUIRE(ctx && (layers || n_layers == 0), "null argument");
-    VBNN_REQUIRE(n_layers >= 0 && n_layers <= 8, "n_layers (0..8)");
-    for (int l = 0; l < n_layers; ++l) {
-        const int st = vbnn_update_layer(ctx, ctx, dtype, l, &layers[l], 0);
-        if (st != VBNN_OK) return st;
-    }
-    return vbnn_update_finish(ctx, dtype, n_layers, layers, extra);
 }
 
 // ---------------------------------------------------------------------------------- pack_input

@@ -14,6 +14,8 @@
 //     barrier   every chunk is reduced
 //     all-gather       rank r copies chunk q (q != r) from rank q's arena into its own
 //     barrier   nobody still reads this rank's chunk: the arena may be overwritten (the next minibatch)
+//   (r05: the third barrier is ONE launch per step, in vbnn_p2p_finish -- or earlier if a region is exchanged twice without a finish
+//   in between: four launches per message instead of five)
 //   The sum has ONE order (rank 0 + rank 1 + ...), so every rank holds bitwise the same arena afterwards.
 //   coherence  data crosses devices only at KERNEL BOUNDARIES (a kernel's stores are written back when it ends, a kernel's
 //              loads see them when it starts after the barrier kernel that observed the producer's signal): the arena is
@@ -43,32 +45,58 @@ struct P2PArenas { float* a[P2P_MAX_WORLD]; };
 // epoch of a barrier that failed, else 0), words [16, 24) = "peer q's exchange is dead" (written by q when ITS barrier fails)
 constexpr int P2P_STATUS_WORD = P2P_MAX_WORLD, P2P_DEAD_WORD0 = 16;
 
-__global__ __launch_bounds__(64) void k_p2p_barrier(P2PFlags peers, unsigned* mine, int rank, int world, unsigned epoch, unsigned* status,
-                                                    unsigned long long timeout_ticks) {
-    const int p = threadIdx.x;
-    if (p >= world) return;
-    // (a rank whose exchange is dead still SIGNALS, so that no peer waits out its timeout on it; it does not poll again --
-    // the exchange stays dead until the host clears the status on every rank)
-    __hip_atomic_store(peers.page[p] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    bool ok = false;
-    for (;;) {
-        const unsigned seen = __hip_atomic_load(mine + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        // a peer whose own barrier failed says so in THIS rank's page: its data kernels have stopped, so what it holds are not
-        // sums -- this rank's exchange is dead too, from this barrier on (the failure reaches every rank within one barrier)
-        const unsigned dead = __hip_atomic_load(mine + P2P_DEAD_WORD0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (dead != 0u) break;
-        if ((int)(seen - epoch) >= 0) { ok = true; break; }
-        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) break;       // gave up: never hang the device
-        __builtin_amdgcn_s_sleep(32);
+// what a barrier needs, by value in a kernel's arguments
+struct P2PSync {
+    P2PFlags peers; unsigned* mine; unsigned* status;
+    int rank, world; unsigned epoch; unsigned long long timeout_ticks;
+};
+
+// One wave's worth of barrier: lane p < world signals peer p (when `signal`) and polls slot p of this rank's own page. Called by a
+// whole wave; returns (to every lane) whether every peer arrived.
+__device__ __forceinline__ bool p2p_wave_barrier(const P2PSync& s, bool signal) {
+    const int p = threadIdx.x & 63;
+    bool ok = true;
+    if (p < s.world) {
+        // (a rank whose exchange is dead still SIGNALS, so that no peer waits out its timeout on it; it does not poll again --
+        // the exchange stays dead until the host clears the status on every rank)
+        if (signal) __hip_atomic_store(s.peers.page[p] + s.rank, s.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+            ok = false;
+        } else {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            ok = false;
+            for (;;) {
+                const unsigned seen = __hip_atomic_load(s.mine + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // a peer whose own barrier failed says so in THIS rank's page: its data kernels have stopped, so what it holds are
+                // not sums -- this rank's exchange is dead too, from this barrier on (the failure reaches every rank within one barrier)
+                const unsigned dead = __hip_atomic_load(s.mine + P2P_DEAD_WORD0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (dead != 0u) break;
+                if ((int)(seen - s.epoch) >= 0) { ok = true; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > s.timeout_ticks) break;       // gave up: never hang the device
+                __builtin_amdgcn_s_sleep(48);
+            }
+            if (!ok) {            // raise this rank's status, tell every peer (idempotent: every polling wave of a kernel may do it)
+                __hip_atomic_store(s.status, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (p != s.rank) __hip_atomic_store(s.peers.page[p] + P2P_DEAD_WORD0 + s.rank, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
-    const bool any_fail = __ballot(!ok) != 0ull;              // (over the `world` active lanes)
-    if (any_fail) {
-        if (p == 0) __hip_atomic_store(status, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (p != rank) __hip_atomic_store(peers.page[p] + P2P_DEAD_WORD0 + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    return __ballot(!ok) == 0ull;
 }
+
+// the barrier as a launch of its own: the ONE barrier per step that remains (vbnn_p2p_finish: "nobody still reads this rank's
+// chunks -- the arena may be overwritten"), and between two exchanges of overlapping regions
+__global__ __launch_bounds__(64) void k_p2p_barrier(P2PSync s) { (void)p2p_wave_barrier(s, true); }
+
+// r05, priced and NOT kept: a phase's entry barrier INSIDE its data kernel (wave 0 of every workgroup polling, the other waves at
+// s_barrier) to save the barrier launches -- an all-reduce is dependent launches on the exchange stream, 8-10 us each whatever they
+// do, and the step's last message has nothing to hide behind. Correct (334 tests) and much SLOWER in the one-GPU stand-in: 1.026 ms
+// per step against 0.891, the overlapped GEMMs 120 -> 186 us and 190 -> 237 us. A barrier's acquire / release at SYSTEM scope is
+// cache maintenance on the executing XCD's L2 (write back, invalidate): done by one wave of a one-workgroup kernel it is noise;
+// done by 256 workgroups' waves beside a GEMM it keeps throwing the GEMM's operand panels out of the L2s. (Polling relaxed and
+// acquiring once is not on offer either: a data kernel that waits INSIDE itself has passed its own start-of-kernel invalidate
+// before the peers produced what it is about to read.) What WAS kept from that exercise: the exit barrier ("nobody still reads this
+// rank's chunk") is ONE launch per step, in vbnn_p2p_finish, not one per message -- four launches per all-reduce instead of five.
 
 // The data kernels do NOTHING once a barrier of this rank has given up: a reduce-scatter on buckets a peer has not
 // finished would put wrong sums into the gradient arena IN PLACE, where the next update reads them. With the status raised the
@@ -193,6 +221,8 @@ struct vbnn_p2p {
     unsigned epoch;
     unsigned long long timeout_ticks;
     bool have_stream, have_ready, have_done;
+    bool need_final;                 // data kernels were enqueued since the last barrier launch: vbnn_p2p_finish owes the step's ONE barrier
+    int n_regions; size_t reg_off[16]; int64_t reg_n[16];    // arena regions exchanged since then (an overlapping one forces that barrier early)
     int rs_blocks, ag_blocks;        // grids of the data kernels (vbnn_p2p_set_grid): workgroups of the reduce-scatter, of the all-gather PER PEER
     int sim_world;                   // > 1 (world == 1 only, vbnn_p2p_standin): the one-GPU stand-in of a sim_world-rank exchange
     double sim_GBps;                 // its pacing: inbound bytes per second a rank's links would deliver (0: unpaced)
@@ -206,8 +236,39 @@ struct vbnn_p2p {
 // equal grids is the default. VBNN_P2P_RS_BLOCKS / VBNN_P2P_AG_BLOCKS override at create, vbnn_p2p_set_grid later.
 constexpr int P2P_DEFAULT_RS_BLOCKS = 256, P2P_DEFAULT_AG_BLOCKS = 32;
 
+// the next phase's barrier arguments (every phase -- every data kernel, every barrier launch -- is one epoch)
+static P2PSync p2p_next_sync(vbnn_p2p* p) {
+    p->epoch += 1;
+    P2PSync s;
+    s.peers = p->pages; s.mine = p->flags; s.status = p->status; s.rank = p->rank; s.world = p->world; s.epoch = p->epoch;
+    s.timeout_ticks = p->timeout_ticks;
+    return s;
+}
+// a phase's ENTRY barrier: a one-workgroup launch in front of its data kernel
+static void p2p_entry_barrier(vbnn_p2p* p) {
+    hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, p->stream, p2p_next_sync(p));
+}
+// the EXIT barrier as a launch: "every rank has finished every phase enqueued so far" -- nobody still reads this rank's arena
+static int p2p_barrier(vbnn_p2p* p) {
+    hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, p->stream, p2p_next_sync(p));
+    p->need_final = false; p->n_regions = 0;
+    return vbnn_check_launch("k_p2p_barrier");
+}
+// a region about to be exchanged: one that overlaps a region exchanged since the last barrier (the same bucket twice in a row: a
+// timing loop) needs that barrier first -- a peer may still be gathering from the chunk this rank is about to reduce into
+static int p2p_claim_region(vbnn_p2p* p, size_t off, int64_t n) {
+    bool clash = p->n_regions >= 16;
+    for (int i = 0; i < p->n_regions && !clash; ++i)
+        clash = off < p->reg_off[i] + (size_t)p->reg_n[i] && p->reg_off[i] < off + (size_t)n;
+    if (clash) { const int st = p2p_barrier(p); if (st != VBNN_OK) return st; }
+    p->reg_off[p->n_regions] = off; p->reg_n[p->n_regions] = n; p->n_regions += 1;
+    p->need_final = true;
+    return VBNN_OK;
+}
+
 template <bool PACED>
 static void p2p_launch_rs(vbnn_p2p* p, const P2PArenas& t, int rank, int W, size_t base, int64_t n, int vec, unsigned long long pace) {
+    p2p_entry_barrier(p);                                         // "every rank's region is complete"
     const int64_t want = ((n + 3) / 4 + 255) / 256;
     const unsigned nb = (unsigned)(want < p->rs_blocks ? (want > 0 ? want : 1) : p->rs_blocks);
 #define VBNN_RS(Wc) case Wc: hipLaunchKernelGGL((k_p2p_reduce_scatter<Wc, PACED>), dim3(nb), dim3(256), 0, p->stream, t, rank, base, n, vec, p->status, pace); break;
@@ -218,6 +279,7 @@ template <bool PACED>
 static void p2p_launch_ag(vbnn_p2p* p, const P2PArenas& t, int rank, int W, size_t off, int64_t n, int64_t cs, int vec, unsigned long long pace) {
     const int64_t want = ((cs + 3) / 4 + 1023) / 1024;          // (four 16-byte loads in flight per lane)
     const unsigned nb = (unsigned)(want < p->ag_blocks ? (want > 0 ? want : 1) : p->ag_blocks);
+    p2p_entry_barrier(p);                                         // "every rank's chunk is complete (reduced / updated)"
     hipLaunchKernelGGL((k_p2p_all_gather<PACED>), dim3(nb, W), dim3(256), 0, p->stream, t, rank, off, n, cs, vec, p->status, pace);
 }
 // the stand-in's pointer tables: "peer q's arena" is THIS arena shifted by whole chunks, so that the bytes this device's memory
@@ -263,6 +325,7 @@ extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_
     p->ctx = ctx; p->rank = rank; p->world = world; p->arena_floats = arena_floats; p->pending = 0; p->epoch = 0; p->connected = world == 1;
     p->arena = nullptr; p->flags = nullptr; p->have_stream = p->have_ready = p->have_done = false;
     p->rs_blocks = P2P_DEFAULT_RS_BLOCKS; p->ag_blocks = P2P_DEFAULT_AG_BLOCKS; p->sim_world = 0; p->sim_GBps = 0.0;
+    p->need_final = false; p->n_regions = 0;
     if (const char* e = getenv("VBNN_P2P_RS_BLOCKS")) { const int v = atoi(e); if (v > 0 && v <= 4096) p->rs_blocks = v; }
     if (const char* e = getenv("VBNN_P2P_AG_BLOCKS")) { const int v = atoi(e); if (v > 0 && v <= 4096) p->ag_blocks = v; }
     for (int q = 0; q < P2P_MAX_WORLD; ++q) { p->arenas.a[q] = nullptr; p->pages.page[q] = nullptr; }
@@ -334,12 +397,6 @@ extern "C" int vbnn_p2p_connect(vbnn_p2p* p, const void* all_handles) {
     VBNN_API_END
 }
 
-static int p2p_barrier(vbnn_p2p* p) {
-    p->epoch += 1;
-    hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, p->stream, p->pages, p->flags, p->rank, p->world, p->epoch, p->status, p->timeout_ticks);
-    return vbnn_check_launch("k_p2p_barrier");
-}
-
 extern "C" int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(p && n > 0 && offset_floats + (size_t)n <= p->arena_floats, "bucket outside the arena");
@@ -354,21 +411,19 @@ extern "C" int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n) 
     const int64_t cs = ((n + W - 1) / W + 3) / 4 * 4;             // chunk length: a multiple of 4 floats
     const int vec = (offset_floats % 4 == 0) ? 1 : 0;             // (hipMalloc bases are 256-byte aligned in every process)
     const int64_t c0 = (int64_t)p->rank * cs, cn = n - c0 < cs ? n - c0 : cs;
-    int st = p2p_barrier(p);
+    int st = p2p_claim_region(p, offset_floats, n);
     if (st != VBNN_OK) return st;
+    // four launches: barrier, reduce-scatter, barrier, all-gather; the exit barrier ("nobody still reads this rank's chunk") is the
+    // step's one barrier launch, in vbnn_p2p_finish
     if (sim) {
         const int64_t last = n - (int64_t)(W - 1) * cs;           // the stand-in reads every chunk over the length of the shortest
-        if (last > 0)
-            p2p_launch_rs<true>(p, p2p_standin_table(p, cs, false), 0, W, offset_floats, last < cs ? last : cs, vec, p2p_standin_ticks(p, 4.0 * (double)cn * (W - 1)));
-    } else if (cn > 0) {
-        p2p_launch_rs<false>(p, p->arenas, p->rank, W, offset_floats + (size_t)c0, cn, vec, 0ull);
+        p2p_launch_rs<true>(p, p2p_standin_table(p, cs, false), 0, W, offset_floats, last > 0 ? (last < cs ? last : cs) : 0, vec, p2p_standin_ticks(p, 4.0 * (double)cn * (W - 1)));
+        p2p_launch_ag<true>(p, p2p_standin_table(p, cs, true), 0, W, offset_floats, n, cs, vec, p2p_standin_ticks(p, 4.0 * (double)cs * (W - 1)));
+    } else {
+        // (a rank whose chunk is empty -- a bucket shorter than the world -- still issues the phase: its barrier is what its peers wait for)
+        p2p_launch_rs<false>(p, p->arenas, p->rank, W, offset_floats + (size_t)(cn > 0 ? c0 : 0), cn > 0 ? cn : 0, vec, 0ull);
+        p2p_launch_ag<false>(p, p->arenas, p->rank, W, offset_floats, n, cs, vec, 0ull);
     }
-    st = p2p_barrier(p);
-    if (st != VBNN_OK) return st;
-    if (sim) p2p_launch_ag<true>(p, p2p_standin_table(p, cs, true), 0, W, offset_floats, n, cs, vec, p2p_standin_ticks(p, 4.0 * (double)cs * (W - 1)));
-    else p2p_launch_ag<false>(p, p->arenas, p->rank, W, offset_floats, n, cs, vec, 0ull);
-    st = p2p_barrier(p);
-    if (st != VBNN_OK) return st;
     return vbnn_check_launch("vbnn_p2p_allreduce");
     VBNN_API_END
 }
@@ -387,11 +442,9 @@ extern "C" int vbnn_p2p_reduce_scatter(vbnn_p2p* p, size_t offset_floats, int64_
     if (p->world == 1) return VBNN_OK;
     const size_t c0 = offset_floats + (size_t)p->rank * (size_t)n_per_rank;
     const int vec = (c0 % 4 == 0 && offset_floats % 4 == 0 && n_per_rank % 4 == 0) ? 1 : 0;
-    int st = p2p_barrier(p);
+    const int st = p2p_claim_region(p, offset_floats, n_per_rank * (int64_t)p->world);
     if (st != VBNN_OK) return st;
-    p2p_launch_rs<false>(p, p->arenas, p->rank, p->world, c0, n_per_rank, vec, 0ull);
-    st = p2p_barrier(p);
-    if (st != VBNN_OK) return st;
+    p2p_launch_rs<false>(p, p->arenas, p->rank, p->world, c0, n_per_rank, vec, 0ull);      // (entry barrier + kernel; the exit barrier is vbnn_p2p_finish's)
     return vbnn_check_launch("vbnn_p2p_reduce_scatter");
     VBNN_API_END
 }
@@ -405,11 +458,9 @@ extern "C" int vbnn_p2p_all_gather(vbnn_p2p* p, size_t offset_floats, int64_t n_
     p->pending += 1;
     if (p->world == 1) return VBNN_OK;
     const int vec = (offset_floats % 4 == 0 && n_per_rank % 4 == 0) ? 1 : 0;
-    int st = p2p_barrier(p);
+    const int st = p2p_claim_region(p, offset_floats, n_per_rank * (int64_t)p->world);
     if (st != VBNN_OK) return st;
     p2p_launch_ag<false>(p, p->arenas, p->rank, p->world, offset_floats, n_per_rank * (int64_t)p->world, n_per_rank, vec, 0ull);
-    st = p2p_barrier(p);
-    if (st != VBNN_OK) return st;
     return vbnn_check_launch("vbnn_p2p_all_gather");
     VBNN_API_END
 }
@@ -444,6 +495,10 @@ extern "C" int vbnn_p2p_finish(vbnn_p2p* p) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(p, "null p2p");
     if (p->pending == 0) return VBNN_OK;
+    if (p->need_final) {                     // the step's one barrier launch: every rank has finished every phase -- the arena may be overwritten
+        const int st = p2p_barrier(p);
+        if (st != VBNN_OK) return st;
+    }
     VBNN_CHECK_HIP(hipEventRecord(p->done, p->stream));
     VBNN_CHECK_HIP(hipStreamWaitEvent(p->ctx->stream, p->done, 0));
     p->pending = 0;

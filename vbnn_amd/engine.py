@@ -282,10 +282,6 @@ class FusedMLP:
         self._rpd = 0            # > 0 inside run_draws: rows per Monte-Carlo draw of the stacked minibatch
         self._x_in = None        # fp32: the raw minibatch of the current run, read in place by layer 1's GEMMs
         self._draws = None
-        # run(.., fuse_update = opt): VBLinear:update's sweeps issued INSIDE the backward (see _fused_update_plan); state of it
-        self._upd_ctx = None          # the side stream's library context (made on first use)
-        self._upd_issued = None       # the opt of a run() that pre-issued its update: update() then only completes it
-        self._upd_events = {}         # layer index -> event of a side sweep the NEXT forward of that layer must wait for
         self.init_parameters()
 
     # mlp.lua:47-55 (He rule for every weight, bias zero) + the bench's non-degenerate means
@@ -408,7 +404,6 @@ class FusedMLP:
     @_ordered
     def prepare(self):
         lib = L.lib()
-        self.join_updates()
         if self._params_stale:
             # after a sharded update: every rank already holds what this sweep would produce -- the gathered operand shadows, the
             # combined prior statistics, the packed final weight (_update_sharded; "update leaves what prepare would" is a test)
@@ -560,7 +555,7 @@ class FusedMLP:
     # raw minibatch's address -- is patched in.
     def _fwd_args(self, li, N, row0):
         direct_x = li == 0 and self._x_in is not None
-        key = ("fwd", li, N, row0, self._rpd, direct_x, self._lrt(), getattr(self.vb[li], "_par", 0))     # (the block bakes in the LRT / MAP operand set and WHICH shadow buffers are current)
+        key = ("fwd", li, N, row0, self._rpd, direct_x, self._lrt())     # (the block bakes in the LRT / MAP operand set)
         a = self._argcache.get(key)
         if a is None:
             a = self._argcache[key] = self._build_fwd_args(li, N, row0)
@@ -594,7 +589,7 @@ class FusedMLP:
 
     def _dw_args(self, li, N, accumulate):
         direct_x = li == 0 and self._x_in is not None
-        key = ("dw", li, N, accumulate, float(self._draws or self.S), direct_x, self._lrt(), getattr(self.vb[li], "_par", 0))
+        key = ("dw", li, N, accumulate, float(self._draws or self.S), direct_x, self._lrt())
         d = self._argcache.get(key)
         if d is None:
             d = self._argcache[key] = self._build_dw_args(li, N, accumulate)
@@ -631,7 +626,7 @@ class FusedMLP:
         return d
 
     def _dx_args(self, li, N):
-        key = ("dx", li, N, self._lrt(), getattr(self.vb[li], "_par", 0))
+        key = ("dx", li, N, self._lrt())
         a = self._argcache.get(key)
         if a is None:
             a = self._argcache[key] = self._build_dx_args(li, N)
@@ -651,15 +646,13 @@ class FusedMLP:
 
     # ---- mlp.lua:76-84, fused
     @_ordered
-    def run(self, inputs, targets, row0=None, backward=True, last_draw=None, fuse_update=None):
+    def run(self, inputs, targets, row0=None, backward=True, last_draw=None):
         """last_draw (data-parallel only): whether this run's gradients are the minibatch's final ones, i.e. whether the
         buckets' all-reduces are issued. Default: the opt.S-th sequential run since resetGradients() (always, inside
         run_draws). The draws of a minibatch ACCUMULATE in the arena (main.lua:32-37): exchanging after every draw would
         all-reduce sums that already contain other ranks' contributions, and the exchange stream's in-place write would
         race with the next draw's accumulate epilogue -- so earlier draws only accumulate."""
         lib, ctx, code = L.lib(), self.ctx.h, self.code
-        if self._upd_issued is not None:
-            raise RuntimeError("run(.., fuse_update = opt) issued this minibatch's update sweeps: call update() before the next run()")
         if backward:
             self._draws_run += 1
             if last_draw is None:
@@ -693,9 +686,6 @@ class FusedMLP:
         nl = len(self.vb)
         # ---------------- forward
         for li in range(nl):
-            ev = self._upd_events.pop(li, None)
-            if ev is not None:                  # a side sweep of the previous minibatch's update wrote this layer's shadows / bias
-                torch.cuda.current_stream(self.device).wait_event(ev)
             a = self._fwd_args(li, N, row0)
             with self._probed("forward", li):
                 L.check(lib.vbnn_forward(ctx, code, C.byref(a)))
@@ -755,28 +745,7 @@ class FusedMLP:
         # all-reduce) of layer li and updateGradInput of layer li are independent of each other (both consume
         # g_li): with `overlap` they run on two HIP streams, so the HBM-bound epilogue of one GEMM sits beside the
         # MFMA main loop of the other instead of every CU hitting its epilogue at the same moment.
-        fused = None
-        if fuse_update is not None and fuse_update is not False:
-            fused = self._fused_update_plan(self.opt if fuse_update is True else fuse_update, lrt, last_draw)
-        if fused is not None:
-            # VBLinear:update's sweeps INSIDE the backward (r05): layer by layer, accGradParameters first; the moment a layer's
-            # gradients are final its sweep goes out -- on the side stream, in the co-resident form, for the layers whose remaining
-            # backward launches leave room for it beside them (fused["side"]), else at the end on this stream -- and update()
-            # only completes what is left. Bitwise the serial step (tools/step_bits.py, tests).
-            for li in range(nl - 1, -1, -1):
-                v = self.vb[li]
-                with self._probed("accGradParameters", li):
-                    L.check(lib.vbnn_acc_grad_parameters(ctx, code, C.byref(self._dw_args(li, N, accumulate))))
-                if not (fused_head and li == nl - 1) and not v.bias_from_dw:
-                    L.check(lib.vbnn_acc_grad_bias(ctx, code, v.g_s.ptr, v.g_s.ld, N, v.O, 1.0, accumulate, _p(v.gradBias)))
-                dx = self._dx_args(li, N) if li > 0 else None        # (built BEFORE the sweep flips the layer's shadow buffers)
-                if li in fused["side"]:
-                    self._issue_sweep(li, fused["opt"], side=True)
-                if li > 0:
-                    with self._probed("updateGradInput", li):
-                        L.check(lib.vbnn_grad_input(ctx, code, C.byref(dx)))
-            self._upd_issued = fused
-        elif self.f32_direct and not self.overlap:
+        if self.f32_direct and not self.overlap:
             # fp32, launch-bound sizes: accGradParameters and updateGradInput of a layer are independent (both consume g_li) and
             # go out as ONE launch where the library can carry both (vbnn_backward_pair: the general kernel's K-major forms at
             # its 32 x 32 geometry; elsewhere the call is the two launches) -- each tile bitwise what its own launch computes
@@ -983,100 +952,6 @@ class FusedMLP:
             raise RuntimeError(f"{what}: the fp32 means / lvars of other ranks' rows are stale after a sharded update -- call "
                                "gather_parameters() on EVERY rank first (a collective; it is never issued implicitly)")
 
-    # ---- VBLinear:update overlapped with the backward (main.lua:28-40 runs update after the whole backward, but
-    # nothing in VBLinear:update of layer l depends on the layers below it). Which layers can be swept on the side stream: the
-    # co-resident sweep takes 64 registers per lane, so it fits beside a launch whose waves allocate <= 224 (updateGradInput 217,
-    # the forwards 211 / 222, the half-height accGradParameters 147) and NOT beside the 4096^3 accGradParameters (226 -> 232: a CU
-    # that holds sweep waves could not take its tile -- two rounds). So: layer li >= 1 goes to the side when every accGradParameters
-    # still to come (layers < li) is the half-height launch -- the wide configuration's layer 2. Everything else is swept at the end.
-    def _fused_update_plan(self, opt, lrt, last_draw):
-        ok = (self.dtype == "bf16" and lrt and self.fuse_kl and self.kl_in_update and not self.reduce and not self.overlap and
-              not self._rpd and bool(last_draw) and self.criterion in ("nll", "mse") and "state" in opt and "meanState" in opt and "varState" in opt)
-        if not ok:
-            return None
-        flat = [v.muT_s is None or not getattr(v, "use_muT", True) for v in self.vb]
-        side = set()
-        for li in range(1, len(self.vb)):
-            v = self.vb[li]
-            if flat[li] and v.I % 4 == 0 and v.O * v.I >= (1 << 21) and all(getattr(self.vb[k], "x_pad256", False) for k in range(li)) \
-                    and not self.opt.get("update_on_main", False):
-                side.add(li)
-        return {"opt": opt, "side": side, "swept": set()}
-
-    def _sweep_desc(self, li, opt, mu_s, var_s):
-        v = self.vb[li]
-        st = self.__dict__.setdefault("_opt_state", {})
-        lr = float(opt["state"]["learningRate"])
-        cfgs = []
-        for key, x, cfg in (("mean", v.means, opt["meanState"]), ("var", v.lvars, opt["varState"])):
-            s = st.setdefault((v.layer_id, key), {"t": 0})
-            if "m" not in s:
-                s["m"], s["v"] = torch.zeros_like(x), torch.zeros_like(x)
-            s["t"] += 1
-            cfgs.append((s, L.AdamCfg(lr=float(cfg["learningRate"]), beta1=float(cfg.get("beta1", 0.9)),
-                                      beta2=float(cfg.get("beta2", 0.999)), eps=float(cfg.get("epsilon", 1e-8)),
-                                      lambda_=float(cfg.get("lambda", 1.0)), t=s["t"])))
-        (sm, cm), (sv, cv) = cfgs
-        use_t = v.muT_s is not None and getattr(v, "use_muT", True)
-        return L.UpdateDesc(means=_p(v.means), lvars=_p(v.lvars), O=v.O, I=v.I, mu_s=mu_s.ptr, var_s=var_s.ptr,
-                            ld_w=mu_s.ld, muT_s=v.muT_s.ptr if use_t else None, varT_s=v.varT_s.ptr if use_t else None,
-                            ld_wT=v.muT_s.ld if v.muT_s else 0, stats=_p(v.stats), grad_mu=_p(v.gradWeight),
-                            grad_lv=_p(v.gradSum), m_mu=_p(sm["m"]), v_mu=_p(sm["v"]), m_lv=_p(sv["m"]), v_lv=_p(sv["v"]),
-                            mu=cm, lv=cv, bias=_p(v.bias), grad_bias=_p(v.gradBias), lr_bias=lr, B=self.B, log14=None,
-                            kl_add=1.0 if self.kl_in_update else 0.0)
-
-    def _issue_sweep(self, li, opt, side):
-        """Layer li's sweep + its own finish kernel (statistics, bias SGD) as a chain of its own. side: on the update stream, in the
-        co-resident form, writing the layer's ALTERNATE shadow buffers (this minibatch's updateGradInput may still be reading the
-        current ones), which become current for the next forward -- that forward waits for the chain's event."""
-        lib, v = L.lib(), self.vb[li]
-        if side:
-            if self._upd_ctx is None:
-                self._upd_stream = torch.cuda.Stream(device=self.device)
-                self._upd_ctx = Context(self.device.index or 0, stream=self._upd_stream)
-            if getattr(v, "mu_alt", None) is None:
-                v.mu_alt, v.var_alt = _Packed(v.O, v.I, self.tdt, self.device), _Packed(v.O, v.I, self.tdt, self.device)
-            main = torch.cuda.current_stream(self.device)
-            ready = torch.cuda.Event()
-            ready.record(main)                               # the layer's gradients are final on the compute stream
-            self._upd_stream.wait_event(ready)
-            d = self._sweep_desc(li, opt, v.mu_alt, v.var_alt)
-            h = self._upd_ctx.h
-            L.check(lib.vbnn_update_layer(h, h, self.code, 0, C.byref(d), 1))
-            L.check(lib.vbnn_update_finish(h, self.code, 1, C.byref(d), None))
-            done = torch.cuda.Event()
-            done.record(self._upd_stream)
-            self._upd_events[li] = done
-            v.mu_s, v.mu_alt = v.mu_alt, v.mu_s              # what the next forward / gradInput / accGradParameters read
-            v.var_s, v.var_alt = v.var_alt, v.var_s
-            v._par = 1 - getattr(v, "_par", 0)
-        else:
-            d = self._sweep_desc(li, opt, v.mu_s, v.var_s)
-            L.check(lib.vbnn_update_layer(self.ctx.h, self.ctx.h, self.code, 0, C.byref(d), 0))
-            L.check(lib.vbnn_update_finish(self.ctx.h, self.code, 1, C.byref(d), None))
-
-    def join_updates(self):
-        """The compute stream waits for every side sweep still in flight (host-visible reads of parameters / shadows, a serial
-        update, prepare): no host block."""
-        main = torch.cuda.current_stream(self.device)
-        for li in list(self._upd_events):
-            main.wait_event(self._upd_events.pop(li))
-
-    def _complete_fused_update(self, fused):
-        """update() after run(.., fuse_update = opt): the final Linear's SGD + packing and the sweeps that did not go to the side."""
-        lib, h, opt = L.lib(), self.ctx.h, fused["opt"]
-        lr = float(opt["state"]["learningRate"])
-        L.check(lib.vbnn_sgd_step(h, _p(self.weight3), _p(self.gradWeight3), self.weight3.numel(), lr))
-        L.check(lib.vbnn_sgd_step(h, _p(self.bias3), _p(self.gradBias3), self.bias3.numel(), lr))
-        for li in range(len(self.vb) - 1, -1, -1):
-            if li not in fused["side"]:
-                self._issue_sweep(li, opt, side=False)
-        w3 = L.PackDesc(src=_p(self.weight3), rows=self.n_classes, cols=self.sizes[-1], ld_src=self.sizes[-1],
-                        dst=self.w3_s.ptr, ld_dst=self.w3_s.ld, dstT=self.w3T_s.ptr, ld_dstT=self.w3T_s.ld)
-        L.check(lib.vbnn_update_finish(h, self.code, 0, None, C.byref(w3)))
-        if not self.opt.get("update_cross_step", False):
-            self.join_updates()              # default: everything the update wrote is ordered on the compute stream when update() returns
-
     def _update_sharded(self, opt):
         """mlp:update / VBLinear:update with the parameters SHARDED by layer rows: the reduce-scatter left this rank the summed
         likelihood gradients of its rows; vbnn_update runs on those rows alone (+ the exact KL gradient, kl_add), then the new
@@ -1215,12 +1090,7 @@ class FusedMLP:
     def update(self, opt=None, log=False):
         if not self.fuse_kl:
             raise RuntimeError("FusedMLP.update needs opt.fuse_kl = True (total gradients from the dW epilogue)")
-        if self._upd_issued is not None:       # run(.., fuse_update = opt) issued the sweeps it could: complete the update
-            fused, self._upd_issued = self._upd_issued, None
-            assert not log, "the fused update forms no logged series: run() without fuse_update, then update(log=True)"
-            return self._complete_fused_update(fused)
         opt = opt or self.opt
-        self.join_updates()
         self.finish()
         self.check_exchange()                  # BEFORE a parameter is touched: an incomplete exchange must not reach them
         if self.sharded:
@@ -1275,7 +1145,6 @@ class FusedMLP:
 
     # ---- reporting (each of these synchronises)
     def loss_and_accuracy(self):
-        self.join_updates()
         self.finish()
         torch.cuda.synchronize(self.device)
         self.check_exchange()
@@ -1286,7 +1155,6 @@ class FusedMLP:
     @_ordered
     def calc_lc(self, opt=None):                                         # mlp.lua:109-115, fresh statistics
         self._need_gathered_parameters("calc_lc")
-        self.join_updates()
         lc = 0.0
         B = float((opt or self.opt).get("B", self.B))
         for v in self.vb:
