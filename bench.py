@@ -405,6 +405,49 @@ def probe_exchange_backends(torch, dist, rank, world, local_rank, n_floats=1 << 
     return out
 
 
+def validate_exchange(eng, x, t, torch, dist, world):
+    """Before anything is timed on N > 1 ranks: does the exchange the step will use SUM? The same minibatch and the same draw twice --
+    once with the collective calls left out (this rank's own gradients, saved), once with them -- then (1) every rank must hold the
+    same arena (two 64-bit checksums of its bits, gathered over the process group: the direct exchange sums in rank order, so its
+    arenas are bitwise equal; RCCL's are equal on every rank as well) and (2) the arena must equal the process group's own all-reduce
+    of the saved gradients to fp32 summation-order rounding. The direct exchange has never run across two DEVICES (its visibility
+    argument -- data crosses devices at kernel boundaries -- is an argument): the first multi-GPU run checks itself, and a
+    throughput measured on sums that are not sums is not reported. Collective: every rank calls it."""
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    d0 = eng.draw
+    eng.skip_exchange = True
+    eng.resetGradients(); eng.sample(); eng.run(x, t); eng.finish()
+    torch.cuda.synchronize()
+    local = eng.grads.clone()
+    eng.skip_exchange = False
+    eng.draw = d0                                           # the same draw again: the same noise, the same local gradients
+    eng.resetGradients(); eng.sample(); eng.run(x, t); eng.finish()
+    torch.cuda.synchronize()
+    gave_up = None
+    try:
+        eng.check_exchange()
+    except RuntimeError as e:                               # (a p2p barrier that gave up: the verdict below is collective all the same)
+        gave_up = str(e)[:300]
+    bits = eng.grads.view(torch.int32).to(torch.int64)
+    mine = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 8191 + 1)).sum()]).to(dev)
+    seen = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine)
+    identical = all(bool(torch.equal(sv, seen[0])) for sv in seen)
+    ref = local                                             # (in place: the saved copy becomes the library's sum)
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max().item()) or 1.0
+    err = float((eng.grads - ref).abs().max().item()) / scale
+    finite = bool(torch.isfinite(eng.grads).all().item())
+    tol = 1e-5 if eng.exchange_dtype == "f32" else 2e-2
+    flag = torch.tensor([1 if (identical and finite and err <= tol and gave_up is None) else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)             # one verdict for every rank
+    return {"ok": bool(flag.item()), "identical_across_ranks": identical, "finite": finite,
+            "max_abs_err_over_max_abs_vs_process_group_sum": err, "tolerance": tol, "backend": eng.comm_backend(), "gave_up": gave_up,
+            "note": "one minibatch and draw twice, without and with the exchange: arena checksums equal on every rank; arena against "
+                    "torch.distributed's all-reduce of the saved local gradients (fp32 summation order)"}
+
+
 def time_other_backend(eng, torch, reps=5):
     """The buckets of the step through the exchange backend the step did NOT use, back to back on the idle GPUs: vbnn_p2p (the
     direct reduce-scatter + all-gather over peer-mapped arenas) when the step ran on RCCL, RCCL when it ran on vbnn_p2p -- so
@@ -642,6 +685,24 @@ def main():
         return wall, evms
 
     eng.prepare()                                        # once: afterwards the update kernel maintains shadows + statistics
+    xval = None
+    if use_dist and world > 1 and args.S == 1 and not args.stack_draws:
+        # the exchange checks itself before anything is timed; the direct exchange failing that check falls back to the library once
+        xval = validate_exchange(eng, x, t, torch, dist, world)
+        if not xval["ok"] and eng.exchange_kind == "p2p" and backend == "nccl":
+            first = xval
+            del eng
+            torch.cuda.empty_cache()
+            opt.pop("exchange", None)
+            eng = FusedMLP(opt, world_size=world, rank=rank, force_reduce=use_dist, stream=stream)
+            eng.prepare()
+            xval = validate_exchange(eng, x, t, torch, dist, world)
+            xval["fell_back_from"] = first
+        if not xval["ok"]:
+            if rank == 0:
+                print(json.dumps({"metric": "VBLinear fwd+bwd samples/sec", "value": None, "n_gpus": world, "exchange_failed": "the exchange did not sum",
+                                  "exchange_validation": xval}), flush=True)
+            sys.exit(3)
     for _ in range(args.warmup):
         step()
     # the box's own speed, measured here and now (rank 0's device; every rank runs it so the ranks stay in step): after the
@@ -772,6 +833,8 @@ def main():
                 "distinct_devices": len({i[2] for i in ident}), "allreduce": eng.time_buckets(5)}
         if xprobe is not None:
             comm["probe"] = xprobe
+        if xval is not None:
+            comm["validation"] = xval
         if noex is not None:
             comm["step_without_exchange"] = noex
         if world > 1 and os.environ.get("VBNN_BENCH_OTHER_BACKEND", "1") != "0":

@@ -97,6 +97,9 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
     # the exposed exchange time, every bucket through the OTHER backend as well (here: the step on torch.distributed / gloo,
     # vbnn_p2p timed beside it over IPC-mapped arenas), no p2p barrier given up, the overlapped GEMMs' own times, and the
     # training step
+    # the exchange checked itself before anything was timed (r05): one minibatch and draw without and with the collective calls
+    val = out["comm"]["validation"]
+    assert val["ok"] and val["identical_across_ranks"] and val["finite"] and val["max_abs_err_over_max_abs_vs_process_group_sum"] <= 1e-5, val
     noex = out["comm"]["step_without_exchange"]
     assert noex["ms_per_step"] > 0 and abs(noex["exposed_exchange_ms"] - (out["ms_per_step"] - noex["ms_per_step"])) < 1e-3
     # (--exchange auto: both backends were timed on a 64 MB message at start-up and the faster carries the step; the other one's
@@ -131,6 +134,7 @@ def test_bench_rehearsal_with_the_p2p_exchange_reports_its_status():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
     assert out["comm"]["backend"] == "vbnn_p2p/ipc" and out["comm"]["p2p_barrier_gave_up_epoch"] == 0
+    assert out["comm"]["validation"]["ok"] and out["comm"]["validation"]["backend"] == "vbnn_p2p/ipc", out["comm"]["validation"]
     assert "error" in out["comm"]["other_backend"]                  # RCCL is not timed with ranks sharing a device, and says so
     assert out["comm"]["step_without_exchange"]["ms_per_step"] > 0
     # a rank count the launcher did not provide is an error, not a silent single-rank run

@@ -11,7 +11,7 @@ for r in $(seq 1 $rounds); do
     python3 - "$name" $out <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-print(f"[{sys.argv[1]:8s}] ms/step {d['ms_per_step']} repeats {d['config']['repeats_wall_ms']} kernels {d['roofline']['timed_region_kernels_ms']}")
+print(f"[{sys.argv[1]:8s}] ms/step {d['ms_per_step']} repeats {d['config']['repeats_wall_ms']} kernels {d['roofline']['timed_region_kernels_ms']}" + (f" train {d['train_step']['ms_per_train_step']} {d['train_step']['repeats_wall_ms']}" if d.get('train_step') else ""))
 PY
   done
 done

@@ -987,12 +987,28 @@ __global__ __launch_bounds__(256) void k_update_finish(UpdFinishArgs a) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) acc[k] = 0.0;
         acc[12] = acc[14] = 1e300; acc[13] = acc[15] = -1e300;
-        for (int b = threadIdx.x; b < a.nb[l]; b += 256) {
-            const double* p = a.partial[l] + (size_t)b * UPD_NSUM;
+        // two partial rows' loads in flight per thread (r05: this launch was ~22 us of the training step, most of it dependent
+        // round trips: eight rows per thread one after the other, then sixteen bias elements one after the other); the rows are
+        // still ADDED in order: the same bits
+        const int nb = a.nb[l];
+        const double* pl = a.partial[l];
+        for (int b = threadIdx.x; b < nb; b += 512) {
+            const bool two = b + 256 < nb;
+            double r0[UPD_NSUM], r1[UPD_NSUM];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) acc[k] += p[k];
-            acc[12] = fmin(acc[12], p[12]); acc[13] = fmax(acc[13], p[13]);
-            acc[14] = fmin(acc[14], p[14]); acc[15] = fmax(acc[15], p[15]);
+            for (int k = 0; k < UPD_NSUM; ++k) r0[k] = pl[(size_t)b * UPD_NSUM + k];
+#pragma unroll
+            for (int k = 0; k < UPD_NSUM; ++k) r1[k] = two ? pl[(size_t)(b + 256) * UPD_NSUM + k] : ((k < 12) ? 0.0 : ((k & 1) ? -1e300 : 1e300));
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] += r0[k];
+            acc[12] = fmin(acc[12], r0[12]); acc[13] = fmax(acc[13], r0[13]);
+            acc[14] = fmin(acc[14], r0[14]); acc[15] = fmax(acc[15], r0[15]);
+            if (two) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) acc[k] += r1[k];
+                acc[12] = fmin(acc[12], r1[12]); acc[13] = fmax(acc[13], r1[13]);
+                acc[14] = fmin(acc[14], r1[14]); acc[15] = fmax(acc[15], r1[15]);
+            }
         }
         __shared__ double tot[UPD_NSUM];
         upd_block_reduce(acc, tot, sh);
@@ -1012,10 +1028,15 @@ __global__ __launch_bounds__(256) void k_update_finish(UpdFinishArgs a) {
             double* st = a.stats[l];                            // as prior_finish, of the NEW parameters
             st[0] = tot[0]; st[1] = tot[1]; st[2] = (1.0 / W) * tot[0]; st[3] = W;
         }
-        if (a.bias[l])                                          // optim.sgd on the bias (VBLinear.lua:125-128)
-            for (int64_t o = threadIdx.x; o < a.O[l]; o += 256) a.bias[l][o] = fmaf(-a.lr_bias[l], a.grad_bias[l][o], a.bias[l][o]);
+        if (a.bias[l] && (int)gridDim.x == a.n)                 // optim.sgd on the bias (VBLinear.lua:125-128): here only when there are no
+            for (int64_t o = threadIdx.x; o < a.O[l]; o += 256) a.bias[l][o] = fmaf(-a.lr_bias[l], a.grad_bias[l][o], a.bias[l][o]);   // packing blocks to share it
         return;
     }
+    // the layers' bias steps, spread over the packing blocks (one element per thread and stride: independent elements)
+    for (int l = 0; l < a.n; ++l)
+        if (a.bias[l])
+            for (int64_t o = (int64_t)(blockIdx.x - a.n) * 256 + threadIdx.x; o < a.O[l]; o += (int64_t)(gridDim.x - a.n) * 256)
+                a.bias[l][o] = fmaf(-a.lr_bias[l], a.grad_bias[l][o], a.bias[l][o]);
     T* dst = (T*)a.dst;
     T* dstT = (T*)a.dstT;
     const int64_t total = a.rows * a.cols;
@@ -1043,6 +1064,9 @@ extern "C" int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_up
     VBNN_REQUIRE((size_t)n_layers * MAXB * UPD_NSUM <= ctx->scratch_doubles, "scratch");
     UpdFinishArgs fa{};
     fa.n = n_layers;
+    // (layer order. r05 A/B, two rounds on one box: the layer whose gradients were written LAST first -- they might still sit in the
+    // Infinity Cache -- 1.025 / 1.029 ms per training step against 1.008 / 1.003; with accGradParameters' gradient stores plain instead
+    // of nontemporal as well, 1.033 / 1.024, and the step without update 0.765 against 0.750: neither is kept.)
     for (int l = 0; l < n_layers; ++l) {
         const vbnn_update_desc& d = layers[l];
         VBNN_REQUIRE(d.means && d.lvars && d.mu_s && d.var_s && d.stats, "null layer argument");
