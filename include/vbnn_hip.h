@@ -65,6 +65,9 @@ const char* vbnn_last_error(void);
                                       gradients only): -1 = by shape (default), 0 = never, 1 = whenever possible */
 #define VBNN_DEBUG_V3_SPLIT 8      /* two-pass kernel's pair-split half-height launch for few-tile parameter gradients: -1 = by shape (default), 0 = never, 1 = whenever possible */
 #define VBNN_DEBUG_V0 9            /* fp32 shapes of the launch-bound geometry: 1 = the latency kernel (gemm_v0.h; default), 0 = gemm_v1's 32 x 32 tile */
+#define VBNN_DEBUG_HEAD_BACKWARD 10   /* the fused head's backward (vbnn_head_backward, bf16): -1 = by shape (default: the streaming form for whole
+                                         128-unit x 32-row tiles with a separate finish kernel), 0 = the tile form, 1 = the streaming form
+                                         whenever the operands allow it (also at sizes whose partial sums the tile form finishes in-launch) */
 #define VBNN_DEBUG_KMAJOR 6        /* K-major operands (gemm_v3.h AK / BK): 1 = use when the shape allows (default), 0 = never, 2 = gemm_v3 only */
 int vbnn_debug_set(int key, int value);
 

@@ -1031,6 +1031,65 @@ def test_head_logits_from_the_forward_tiles_equal_the_heads_own_pass_over_h(orac
     assert rel <= 1e-4, f"weight-noise gradient arenas of the two head forms: relative Frobenius {rel:.3e}"
 
 
+@pytest.mark.parametrize("N,H,C,with_r", [(4096, 4096, 10, True), (512, 256, 10, True), (320, 384, 3, True), (64, 128, 12, False), (1024, 1024, 1, True)])
+def test_streaming_head_backward_agrees_with_the_tile_form_and_with_float64(nnmod, N, H, C, with_r):
+    """The fused head's backward in its STREAMING form (r05, k_head_backward_stream: no LDS in the loop, four waves per SIMD,
+    d(loss)/d(logits) as scalar operands of v_dot2c_f32_bf16) against the tile form (k_head_backward: MFMA sums over LDS tiles), forced
+    one after the other through vbnn_debug_set(VBNN_DEBUG_HEAD_BACKWARD), and both against float64 on the same bf16 operands:
+    g_prev = (round_bf16(g) W3) . [h > 0], gv_prev = g_prev . r (bf16 outputs: equal up to one bf16 ulp where the fp32 sums round
+    differently), gradWeight = round_bf16(g)^T h, the layer below's bias gradient = column sums of the ROUNDED g_prev, the final
+    bias gradient = column sums of the unrounded g; with accumulate = 1 on top of what is there. Ragged class counts (1, 3, 12),
+    a net without r (weight-noise mode), sizes whose partial sums the tile form would finish in-launch."""
+    from vbnn_amd import _lib as L
+    from vbnn_amd.nn import Context, _Packed, _p
+    lib, ctx = L.lib(), Context.get(torch.device("cuda", 0))
+    gen = torch.Generator(device="cuda").manual_seed(N + H + C)
+    bf = torch.bfloat16
+    hs, rs, w3 = _Packed(N, H, bf, "cuda"), _Packed(N, H, bf, "cuda"), _Packed(C, H, bf, "cuda")
+    hs.t[:, :H] = torch.relu(torch.randn(N, H, device="cuda", generator=gen)).to(bf)
+    rs.t[:, :H] = (0.5 * torch.randn(N, H, device="cuda", generator=gen)).to(bf)
+    w3.t[:, :H] = (torch.randn(C, H, device="cuda", generator=gen) / 8).to(bf)
+    g = (torch.randn(N, C, device="cuda", generator=gen) / N).contiguous()
+    base = {k: torch.randn(*shape, device="cuda", generator=gen) for k, shape in (("gw", (C, H)), ("gb", (C,)), ("gbp", (H,)))}
+    res = {}
+    try:
+        for form in (0, 1):
+            L.check(lib.vbnn_debug_set(10, form))
+            outs = []
+            for accumulate in (0, 1):
+                gw, gb, gbp = base["gw"].clone(), base["gb"].clone(), base["gbp"].clone()
+                gp, gvp = _Packed(N, H, bf, "cuda"), _Packed(N, H, bf, "cuda")
+                L.check(lib.vbnn_head_backward(ctx.h, L.BF16, hs.ptr, hs.ld, w3.ptr, w3.ld, _p(g), N, H, C, accumulate, _p(gw), _p(gb), _p(gbp), 1,
+                                               rs.ptr if with_r else None, rs.ld, 1, gp.ptr, gvp.ptr if with_r else None, gp.ld, None, None, 0))
+                torch.cuda.synchronize()
+                outs.append(dict(gw=gw, gb=gb, gbp=gbp, gp=gp.t[:, :H].float(), gvp=gvp.t[:, :H].float()))
+            res[form] = outs
+    finally:
+        L.check(lib.vbnn_debug_set(10, -1))
+    h64, r64, w64 = hs.t[:, :H].double(), rs.t[:, :H].double(), w3.t[:, :H].double()
+    g64 = g.to(bf).double()
+    gx = (g64 @ w64) * (h64 > 0)
+    for form in (0, 1):
+        for accumulate in (0, 1):
+            o = res[form][accumulate]
+            tag = f"form {form} accumulate {accumulate}"
+            # bf16 outputs against float64: within one bf16 rounding of the exact value (2^-8 relative) plus the fp32 sum's own rounding
+            assert float((o["gp"].double() - gx).abs().max()) <= 2.0 ** -8 * float(gx.abs().max()) + 1e-12, tag
+            if with_r:
+                # (gv_prev = bf16(g_prev before ITS rounding x r): half an ulp from each of the two roundings)
+                assert float((o["gvp"].double() - o["gp"].double() * r64).abs().max()) <= 2.0 ** -7 * float((gx * r64).abs().max()) + 1e-12, tag
+            want_w = g64.T @ h64 + (base["gw"].double() if accumulate else 0)
+            want_bp = o["gp"].double().sum(0) + (base["gbp"].double() if accumulate else 0)          # of the ROUNDED g_prev this form stored
+            want_b = g.double().sum(0) + (base["gb"].double() if accumulate else 0)
+            assert float((o["gw"].double() - want_w).abs().max()) <= 2e-6 * float((g64.abs().T @ h64).max()) + 1e-6 * float(base["gw"].abs().max()) * accumulate + 1e-12, tag
+            assert float((o["gbp"].double() - want_bp).abs().max()) <= 2e-6 * float(o["gp"].double().abs().sum(0).max()) + 1e-6 * float(base["gbp"].abs().max()) * accumulate + 1e-12, tag
+            assert float((o["gb"].double() - want_b).abs().max()) <= 2e-6 * float(g.double().abs().sum(0).max()) + 1e-6 * float(base["gb"].abs().max()) * accumulate + 1e-12, tag
+    # the two forms against each other: the bf16 outputs differ, if at all, by one bf16 ulp in a small fraction of places
+    a, b = res[0][0], res[1][0]
+    d = (a["gp"] - b["gp"]).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(a["gp"].abs().max()) and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_one_engine_alternates_sampled_and_map_passes_at_one_batch_size(oracle, nnmod, dtype):
     """the kept argument blocks bake in the LRT / MAP operand set, and their cache key did not say which.

@@ -40,7 +40,7 @@ def main():
     for gi, ctrs in enumerate(groups):
         d = os.path.join(out_dir, f"g{gi}")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", d, "-o", f"g{gi}", "--",
-               "python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline",
+               "python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-box",
                "--no-reporting-config", "--no-deep-config", "--no-train-step", *bench_args]
         print("pass", gi, " ".join(ctrs), flush=True)
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)

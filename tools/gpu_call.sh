@@ -1,4 +1,9 @@
 set -o pipefail
 mkdir -p gpurun_out
-echo "== tests"; timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --durations=8 > gpurun_out/r05e_tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/r05e_tests.log
-echo "== A/B sweep order / gradient stores"; bash tools/ab_lib.sh r05ntg 2 "--steps 20 --warmup 5 --no-reporting-config --no-deep-config --no-box" . rev ntg0 ntg0r 2>&1 | tail -10
+echo "== tests"; timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --durations=5 > gpurun_out/r05h_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r05h_tests.log
+echo "== bench"; timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > gpurun_out/r05h_bench_wide_driver.json 2> gpurun_out/r05h_bench.err; echo "bench rc=$?"
+python3 - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r05h_bench_wide_driver.json").read().strip().splitlines()[-1])
+print(d["ms_per_step"], d["value"], d["config"]["repeats_wall_ms"], d["box"]["mfma_clock_ghz"], d["roofline"].get("frac"), d["roofline"].get("frac_at_held_clock"), d["train_step"]["ms_per_train_step"], d["deep_config"]["ms_per_step"])
+PY

@@ -22,14 +22,14 @@ timeout -k 10 300 python3 bench.py --config small --S 30 --batch 1 --stack-draws
 timeout -k 10 400 python3 bench.py --config deep --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_bench_deep.json 2>> gpurun_out/${tag}_bench.err; echo "deep rc=$?"
 VBNN_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-deep-config --steps 20 --warmup 5 > gpurun_out/${tag}_bench_dist1.json 2>> gpurun_out/${tag}_bench.err; echo "dist1 rc=$?"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag} -o ${tag} -- python3 $root/bench.py --no-cpu-baseline --no-reporting-config --no-deep-config --no-train-step --steps 20 --warmup 10 --repeats 2 > /dev/null 2>&1; echo "prof rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag} -o ${tag} -- python3 $root/bench.py --no-cpu-baseline --no-reporting-config --no-deep-config --no-train-step --no-box --steps 20 --warmup 10 --repeats 2 > /dev/null 2>&1; echo "prof rc=$?"
 cd $root
 python3 profiles/summarize_db.py gpurun_out/prof_${tag}/${tag}_results.db 70 > gpurun_out/${tag}_wide_kernel_stats.txt 2>&1
 python3 tools/step_timeline.py gpurun_out/prof_${tag}/${tag}_results.db > gpurun_out/${tag}_wide_step_timeline.txt 2>&1
 head -14 gpurun_out/${tag}_wide_kernel_stats.txt; cat gpurun_out/${tag}_wide_step_timeline.txt
 # the update sweep (VBLinear:update, excluded from the metric): its kernel rows
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}u -o ${tag}u -- python3 $root/bench.py --no-cpu-baseline --no-reporting-config --no-deep-config --steps 10 --warmup 5 --repeats 1 --with-update > /dev/null 2>&1; echo "prof update rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}u -o ${tag}u -- python3 $root/bench.py --no-cpu-baseline --no-reporting-config --no-deep-config --no-box --steps 10 --warmup 5 --repeats 1 --with-update > /dev/null 2>&1; echo "prof update rc=$?"
 cd $root
 python3 profiles/summarize_db.py gpurun_out/prof_${tag}u/${tag}u_results.db 70 | grep -i "update\|total ms" > gpurun_out/${tag}_update_kernel_stats.txt 2>&1; cat gpurun_out/${tag}_update_kernel_stats.txt
 # the fp32 configuration: kernel stats and one step's timeline

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The fused head's backward launch (vbnn_head_backward) in isolation at the wide configuration's size, microseconds per launch
 (HIP events around 20 back-to-back launches): python tools/time_head.py [label]. Variants by environment (one process each):
-VBNN_HEAD_FAST=0 (the general kernel), VBNN_HEAD_BLOCKS=n (target workgroup count)."""
+VBNN_HEAD_FAST=0 (the general kernel), VBNN_HEAD_BLOCKS=n (target workgroup count), VBNN_HEAD_STREAM=0 (the tile form instead of the streaming one)."""
 import ctypes as C
 import os
 import sys

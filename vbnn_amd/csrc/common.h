@@ -63,6 +63,7 @@ struct vbnn_ctx {
 constexpr int VBNN_CNT_HEAD_FWD = 0, VBNN_CNT_TILES = 16, VBNN_CNT_TILES_MAX = 1008, VBNN_CNT_TOTAL = 1024;   // [16, 1024): one ticket per column tile of the head's in-launch finish
 
 void vbnn_set_error(const char* fmt, ...);
+inline int g_head_stream = -1;   // vbnn_debug_set key 10 (VBNN_DEBUG_HEAD_BACKWARD): the head's backward -- -1 by shape, 0 tile form, 1 streaming form whenever the operands allow
 
 // hipFuncSetAttribute (the dynamic-LDS opt-in of the pipelined kernels) is per DEVICE: a per-instantiation flag that
 // remembers "done" must remember it per device, or the second GPU of a process launches unconfigured kernels.

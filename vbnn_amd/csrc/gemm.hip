@@ -11,6 +11,7 @@ extern "C" int vbnn_debug_set(int key, int value) {
     if (key == VBNN_DEBUG_KMAJOR && value >= 0 && value <= 2) { g_kmajor = value; return VBNN_OK; }   // 2: gemm_v3 only
     if (key == VBNN_DEBUG_V3_SPLIT && value >= -1 && value <= 1) { g_v3_split = value; return VBNN_OK; }
     if (key == VBNN_DEBUG_V0 && (value == 0 || value == 1)) { g_v0 = value; return VBNN_OK; }
+    if (key == VBNN_DEBUG_HEAD_BACKWARD && value >= -1 && value <= 1) { g_head_stream = value; return VBNN_OK; }
     vbnn_set_error("vbnn_debug_set: unknown key %d / value %d", key, value);
     return VBNN_ERR_INVALID;
 }

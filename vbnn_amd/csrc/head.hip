@@ -542,6 +542,182 @@ __global__ __launch_bounds__(256) void k_head_backward(const T* __restrict__ h, 
     }
 }
 
+// ---- the STREAMING form of the same backward (r05): bf16, whole tiles, C <= 12, r in the operand type, no transposed outputs -- the wide
+// configurations. k_head_backward above is latency-bound at TWO waves per SIMD (248 registers: the weight columns as 96 floats;
+// two barriers and three LDS tiles per 64 rows; r04's counters: VALU 27 % busy, LDS 26 %, nothing saturated). This form has no LDS
+// in its loop and no barrier, and runs FOUR waves per SIMD (1024-thread workgroups, <= 128 registers):
+//   - a lane owns 4 consecutive hidden units of a 256-wide column block, a wave a set of row PAIRS of the workgroup's row chunk;
+//   - d(loss)/d(logits) of a row is wave-uniform: 24 lanes load the pair's 2 x 12 values, round them to the operand type and hand
+//     them round by v_readlane -- they are SGPR operands of the dot products below, packed by the scalar unit as pairs over
+//     CLASSES (c, c + 1) of one row for the gradInput and as pairs over ROWS (n, n + 1) of one class for gradWeight;
+//   - gx[e] = sum over class pairs of v_dot2c_f32_bf16(g pair, weight pair): the weight columns as 24 registers of packed pairs;
+//   - gradWeight[c][i] += v_dot2c_f32_bf16(g row pair of class c, h row pair of unit i): 48 accumulators per lane, per row PAIR;
+//   - the bias gradient of the layer below: the rounded g_prev added up per lane; the final bias gradient from the unrounded g.
+// The sixteen waves' accumulators meet ONCE, at the end, through LDS in wave order (deterministic); the row-chunk partials go to
+// the same scratch layout and the same finish kernel. bf16 products are exact in fp32; the sums differ from the MFMA form's in
+// association (tolerances of the parity tests; every host runs the same kernel).
+typedef __bf16 hb_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float hb_dot2(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hb_bf16x2, a), __builtin_bit_cast(hb_bf16x2, b), c, false);
+}
+__device__ __forceinline__ unsigned hb_bf16_bits(float v) {           // RNE, NaN-safe: the operand type's rounding (v_cvt_pk_bf16_f32)
+    return (unsigned)__builtin_bit_cast(unsigned short, (bf16_t)v);
+}
+// U: hidden units per lane (a wave covers 64 U of them). 4 needs 48 + 24 registers of accumulators and weight pairs alone and spilled
+// at the 128 a 1024-thread workgroup allows; 2 (4-byte loads, 128 units per wave) leaves room for the next row pair in flight.
+template <int U, int HEAD_SW /* waves of a workgroup */>
+__global__ __launch_bounds__(64 * HEAD_SW) void k_head_backward_stream(
+    const bf16_t* __restrict__ h, int64_t ld_h, const bf16_t* __restrict__ w3, int64_t ld_w, const float* __restrict__ g, int64_t N,
+    int64_t H, int C, int relu_mask, const bf16_t* __restrict__ r_prev, int64_t ld_r, bf16_t* __restrict__ g_prev,
+    bf16_t* __restrict__ gv_prev, int64_t ld_gp, int rows_per_chunk, float* __restrict__ partial_w /* [R][C][H] */,
+    float* __restrict__ partial_b /* [R][C] */, float* __restrict__ partial_bp /* [R][H] */) {
+    static_assert(U == 2 || U == 4, "2 or 4 hidden units per lane");
+    constexpr int CP = 12, NP = CP / 2, UW = U / 2;                    // UW: 32-bit words of packed bf16 per lane and row
+    typedef float accv __attribute__((ext_vector_type(U)));
+    typedef unsigned rawv __attribute__((ext_vector_type(UW)));
+    __shared__ accv red[4][HEAD_SW][64];                               // four accumulator groups of every wave at a time
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t cb0 = (int64_t)blockIdx.x * (64 * U);                // the workgroup's column block
+    const int64_t c0 = cb0 + U * lane;                                 // the lane's U hidden units
+    const int64_t n_lo = (int64_t)blockIdx.y * rows_per_chunk, n_hi = min(N, n_lo + rows_per_chunk);
+    // ---- the lane's weight columns as pairs over classes: wp[p][e] = (w3[2p][c0 + e], w3[2p + 1][c0 + e])
+    unsigned wp[NP][U];
+    {
+        unsigned wr[CP][UW];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            rawv t = 0u;
+            if (c < C) t = *reinterpret_cast<const rawv*>(w3 + (int64_t)c * ld_w + c0);
+#pragma unroll
+            for (int k = 0; k < UW; ++k) wr[c][k] = ((const unsigned*)&t)[k];
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const unsigned lo = (wr[2 * p][e >> 1] >> (16 * (e & 1))) & 0xffffu, hi = (wr[2 * p + 1][e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                wp[p][e] = lo | (hi << 16);
+            }
+    }
+    float accw[CP][U], accb[U], accg = 0.f;
+#pragma unroll
+    for (int e = 0; e < U; ++e) accb[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+#pragma unroll
+        for (int e = 0; e < U; ++e) accw[c][e] = 0.f;
+    // lanes 0 .. 11: class `lane` of the pair's first row; lanes 12 .. 23: class `lane - 12` of its second row
+    const int gcls = lane < CP ? lane : lane - CP;
+    const bool gl_on = lane < 2 * CP && gcls < C;
+    const bool has_r = r_prev != nullptr;
+    const unsigned lo_h = (unsigned)(U * lane);
+    auto ldrow = [&](int64_t n, rawv& hv, rawv& rv) {
+        hv = *reinterpret_cast<const rawv*>(h + (n * ld_h + cb0) + lo_h);
+        rv = 0u;
+        if (has_r) rv = *reinterpret_cast<const rawv*>(r_prev + (n * ld_r + cb0) + lo_h);
+    };
+    auto ldg = [&](int64_t n) { return gl_on ? g[(n + (lane >= CP ? 1 : 0)) * C + gcls] : 0.f; };
+    auto word = [](const rawv& v, int k) { return ((const unsigned*)&v)[k]; };
+    int64_t n = n_lo + 2 * wave;
+    rawv h0 = 0u, h1 = 0u, r0 = 0u, r1 = 0u;                            // one row pair ahead in flight
+    float gv = 0.f;
+    if (n < n_hi) { ldrow(n, h0, r0); ldrow(n + 1, h1, r1); gv = ldg(n); }
+    for (; n < n_hi; n += 2 * HEAD_SW) {
+        const rawv hh[2] = {h0, h1}, rr[2] = {r0, r1};
+        const float cg = gv;
+        const int64_t nn = n + 2 * HEAD_SW;
+        if (nn < n_hi) { ldrow(nn, h0, r0); ldrow(nn + 1, h1, r1); gv = ldg(nn); }
+        accg += cg;                                                    // UNROUNDED: the final Linear's bias gradient (column block 0 stores it)
+        const unsigned gb = hb_bf16_bits(cg);
+        // the pair's 2 x 12 rounded values as wave-uniform scalars
+        unsigned g0[CP], g1[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) { g0[c] = __builtin_amdgcn_readlane(gb, c); g1[c] = __builtin_amdgcn_readlane(gb, CP + c); }
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const unsigned* gs = row ? g1 : g0;
+            float gx[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) gx[e] = 0.f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const unsigned gp2 = gs[2 * p] | (gs[2 * p + 1] << 16);     // classes (2p, 2p + 1) of this row: scalar
+#pragma unroll
+                for (int e = 0; e < U; ++e) gx[e] = hb_dot2(gp2, wp[p][e], gx[e]);
+            }
+            unsigned gbits[U], vbits[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const unsigned hw = word(hh[row], e >> 1), rw = word(rr[row], e >> 1);
+                const float hv = __builtin_bit_cast(float, (e & 1) ? (hw & 0xffff0000u) : (hw << 16));
+                const float rv = __builtin_bit_cast(float, (e & 1) ? (rw & 0xffff0000u) : (rw << 16));
+                const float gp = (relu_mask && !(hv > 0.f)) ? 0.f : gx[e];
+                gbits[e] = hb_bf16_bits(gp);
+                vbits[e] = hb_bf16_bits(has_r ? gp * rv : 0.f);
+                accb[e] += __builtin_bit_cast(float, gbits[e] << 16);  // the layer below's bias gradient adds the ROUNDED g_prev (what its GEMMs read)
+            }
+            const int64_t ro = (n + row) * ld_gp + cb0;
+            rawv og, ov;
+#pragma unroll
+            for (int k = 0; k < UW; ++k) { ((unsigned*)&og)[k] = gbits[2 * k] | (gbits[2 * k + 1] << 16); ((unsigned*)&ov)[k] = vbits[2 * k] | (vbits[2 * k + 1] << 16); }
+            *reinterpret_cast<rawv*>(g_prev + ro + lo_h) = og;
+            if (gv_prev) *reinterpret_cast<rawv*>(gv_prev + ro + lo_h) = ov;
+        }
+        // gradWeight: pairs over the two ROWS -- (h[n][i], h[n + 1][i]) per unit, (g[n][c], g[n + 1][c]) per class (scalar)
+        unsigned hp[U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const unsigned a = word(hh[0], e >> 1), b = word(hh[1], e >> 1);
+            hp[e] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+        }
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            const unsigned gr2 = g0[c] | (g1[c] << 16);
+#pragma unroll
+            for (int e = 0; e < U; ++e) accw[c][e] = hb_dot2(gr2, hp[e], accw[c][e]);
+        }
+    }
+    // ---- the sixteen waves' accumulators meet, four groups at a time, summed in wave order by waves 0 .. 3
+    const int64_t chunk = blockIdx.y;
+    auto meet = [&](const accv (&q)[4], int nq, auto&& emit) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nq) red[k][wave][lane] = q[k];
+        __syncthreads();
+        if (wave < nq) {
+            accv t = red[wave][0][lane];
+#pragma unroll
+            for (int w = 1; w < HEAD_SW; ++w) t += red[wave][w][lane];
+            emit(wave, t);
+        }
+    };
+#pragma unroll
+    for (int c4 = 0; c4 < CP; c4 += 4) {
+        accv q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < U; ++e) q[k][e] = accw[c4 + k][e];
+        meet(q, 4, [&](int k, accv t) {
+            if (partial_w && c4 + k < C) *reinterpret_cast<accv*>(partial_w + ((chunk * C + c4 + k) * H + c0)) = t;
+        });
+    }
+    {
+        accv q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < U; ++e) q[k][e] = (k == 0) ? accb[e] : ((k == 1 && e == 0) ? accg : 0.f);
+        meet(q, 2, [&](int k, accv t) {
+            // (k is wave-uniform) lane c holds the even rows' sum of class c, lane 12 + c the odd rows': even + odd
+            const float odd = __shfl(t[0], (lane + CP) & 63, 64);
+            if (k == 0) { if (partial_bp) *reinterpret_cast<accv*>(partial_bp + (chunk * H + c0)) = t; }
+            else if (partial_b && blockIdx.x == 0 && lane < CP && lane < C) partial_b[chunk * C + lane] = t[0] + odd;
+        });
+    }
+}
+
 // stage 2: k over C * H (gradWeight) followed by H (gradBias_prev); chunk partials added in chunk order
 __global__ __launch_bounds__(256) void k_head_backward_finish(const float* __restrict__ partial_w, const float* __restrict__ partial_b,
                                                               const float* __restrict__ partial_bp, int R, int64_t H, int C,
@@ -890,6 +1066,41 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
     // arriver's serial tail behind thousands of streaming workgroups costs more than the launch it saves, r01)
     const bool inline_fin = sums && tiles_c * R <= vbnn_cu_count() && tiles_c <= VBNN_CNT_TILES_MAX && g_head_inline_finish;
     unsigned* ft = inline_fin ? ctx->counters + VBNN_CNT_TILES : nullptr;
+    // the streaming form (k_head_backward_stream): bf16, whole tiles of 256 hidden units x 32 rows, C <= 12, r packed or absent, no
+    // transposed outputs -- the wide configurations. vbnn_debug_set(VBNN_DEBUG_HEAD_BACKWARD, 0 / 1) or VBNN_HEAD_STREAM=0: the tile form / this one (A/B, tests).
+    static const bool env_stream = [] { const char* e = getenv("VBNN_HEAD_STREAM"); return !(e && e[0] == '0'); }();
+    if constexpr (sizeof(T) == 2) {
+        const bool want = g_head_stream == 1 || (g_head_stream == -1 && env_stream && !inline_fin);
+        if (want && full && C <= 12 && !r_prev && g_prev && !gT_prev && !gvT_prev && H % 128 == 0 && N % 32 == 0) {
+            // 2 hidden units per lane, 16 waves per workgroup, one workgroup per CU. (Lab, same box, head backward + finish per call: the tile
+            // form 36.0 / 35.7 us, this one 32.1 / 32.0; 4 units x 8 waves 34.4 / 30.3 -- 142 registers, three waves per SIMD --; 2 x 8
+            // with two workgroups per CU 33.1 / 34.3.)
+            constexpr int SU = 2, SWV = 16;
+            if (H % (64 * SU) == 0 && N % (2 * SWV) == 0) {
+            const int64_t cb = H / (64 * SU);
+            int64_t Rs = ((int64_t)vbnn_cu_count() + cb - 1) / cb;
+            if (Rs < 1) Rs = 1;
+            if (sums && Rs > cap) Rs = cap;
+            const int rpc = (int)(((N + Rs - 1) / Rs + 2 * SWV - 1) / (2 * SWV) * (2 * SWV));
+            Rs = (N + rpc - 1) / rpc;
+            float* spw = reinterpret_cast<float*>(ctx->scratch);
+            float* spb = spw + Rs * C * H;
+            float* spbp = spb + Rs * C;
+#define VBNN_HS_LAUNCH(UU, WW) hipLaunchKernelGGL((k_head_backward_stream<UU, WW>), dim3((unsigned)cb, (unsigned)Rs), dim3(64 * WW), 0, ctx->stream, (const bf16_t*)h, ld_h, \
+                               (const bf16_t*)w3, ld_w, g_logits, N, H, (int)C, relu_mask, (const bf16_t*)r_prev_t, ld_r_prev, (bf16_t*)g_prev,  \
+                               (bf16_t*)gv_prev, ld_gp, rpc, (gradWeight || gradBias_prev) ? spw : nullptr, gradBias ? spb : nullptr,         \
+                               gradBias_prev ? spbp : nullptr)
+            VBNN_HS_LAUNCH(SU, SWV);
+#undef VBNN_HS_LAUNCH
+            if (sums) {
+                const int64_t outs = C * H + (gradBias_prev ? H : 0);
+                hipLaunchKernelGGL(k_head_backward_finish, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, ctx->stream, spw, spb, spbp,
+                                   (int)Rs, H, (int)C, accumulate, gradWeight, gradBias, gradBias_prev);
+            }
+            return vbnn_check_launch("k_head_backward_stream");
+            }
+        }
+    }
     if (full && C <= 12 && !r_prev)
         hipLaunchKernelGGL((k_head_backward<T, true, true, 12>), grid, dim3(256), 0, ctx->stream, h, ld_h, w3, ld_w, g_logits, N, H, (int)C,
                            relu_mask, r_prev, r_prev_t, ld_r_prev, g_prev, gv_prev, ld_gp, gT_prev, gvT_prev, ld_gpT, rows_per_chunk,
