@@ -1,9 +1,4 @@
 set -o pipefail
 mkdir -p gpurun_out
-echo "== tests"; timeout -k 10 900 python3 -m pytest tests -m gpu -x -q --durations=5 > gpurun_out/r05h_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r05h_tests.log
-echo "== bench"; timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > gpurun_out/r05h_bench_wide_driver.json 2> gpurun_out/r05h_bench.err; echo "bench rc=$?"
-python3 - <<'PY'
-import json
-d = json.loads(open("gpurun_out/r05h_bench_wide_driver.json").read().strip().splitlines()[-1])
-print(d["ms_per_step"], d["value"], d["config"]["repeats_wall_ms"], d["box"]["mfma_clock_ghz"], d["roofline"].get("frac"), d["roofline"].get("frac_at_held_clock"), d["train_step"]["ms_per_train_step"], d["deep_config"]["ms_per_step"])
-PY
+echo "== head tests"; timeout -k 10 600 python3 -m pytest tests/test_parity_gpu.py tests/test_c_host.py -m gpu -x -q -k "streaming_head or head_logits or full_size_wide_step or wide_training_steps or c_host" > gpurun_out/r05i_tests.log 2>&1; echo "rc=$?"; tail -3 gpurun_out/r05i_tests.log
+echo "== head timing"; for r in 1 2; do VBNN_HEAD_STREAM=0 timeout -k 10 120 python3 tools/time_head.py tile; VBNN_HEAD_INLINE_FINISH=0 timeout -k 10 120 python3 tools/time_head.py stream+finish-kernel; timeout -k 10 120 python3 tools/time_head.py stream+inline-finish; done 2>&1 | grep -v amdgpu.ids

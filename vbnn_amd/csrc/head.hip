@@ -570,7 +570,8 @@ __global__ __launch_bounds__(64 * HEAD_SW) void k_head_backward_stream(
     const bf16_t* __restrict__ h, int64_t ld_h, const bf16_t* __restrict__ w3, int64_t ld_w, const float* __restrict__ g, int64_t N,
     int64_t H, int C, int relu_mask, const bf16_t* __restrict__ r_prev, int64_t ld_r, bf16_t* __restrict__ g_prev,
     bf16_t* __restrict__ gv_prev, int64_t ld_gp, int rows_per_chunk, float* __restrict__ partial_w /* [R][C][H] */,
-    float* __restrict__ partial_b /* [R][C] */, float* __restrict__ partial_bp /* [R][H] */) {
+    float* __restrict__ partial_b /* [R][C] */, float* __restrict__ partial_bp /* [R][H] */,
+    unsigned* fin_tickets /* NULL: a finish kernel follows */, int fin_accumulate, float* fin_gw, float* fin_gb, float* fin_gbp) {
     static_assert(U == 2 || U == 4, "2 or 4 hidden units per lane");
     constexpr int CP = 12, NP = CP / 2, UW = U / 2;                    // UW: 32-bit words of packed bf16 per lane and row
     typedef float accv __attribute__((ext_vector_type(U)));
@@ -679,6 +680,12 @@ __global__ __launch_bounds__(64 * HEAD_SW) void k_head_backward_stream(
     }
     // ---- the sixteen waves' accumulators meet, four groups at a time, summed in wave order by waves 0 .. 3
     const int64_t chunk = blockIdx.y;
+    // (with an in-launch finish the partials are the last arriver's payload: write-through stores, vbnn_last_arriver)
+    auto put = [&](float* p, const accv& t) {
+        if (!fin_tickets) { *reinterpret_cast<accv*>(p) = t; return; }
+#pragma unroll
+        for (int e = 0; e < U; e += 2) vbnn_store_wt2(p + e, t[e], t[e + 1]);
+    };
     auto meet = [&](const accv (&q)[4], int nq, auto&& emit) {
         __syncthreads();
 #pragma unroll
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(64 * HEAD_SW) void k_head_backward_stream(
 #pragma unroll
             for (int e = 0; e < U; ++e) q[k][e] = accw[c4 + k][e];
         meet(q, 4, [&](int k, accv t) {
-            if (partial_w && c4 + k < C) *reinterpret_cast<accv*>(partial_w + ((chunk * C + c4 + k) * H + c0)) = t;
+            if (partial_w && c4 + k < C) put(partial_w + ((chunk * C + c4 + k) * H + c0), t);
         });
     }
     {
@@ -712,9 +719,33 @@ __global__ __launch_bounds__(64 * HEAD_SW) void k_head_backward_stream(
         meet(q, 2, [&](int k, accv t) {
             // (k is wave-uniform) lane c holds the even rows' sum of class c, lane 12 + c the odd rows': even + odd
             const float odd = __shfl(t[0], (lane + CP) & 63, 64);
-            if (k == 0) { if (partial_bp) *reinterpret_cast<accv*>(partial_bp + (chunk * H + c0)) = t; }
-            else if (partial_b && blockIdx.x == 0 && lane < CP && lane < C) partial_b[chunk * C + lane] = t[0] + odd;
+            if (k == 0) { if (partial_bp) put(partial_bp + (chunk * H + c0), t); }
+            else if (partial_b && blockIdx.x == 0 && lane < CP && lane < C) {
+                if (fin_tickets) vbnn_store_wt(&partial_b[chunk * C + lane], t[0] + odd); else partial_b[chunk * C + lane] = t[0] + odd;
+            }
         });
+    }
+    // ---- in-launch finish (as k_head_backward's): the LAST of the column block's row-chunk workgroups to arrive adds the chunks' partials
+    // in chunk order -- head_sum_partials, the finish kernel's order and arithmetic: the same bits -- instead of a ~5 us launch behind
+    // 256 workgroups (the head's forward made the same trade at the same grid size)
+    if (!fin_tickets) return;
+    __shared__ int fin_last;
+    if (!vbnn_last_arriver(fin_tickets + blockIdx.x, gridDim.y, &fin_last)) return;
+    const int R = (int)gridDim.y;
+    const int64_t nw = (int64_t)C * H;
+    constexpr int CB = 64 * U;
+    for (int k = tid; k < C * CB + CB; k += 64 * HEAD_SW) {         // the block's C x CB gradWeight entries, then its CB gradBias_prev entries
+        const bool is_w = k < C * CB;
+        const int64_t i = cb0 + (is_w ? k % CB : k - C * CB);
+        float* dst = is_w ? (fin_gw ? fin_gw + (int64_t)(k / CB) * H + i : nullptr) : (fin_gbp ? fin_gbp + i : nullptr);
+        if (!dst) continue;
+        const float* src = is_w ? partial_w + (int64_t)(k / CB) * H + i : partial_bp + i;
+        const float tot = head_sum_partials(src, is_w ? nw : H, R);
+        *dst = (fin_accumulate ? *dst : 0.f) + tot;
+    }
+    if (blockIdx.x == 0 && tid < C && fin_gb) {
+        const float tot = head_sum_partials(partial_b + tid, C, R);
+        fin_gb[tid] = (fin_accumulate ? fin_gb[tid] : 0.f) + tot;
     }
 }
 
@@ -1089,10 +1120,12 @@ static int head_backward_t(vbnn_ctx* ctx, const T* h, int64_t ld_h, const T* w3,
 #define VBNN_HS_LAUNCH(UU, WW) hipLaunchKernelGGL((k_head_backward_stream<UU, WW>), dim3((unsigned)cb, (unsigned)Rs), dim3(64 * WW), 0, ctx->stream, (const bf16_t*)h, ld_h, \
                                (const bf16_t*)w3, ld_w, g_logits, N, H, (int)C, relu_mask, (const bf16_t*)r_prev_t, ld_r_prev, (bf16_t*)g_prev,  \
                                (bf16_t*)gv_prev, ld_gp, rpc, (gradWeight || gradBias_prev) ? spw : nullptr, gradBias ? spb : nullptr,         \
-                               gradBias_prev ? spbp : nullptr)
+                               gradBias_prev ? spbp : nullptr, sft, accumulate, gradWeight, gradBias, gradBias_prev)
+            // the in-launch finish where the tickets reach (one per column block); VBNN_HEAD_INLINE_FINISH=0: the finish kernel (A/B)
+            unsigned* sft = (sums && g_head_inline_finish && cb <= VBNN_CNT_TILES_MAX) ? ctx->counters + VBNN_CNT_TILES : nullptr;
             VBNN_HS_LAUNCH(SU, SWV);
 #undef VBNN_HS_LAUNCH
-            if (sums) {
+            if (sums && !sft) {
                 const int64_t outs = C * H + (gradBias_prev ? H : 0);
                 hipLaunchKernelGGL(k_head_backward_finish, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, ctx->stream, spw, spb, spbp,
                                    (int)Rs, H, (int)C, accumulate, gradWeight, gradBias, gradBias_prev);
