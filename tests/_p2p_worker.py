@@ -92,8 +92,21 @@ def main():
             for p in range(1, world):
                 acc += everyone[p][off:off + cnt]                          # rank order, fp32: the kernel's order
             want[off:off + cnt] = acc
+        # r05: the data kernels' grids are small by design (they co-reside with the GEMMs): a tiny grid walks every region in many
+        # grid-stride rounds, a large one in a single round -- the same bits either way
+        ex.set_grid(*[(0, 0), (3, 2), (1024, 256)][rep])
         for off, cnt in regions:
             ex.allreduce(ex.arena[off:off + cnt])
+        if rep == 2:
+            # the SAME region again with no finish() in between (a timing loop does this): the exchange must put its exit barrier in
+            # front -- a peer may still be gathering from the chunk this rank is about to reduce into. Every rank holds the sum S:
+            # the second all-reduce leaves (S + S) + ... in rank order
+            off, cnt = regions[0]
+            ex.allreduce(ex.arena[off:off + cnt])
+            acc = want[off:off + cnt].clone()
+            for p in range(1, world):
+                acc += want[off:off + cnt]
+            want[off:off + cnt] = acc
         ex.finish()
         got = (ex.arena * 1.0).cpu()                                        # consumer on the compute stream, behind finish()
         gave_up = ex.gave_up()

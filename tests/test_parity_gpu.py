@@ -2011,6 +2011,59 @@ def test_staged_stores_stay_inside_their_tensors(oracle, nnmod, hidden, I0, N):
 
 
 # ------------------------------------------------------------------------------------------- errors
+def test_box_calibration_reports_a_plausible_box(nnmod):
+    """vbnn_box_calibrate (bench.py's `box` block): the register-only MFMA probe holds a clock between 1.2 and 2.6 GHz and reaches
+    at least 85 % of what 2.5 PFLOP/s scales to at that clock (1024 SIMDs x 1024 flop per cycle); the stream copy moves its 1 GiB at
+    2 ... 8 TB/s; two calls agree to 5 %."""
+    import ctypes as C
+    from vbnn_amd import _lib as L
+    from vbnn_amd.nn import Context
+    ctx = Context.get(torch.device("cuda", 0))
+    got = []
+    for _ in range(2):
+        info = L.BoxInfo()
+        L.check(L.lib().vbnn_box_calibrate(ctx.h, C.byref(info)))
+        assert info.cus >= 64 and info.hbm_bytes == 1 << 30
+        assert 1.2 <= info.mfma_clock_ghz <= 2.6, info.mfma_clock_ghz
+        ceiling = info.cus * 4 * 1024 * info.mfma_clock_ghz * 1e9 / 1e12
+        assert 0.85 * ceiling <= info.mfma_tflops <= 1.02 * ceiling, (info.mfma_tflops, ceiling)
+        assert 2.0 <= info.hbm_TBps <= 8.0, info.hbm_TBps
+        got.append((info.mfma_clock_ghz, info.mfma_tflops, info.hbm_TBps))
+    for a, b in zip(*got):
+        assert abs(a - b) <= 0.05 * max(a, b), got
+
+
+def test_p2p_stand_in_runs_what_a_rank_of_eight_runs_and_switches_off(nnmod):
+    """vbnn_p2p_standin (LAB, one rank): with the stand-in on, an all-reduce launches the barrier / reduce-scatter / barrier /
+    all-gather chain of an 8-rank exchange against this arena -- its values are garbage afterwards by design, its status word
+    stays clear, the compute stream is ordered behind it by finish() -- and with it off the world-of-one exchange leaves the
+    arena alone again; paced and unpaced, default and tiny grids; a region that is shorter than the world."""
+    from vbnn_amd.comm import P2PExchange
+    from vbnn_amd.nn import Context
+    ctx = Context.get(torch.device("cuda", 0))
+    n = 1_000_003
+    ex = P2PExchange(ctx, 0, 1, n)
+    try:
+        ref = torch.randn(n, device="cuda")
+        for gbps, grid in ((0.0, (0, 0)), (770.0, (0, 0)), (0.0, (2, 1))):
+            ex.arena.copy_(ref)
+            ex.set_grid(*grid)
+            ex.standin(8, gbps)
+            for off, cnt in ((0, 500_000), (500_000, 500_003), (16, 5)):
+                ex.allreduce(ex.arena[off:off + cnt])
+            ex.finish()
+            torch.cuda.synchronize()
+            assert ex.gave_up() == 0
+            assert not torch.equal(ex.arena, ref), "the stand-in's kernels did not run"
+            ex.standin(0)
+            ex.arena.copy_(ref)
+            ex.allreduce(ex.arena[:n]); ex.finish()
+            torch.cuda.synchronize()
+            assert torch.equal(ex.arena, ref)
+    finally:
+        ex.close()
+
+
 def test_error_convention(nnmod):
     """Non-zero status + message instead of a crash (SURVEY 8b error convention)."""
     from vbnn_amd import _lib as L
