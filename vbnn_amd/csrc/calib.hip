@@ -125,7 +125,9 @@ extern "C" int vbnn_box_calibrate(vbnn_ctx* ctx, vbnn_box_info* out) {
         const int64_t n16 = (int64_t)(half / 16);
         for (int r = 0; r < 8; ++r) {
             if (r == 3 && hipEventRecord(e0, ctx->stream) != hipSuccess) { status = VBNN_ERR_HIP; break; }
-            hipLaunchKernelGGL(k_calib_copy, dim3(cus * 8), dim3(256), 0, ctx->stream, (const f32x4*)buf, (f32x4*)(buf + half), n16);
+            // (lab, one box: 4 nontemporal 16-byte loads in flight per lane; 8 workgroups per CU 4.3 TB/s, 32: 5.0, 64: 5.1; plain loads / stores
+            // or 8 in flight: 4.0-4.9; torch's copy_ of the same buffers: 5.3)
+            hipLaunchKernelGGL(k_calib_copy, dim3(cus * 64), dim3(256), 0, ctx->stream, (const f32x4*)buf, (f32x4*)(buf + half), n16);
         }
         if (status != VBNN_OK || hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) {
             vbnn_set_error("vbnn_box_calibrate: stream probe: %s", hipGetErrorString(hipGetLastError()));
