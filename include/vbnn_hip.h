@@ -457,7 +457,9 @@ int vbnn_transpose_packed(vbnn_ctx* ctx, int dtype, const void* src, int64_t ld_
  * handles round by its own means (as the RCCL unique id), every rank calls vbnn_p2p_connect with all of them in rank order
  * (world x VBNN_P2P_HANDLE_BYTES), and from then on vbnn_p2p_allreduce(offset, n) sums arena[offset, offset + n) over the ranks
  * in place: ordered behind the context's stream, run on a high-priority stream of its own, the sum formed in rank order (bitwise
- * the same arena on every rank). vbnn_p2p_finish orders the context's stream behind it. Every rank issues the same sequence.
+ * the same arena on every rank). vbnn_p2p_finish orders the context's stream behind it -- and launches the ONE exit barrier of the
+ * exchanges issued since the last finish ("every rank has finished gathering": only then may the arena be overwritten), so a host
+ * calls it before it lets anything write the arena again. Every rank issues the same sequence.
  * A barrier whose peers never arrive gives up after a bounded WALL time -- 20 s by default, VBNN_P2P_TIMEOUT_S in the environment
  * at create, or vbnn_p2p_set_timeout -- instead of hanging the device, and raises the exchange's status word: from then on every
  * data kernel of the exchange is a no-op (the arena keeps this rank's OWN gradients; no partial sum is ever written over them)

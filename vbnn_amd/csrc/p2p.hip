@@ -475,7 +475,7 @@ extern "C" int vbnn_p2p_set_grid(vbnn_p2p* p, int rs_blocks, int ag_blocks_per_p
     VBNN_API_END
 }
 
-// LAB, one rank only: from now on vbnn_p2p_allreduce runs what a rank of a `sim_world`-rank exchange would run -- the same three
+// LAB, one rank only: from now on vbnn_p2p_allreduce runs what a rank of a `sim_world`-rank exchange would run -- the same
 // barriers, the same two data kernels with the same grids and register footprint on the same high-priority stream behind the same
 // event -- against "peers" that are this arena itself, shifted by whole chunks (the bytes this device's memory serves and takes
 // per phase are a real rank's), each phase PACED to the wall time `inbound_GBps` of link bandwidth would need for the bytes a
