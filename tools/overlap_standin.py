@@ -25,7 +25,24 @@ from vbnn_amd.nn import fill_normal                       # noqa: E402
 STEPS, BLOCKS = 20, 3
 
 
+def one_arm():
+    """The default arm alone, 40 steps (for a kernel trace: tools/standin_timeline.py)."""
+    opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype="bf16", seed=3, input_size=784, hidden=[4096, 4096], n_classes=10,
+               fuse_kl=True, exchange="p2p")
+    eng = FusedMLP(opt, world_size=1, rank=0, force_reduce=True)
+    x = torch.empty(4096, 784, dtype=torch.float32, device="cuda")
+    fill_normal(x, 3, L.STREAM_DATA, 0, 0)
+    t = eng.synthetic_targets(x, 0)
+    eng.prepare()
+    eng.exchange().standin(8, 770.0)
+    for _ in range(40):
+        eng.resetGradients(); eng.sample(); eng.run(x, t); eng.finish()
+    torch.cuda.synchronize()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--one-arm":
+        return one_arm()
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05_overlap_standin.json")
     N = 4096
     opt = dict(var_init=1e-3, B=1e6, S=1, mode="lrt", dtype="bf16", seed=3, input_size=784, hidden=[4096, 4096], n_classes=10,

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(64) void k_p2p_barrier(P2PSync s) { (void)p2p_wave_
 // cache maintenance on the executing XCD's L2 (write back, invalidate): done by one wave of a one-workgroup kernel it is noise;
 // done by 256 workgroups' waves beside a GEMM it keeps throwing the GEMM's operand panels out of the L2s. (Polling relaxed and
 // acquiring once is not on offer either: a data kernel that waits INSIDE itself has passed its own start-of-kernel invalidate
-// before the peers produced what it is about to read.) What WAS kept from that exercise: the exit barrier ("nobody still reads this
+// before the peers produced what it is about to read: the form that polls relaxed and fences once per workgroup was built too --
+// it costs the GEMMs nothing and buys 3 us of a 0.89 ms step, LAB_NOTES.md section 11 -- and not kept.) What WAS kept from that exercise: the exit barrier ("nobody still reads this
 // rank's chunk") is ONE launch per step, in vbnn_p2p_finish, not one per message -- four launches per all-reduce instead of five.
 
 // The data kernels do NOTHING once a barrier of this rank has given up: a reduce-scatter on buckets a peer has not
