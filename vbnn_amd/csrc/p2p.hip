@@ -93,11 +93,12 @@ __global__ __launch_bounds__(64) void k_p2p_barrier(P2PSync s) { (void)p2p_wave_
 // do, and the step's last message has nothing to hide behind. Correct (334 tests) and much SLOWER in the one-GPU stand-in: 1.026 ms
 // per step against 0.891, the overlapped GEMMs 120 -> 186 us and 190 -> 237 us. A barrier's acquire / release at SYSTEM scope is
 // cache maintenance on the executing XCD's L2 (write back, invalidate): done by one wave of a one-workgroup kernel it is noise;
-// done by 256 workgroups' waves beside a GEMM it keeps throwing the GEMM's operand panels out of the L2s. (Polling relaxed and
-// acquiring once is not on offer either: a data kernel that waits INSIDE itself has passed its own start-of-kernel invalidate
-// before the peers produced what it is about to read: the form that polls relaxed and fences once per workgroup was built too --
-// it costs the GEMMs nothing and buys 3 us of a 0.89 ms step, LAB_NOTES.md section 11 -- and not kept.) What WAS kept from that exercise: the exit barrier ("nobody still reads this
-// rank's chunk") is ONE launch per step, in vbnn_p2p_finish, not one per message -- four launches per all-reduce instead of five.
+// done by 256 workgroups' waves beside a GEMM it keeps throwing the GEMM's operand panels out of the L2s. A second form -- the flag
+// page polled RELAXED (it is uncached: no cache maintenance) and exactly ONE acquire fence per workgroup once the last signal was
+// seen -- costs the GEMMs nothing and buys 3 us of a 0.89 ms step (the exposed tail is the last message's data and the stream
+// hand-offs, not the barrier launches: LAB_NOTES.md section 11): not kept either, two launches per message are not worth a second
+// synchronisation protocol that no second device has ever run. What WAS kept from that exercise: the exit barrier ("nobody still
+// reads this rank's chunk") is ONE launch per step, in vbnn_p2p_finish, not one per message -- four launches per all-reduce instead of five.
 
 // The data kernels do NOTHING once a barrier of this rank has given up: a reduce-scatter on buckets a peer has not
 // finished would put wrong sums into the gradient arena IN PLACE, where the next update reads them. With the status raised the
