@@ -459,7 +459,10 @@ int vbnn_transpose_packed(vbnn_ctx* ctx, int dtype, const void* src, int64_t ld_
  * in place: ordered behind the context's stream, run on a high-priority stream of its own, the sum formed in rank order (bitwise
  * the same arena on every rank). vbnn_p2p_finish orders the context's stream behind it -- and launches the ONE exit barrier of the
  * exchanges issued since the last finish ("every rank has finished gathering": only then may the arena be overwritten), so a host
- * calls it before it lets anything write the arena again. Every rank issues the same sequence.
+ * calls it before it lets anything write the arena again. Every rank issues the same sequence. (r05: a bucket is handed from the
+ * context's stream to the exchange stream through a TRIGGER word of the rank's flag page -- a one-thread kernel behind the launch
+ * that fills the bucket, polled by the exchange's first barrier -- not through an event: a marker packet costs the compute stream
+ * ~8 us of bubble per bucket and the exchange stream ~12 us to wake up; VBNN_P2P_FLAG_TRIGGER=0 at create keeps the events.)
  * A barrier whose peers never arrive gives up after a bounded WALL time -- 20 s by default, VBNN_P2P_TIMEOUT_S in the environment
  * at create, or vbnn_p2p_set_timeout -- instead of hanging the device, and raises the exchange's status word: from then on every
  * data kernel of the exchange is a no-op (the arena keeps this rank's OWN gradients; no partial sum is ever written over them)

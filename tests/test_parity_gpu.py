@@ -2055,6 +2055,20 @@ def test_p2p_stand_in_runs_what_a_rank_of_eight_runs_and_switches_off(nnmod):
             torch.cuda.synchronize()
             assert ex.gave_up() == 0
             assert not torch.equal(ex.arena, ref), "the stand-in's kernels did not run"
+            # the EIGHT-way reduce-scatter's arithmetic, bitwise (a world above four takes a second batch of peer loads; the box's
+            # process limit keeps the multi-process tests at four ranks): the stand-in's peers are this arena's own chunks, so its
+            # chunk 0 must hold ((((c0 + c1) + c2) + ...) + c7) of the ORIGINAL chunks in rank order -- and chunk 1, gathered from
+            # "peer 0", that same sum
+            ex.arena.copy_(ref)
+            ex.standin(8, gbps)
+            ex.allreduce(ex.arena[:800_000]); ex.finish()
+            torch.cuda.synchronize()
+            cs = 100_000
+            want = ref[:cs].clone()
+            for q in range(1, 8):
+                want += ref[q * cs:(q + 1) * cs]
+            assert torch.equal(ex.arena[:cs].view(torch.int32), want.view(torch.int32)), "the 8-way reduce-scatter's sum is not the rank-ordered fp32 sum"
+            assert torch.equal(ex.arena[cs:2 * cs].view(torch.int32), want.view(torch.int32)), "the all-gather did not deliver the reduced chunk"
             ex.standin(0)
             ex.arena.copy_(ref)
             ex.allreduce(ex.arena[:n]); ex.finish()

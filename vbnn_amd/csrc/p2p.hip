@@ -44,24 +44,47 @@ struct P2PArenas { float* a[P2P_MAX_WORLD]; };
 // flag page of a rank (uncached, 4 KiB): words [0, 8) = the epoch each peer has signalled, word 8 = this rank's status (the
 // epoch of a barrier that failed, else 0), words [16, 24) = "peer q's exchange is dead" (written by q when ITS barrier fails)
 constexpr int P2P_STATUS_WORD = P2P_MAX_WORLD, P2P_DEAD_WORD0 = 16;
+// word 24: this rank's TRIGGER count -- written by a one-thread kernel on the COMPUTE stream behind the launch that fills a bucket,
+// polled by the first barrier of that bucket's exchange (see p2p_trigger)
+constexpr int P2P_TRIGGER_WORD = 24;
 
 // what a barrier needs, by value in a kernel's arguments
 struct P2PSync {
     P2PFlags peers; unsigned* mine; unsigned* status;
     int rank, world; unsigned epoch; unsigned long long timeout_ticks;
+    unsigned trig;            // != 0: before it signals, the barrier waits for this rank's own trigger word to reach this count
 };
+
+__global__ __launch_bounds__(64) void k_p2p_signal(unsigned* word, unsigned value) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // One wave's worth of barrier: lane p < world signals peer p (when `signal`) and polls slot p of this rank's own page. Called by a
 // whole wave; returns (to every lane) whether every peer arrived.
 __device__ __forceinline__ bool p2p_wave_barrier(const P2PSync& s, bool signal) {
     const int p = threadIdx.x & 63;
     bool ok = true;
+    if (s.trig != 0u) {
+        // the bucket is complete on THIS rank once the compute stream's trigger kernel has run (it sits behind the launch that fills
+        // the bucket; that launch's end wrote its data back). Bounded like every poll; a rank whose trigger never comes fails its
+        // barrier AFTER signalling (below), so its peers do not wait out their own timeouts on it.
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int)(__hip_atomic_load(s.mine + P2P_TRIGGER_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - s.trig) < 0) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > s.timeout_ticks) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    const bool trig_ok = ok;
     if (p < s.world) {
         // (a rank whose exchange is dead still SIGNALS, so that no peer waits out its timeout on it; it does not poll again --
         // the exchange stays dead until the host clears the status on every rank)
         if (signal) __hip_atomic_store(s.peers.page[p] + s.rank, s.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (__hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+        if (!trig_ok || __hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
             ok = false;
+            if (!trig_ok) {
+                __hip_atomic_store(s.status, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (p != s.rank) __hip_atomic_store(s.peers.page[p] + P2P_DEAD_WORD0 + s.rank, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         } else {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             ok = false;
@@ -223,6 +246,8 @@ struct vbnn_p2p {
     unsigned epoch;
     unsigned long long timeout_ticks;
     bool have_stream, have_ready, have_done;
+    bool flag_trigger;               // buckets are handed to the exchange stream through the trigger word (p2p_trigger) instead of an event
+    unsigned trig_count, trig_pending;   // triggers issued so far; the count the NEXT entry barrier must wait for (0: none)
     bool need_final;                 // data kernels were enqueued since the last barrier launch: vbnn_p2p_finish owes the step's ONE barrier
     int n_regions; size_t reg_off[16]; int64_t reg_n[16];    // arena regions exchanged since then (an overlapping one forces that barrier early)
     int rs_blocks, ag_blocks;        // grids of the data kernels (vbnn_p2p_set_grid): workgroups of the reduce-scatter, of the all-gather PER PEER
@@ -237,6 +262,9 @@ struct vbnn_p2p {
 // keep up with the links even from LOCAL memory (32 / 4: +0.38 ms). Remote latency is higher than local, so the larger of the
 // equal grids is the default. VBNN_P2P_RS_BLOCKS / VBNN_P2P_AG_BLOCKS override at create, vbnn_p2p_set_grid later.
 constexpr int P2P_DEFAULT_RS_BLOCKS = 256, P2P_DEFAULT_AG_BLOCKS = 32;
+// (r05, the stand-in at 110 GB/s per link, two rounds on one box: 0.8979 / 0.8950 ms per step with event hand-offs, 0.8858 / 0.8825 with the
+// trigger word; VBNN_P2P_FLAG_TRIGGER=0 at create: the events)
+constexpr bool P2P_DEFAULT_FLAG_TRIGGER = true;
 
 // the next phase's barrier arguments (every phase -- every data kernel, every barrier launch -- is one epoch)
 static P2PSync p2p_next_sync(vbnn_p2p* p) {
@@ -244,7 +272,24 @@ static P2PSync p2p_next_sync(vbnn_p2p* p) {
     P2PSync s;
     s.peers = p->pages; s.mine = p->flags; s.status = p->status; s.rank = p->rank; s.world = p->world; s.epoch = p->epoch;
     s.timeout_ticks = p->timeout_ticks;
+    s.trig = p->trig_pending; p->trig_pending = 0;            // (the first barrier behind a trigger waits for it)
     return s;
+}
+// "the bucket is complete on this rank": everything enqueued on the compute stream so far comes first. An EVENT (record on the
+// compute stream, wait on the exchange stream) costs the compute stream a marker packet -- ~8 us of bubble between the two launches it
+// separates -- and the exchange stream ~12 us to wake up (kernel trace of the stand-in); the TRIGGER is a one-thread kernel on the
+// compute stream that bumps a word of this rank's own flag page, and the exchange's first barrier -- already resident, polling -- goes
+// on within a microsecond of it.
+static int p2p_trigger(vbnn_p2p* p) {
+    if (!p->flag_trigger || (p->world == 1 && p->sim_world <= 1)) {
+        VBNN_CHECK_HIP(hipEventRecord(p->ready, p->ctx->stream));
+        VBNN_CHECK_HIP(hipStreamWaitEvent(p->stream, p->ready, 0));
+        return VBNN_OK;
+    }
+    p->trig_count += 1;
+    hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, p->ctx->stream, p->flags + P2P_TRIGGER_WORD, p->trig_count);
+    p->trig_pending = p->trig_count;
+    return vbnn_check_launch("k_p2p_signal");
 }
 // a phase's ENTRY barrier: a one-workgroup launch in front of its data kernel
 static void p2p_entry_barrier(vbnn_p2p* p) {
@@ -328,6 +373,8 @@ extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_
     p->arena = nullptr; p->flags = nullptr; p->have_stream = p->have_ready = p->have_done = false;
     p->rs_blocks = P2P_DEFAULT_RS_BLOCKS; p->ag_blocks = P2P_DEFAULT_AG_BLOCKS; p->sim_world = 0; p->sim_GBps = 0.0;
     p->need_final = false; p->n_regions = 0;
+    p->flag_trigger = P2P_DEFAULT_FLAG_TRIGGER; p->trig_count = 0; p->trig_pending = 0;
+    if (const char* e = getenv("VBNN_P2P_FLAG_TRIGGER")) p->flag_trigger = e[0] == '1';
     if (const char* e = getenv("VBNN_P2P_RS_BLOCKS")) { const int v = atoi(e); if (v > 0 && v <= 4096) p->rs_blocks = v; }
     if (const char* e = getenv("VBNN_P2P_AG_BLOCKS")) { const int v = atoi(e); if (v > 0 && v <= 4096) p->ag_blocks = v; }
     for (int q = 0; q < P2P_MAX_WORLD; ++q) { p->arenas.a[q] = nullptr; p->pages.page[q] = nullptr; }
@@ -404,8 +451,7 @@ extern "C" int vbnn_p2p_allreduce(vbnn_p2p* p, size_t offset_floats, int64_t n) 
     VBNN_REQUIRE(p && n > 0 && offset_floats + (size_t)n <= p->arena_floats, "bucket outside the arena");
     VBNN_REQUIRE(p->connected, "vbnn_p2p_connect first");
     // everything enqueued on the compute stream so far (the accGradParameters launch that fills the bucket) comes first
-    VBNN_CHECK_HIP(hipEventRecord(p->ready, p->ctx->stream));
-    VBNN_CHECK_HIP(hipStreamWaitEvent(p->stream, p->ready, 0));
+    { const int tst = p2p_trigger(p); if (tst != VBNN_OK) return tst; }
     p->pending += 1;
     if (p->world == 1 && p->sim_world <= 1) return VBNN_OK;       // the sum over one rank (still ordered: finish waits for the stream)
     const bool sim = p->world == 1;                               // the one-GPU stand-in of a sim_world-rank exchange (vbnn_p2p_standin)
@@ -438,8 +484,7 @@ extern "C" int vbnn_p2p_reduce_scatter(vbnn_p2p* p, size_t offset_floats, int64_
     VBNN_API_BEGIN
     VBNN_REQUIRE(p && n_per_rank > 0 && offset_floats + (size_t)n_per_rank * (size_t)p->world <= p->arena_floats, "region outside the arena");
     VBNN_REQUIRE(p->connected, "vbnn_p2p_connect first");
-    VBNN_CHECK_HIP(hipEventRecord(p->ready, p->ctx->stream));
-    VBNN_CHECK_HIP(hipStreamWaitEvent(p->stream, p->ready, 0));
+    { const int tst = p2p_trigger(p); if (tst != VBNN_OK) return tst; }
     p->pending += 1;
     if (p->world == 1) return VBNN_OK;
     const size_t c0 = offset_floats + (size_t)p->rank * (size_t)n_per_rank;
@@ -455,8 +500,7 @@ extern "C" int vbnn_p2p_all_gather(vbnn_p2p* p, size_t offset_floats, int64_t n_
     VBNN_API_BEGIN
     VBNN_REQUIRE(p && n_per_rank > 0 && offset_floats + (size_t)n_per_rank * (size_t)p->world <= p->arena_floats, "region outside the arena");
     VBNN_REQUIRE(p->connected, "vbnn_p2p_connect first");
-    VBNN_CHECK_HIP(hipEventRecord(p->ready, p->ctx->stream));
-    VBNN_CHECK_HIP(hipStreamWaitEvent(p->stream, p->ready, 0));
+    { const int tst = p2p_trigger(p); if (tst != VBNN_OK) return tst; }
     p->pending += 1;
     if (p->world == 1) return VBNN_OK;
     const int vec = (offset_floats % 4 == 0 && n_per_rank % 4 == 0) ? 1 : 0;
