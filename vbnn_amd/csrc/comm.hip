@@ -73,10 +73,36 @@ struct vbnn_comm {
     ncclComm_t comm;
     int rank, world;
     hipStream_t stream;        // the exchange stream: all-reduces run here, beside the compute stream
-    hipEvent_t ready;          // compute stream -> exchange stream: the bucket is complete
+    hipEvent_t ready;          // compute stream -> exchange stream: the bucket is complete (the event form of the hand-off)
     hipEvent_t done;           // exchange stream -> compute stream: every all-reduce issued so far has finished
     int64_t pending;           // all-reduces issued since the last vbnn_comm_finish
+    unsigned* trig;            // uncached device word: the TRIGGER form of the hand-off (comm_handoff), or NULL: events
+    unsigned trig_count;
 };
+
+// ---- compute stream -> exchange stream: "the bucket is complete". As in p2p.hip (r05): an event record is a marker packet on the
+// compute stream -- ~8 us of bubble between the two launches it separates, per bucket -- and the exchange stream needs ~12 us to wake
+// up behind it (kernel trace of the one-GPU stand-in). The trigger form: a one-thread kernel on the compute stream bumps an uncached
+// word; a one-wave kernel on the exchange stream, in front of the collective, polls it. VBNN_COMM_FLAG_TRIGGER=0 at create: events.
+__global__ __launch_bounds__(64) void k_comm_signal(unsigned* word, unsigned value) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void k_comm_wait(const unsigned* word, unsigned value) {
+    // (unbounded on purpose: the trigger sits on the compute stream behind launches already enqueued -- it comes unless the device
+    // is lost; the sleep keeps the wave off the SIMD's issue slots)
+    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) __builtin_amdgcn_s_sleep(8);
+}
+static int comm_handoff(vbnn_comm* c) {
+    if (!c->trig) {
+        VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
+        VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+        return VBNN_OK;
+    }
+    c->trig_count += 1;
+    hipLaunchKernelGGL(k_comm_signal, dim3(1), dim3(64), 0, c->ctx->stream, c->trig, c->trig_count);
+    hipLaunchKernelGGL(k_comm_wait, dim3(1), dim3(64), 0, c->stream, c->trig, c->trig_count);
+    return vbnn_check_launch("comm hand-off");
+}
 
 extern "C" int vbnn_comm_unique_id(void* id_out) {
     VBNN_API_BEGIN
@@ -101,7 +127,7 @@ extern "C" int vbnn_comm_create(vbnn_ctx* ctx, int rank, int world, const void* 
     ncclUniqueId uid;
     memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
     vbnn_comm* c = new vbnn_comm();
-    c->ctx = ctx; c->rank = rank; c->world = world; c->pending = 0;
+    c->ctx = ctx; c->rank = rank; c->world = world; c->pending = 0; c->trig = nullptr; c->trig_count = 0;
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);
     if (r != ncclSuccess) {
         vbnn_set_error("ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device, g_rccl.GetErrorString(r));
@@ -113,6 +139,13 @@ extern "C" int vbnn_comm_create(vbnn_ctx* ctx, int rank, int world, const void* 
     hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+    {
+        const char* ev = getenv("VBNN_COMM_FLAG_TRIGGER");
+        if (e == hipSuccess && !(ev && ev[0] == '0')) {
+            e = hipExtMallocWithFlags((void**)&c->trig, 4096, hipDeviceMallocUncached);
+            if (e == hipSuccess) e = hipMemset(c->trig, 0, 4096);
+        }
+    }
     if (e != hipSuccess) {
         vbnn_set_error("exchange stream / events: %s", hipGetErrorString(e));
         (void)g_rccl.CommDestroy(c->comm);
@@ -133,6 +166,7 @@ extern "C" int vbnn_comm_destroy(vbnn_comm* c) {
     (void)hipEventDestroy(c->ready);
     (void)hipEventDestroy(c->done);
     (void)hipStreamDestroy(c->stream);
+    if (c->trig) (void)hipFree(c->trig);
     delete c;
     return VBNN_OK;
     VBNN_API_END
@@ -152,8 +186,7 @@ extern "C" int vbnn_allreduce_grads(vbnn_comm* c, float* buf, int64_t n) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(c && buf && n > 0, "argument");
     // everything enqueued on the compute stream so far (the accGradParameters launch that fills `buf`) comes first
-    VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
-    VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    { const int hst = comm_handoff(c); if (hst != VBNN_OK) return hst; }
     VBNN_CHECK_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, c->stream));
     c->pending += 1;
     return VBNN_OK;
@@ -163,8 +196,7 @@ extern "C" int vbnn_allreduce_grads(vbnn_comm* c, float* buf, int64_t n) {
 extern "C" int vbnn_allreduce_grads_bf16(vbnn_comm* c, void* buf, int64_t n) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(c && buf && n > 0, "argument");
-    VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
-    VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    { const int hst = comm_handoff(c); if (hst != VBNN_OK) return hst; }
     VBNN_CHECK_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclBfloat16, ncclSum, c->comm, c->stream));
     c->pending += 1;
     return VBNN_OK;
@@ -188,8 +220,7 @@ extern "C" int vbnn_comm_finish(vbnn_comm* c) {
 extern "C" int vbnn_comm_allgather_u64(vbnn_comm* c, const uint64_t* mine_dev, uint64_t* all_dev) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(c && mine_dev && all_dev, "argument");
-    VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
-    VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    { const int hst = comm_handoff(c); if (hst != VBNN_OK) return hst; }
     VBNN_CHECK_NCCL(g_rccl.AllGather(mine_dev, all_dev, 1, ncclUint64, c->comm, c->stream));
     c->pending += 1;
     return VBNN_OK;
@@ -201,8 +232,7 @@ extern "C" int vbnn_comm_allgather_u64(vbnn_comm* c, const uint64_t* mine_dev, u
 extern "C" int vbnn_comm_reduce_scatter(vbnn_comm* c, float* buf, int64_t n_per_rank) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(c && buf && n_per_rank > 0, "argument");
-    VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
-    VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    { const int hst = comm_handoff(c); if (hst != VBNN_OK) return hst; }
     VBNN_CHECK_NCCL(g_rccl.ReduceScatter(buf, buf + (size_t)c->rank * (size_t)n_per_rank, (size_t)n_per_rank, ncclFloat32, ncclSum, c->comm, c->stream));
     c->pending += 1;
     return VBNN_OK;
@@ -212,8 +242,7 @@ extern "C" int vbnn_comm_reduce_scatter(vbnn_comm* c, float* buf, int64_t n_per_
 extern "C" int vbnn_comm_all_gather(vbnn_comm* c, void* buf, int64_t bytes_per_rank) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(c && buf && bytes_per_rank > 0, "argument");
-    VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
-    VBNN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    { const int hst = comm_handoff(c); if (hst != VBNN_OK) return hst; }
     char* b = static_cast<char*>(buf);
     VBNN_CHECK_NCCL(g_rccl.AllGather(b + (size_t)c->rank * (size_t)bytes_per_rank, b, (size_t)bytes_per_rank, ncclInt8, c->comm, c->stream));
     c->pending += 1;
