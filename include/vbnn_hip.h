@@ -412,7 +412,8 @@ int vbnn_update(vbnn_ctx* ctx, int dtype, int n_layers, const vbnn_update_desc* 
  * librccl is loaded on first use (dlopen: VBNN_RCCL_PATH, then librccl.so.1); without it these calls return
  * VBNN_ERR_UNSUPPORTED and nothing else in the library is affected. (r05: the ordering behind the context's stream is a TRIGGER word --
  * a one-thread kernel on the context's stream, a one-wave kernel polling it on the exchange stream in front of the collective -- not
- * an event: a marker packet costs the context's stream ~8 us of bubble per bucket; VBNN_COMM_FLAG_TRIGGER=0 at create keeps the events.) */
+ * an event: a marker packet costs the context's stream ~8 us of bubble per bucket; vbnn_comm_finish hands BACK the same way, the roles
+ * swapped, as vbnn_p2p_finish does; VBNN_COMM_FLAG_TRIGGER=0 / VBNN_P2P_FLAG_TRIGGER=0 at create keep the events.) */
 #define VBNN_COMM_ID_BYTES 128
 typedef struct vbnn_comm vbnn_comm;
 int vbnn_comm_unique_id(void* id_out /* VBNN_COMM_ID_BYTES, host memory */);

@@ -77,7 +77,7 @@ struct vbnn_comm {
     hipEvent_t done;           // exchange stream -> compute stream: every all-reduce issued so far has finished
     int64_t pending;           // all-reduces issued since the last vbnn_comm_finish
     unsigned* trig;            // uncached device word: the TRIGGER form of the hand-off (comm_handoff), or NULL: events
-    unsigned trig_count;
+    unsigned trig_count, done_count;
 };
 
 // ---- compute stream -> exchange stream: "the bucket is complete". As in p2p.hip (r05): an event record is a marker packet on the
@@ -127,7 +127,7 @@ extern "C" int vbnn_comm_create(vbnn_ctx* ctx, int rank, int world, const void* 
     ncclUniqueId uid;
     memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
     vbnn_comm* c = new vbnn_comm();
-    c->ctx = ctx; c->rank = rank; c->world = world; c->pending = 0; c->trig = nullptr; c->trig_count = 0;
+    c->ctx = ctx; c->rank = rank; c->world = world; c->pending = 0; c->trig = nullptr; c->trig_count = 0; c->done_count = 0;
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);
     if (r != ncclSuccess) {
         vbnn_set_error("ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device, g_rccl.GetErrorString(r));
@@ -207,7 +207,15 @@ extern "C" int vbnn_comm_finish(vbnn_comm* c) {
     VBNN_API_BEGIN
     VBNN_REQUIRE(c, "null comm");
     if (c->pending == 0) return VBNN_OK;
-    // no host wait: the compute stream's NEXT launch (the update, the next minibatch) is ordered behind the exchange
+    // no host wait: the compute stream's NEXT launch (the update, the next minibatch) is ordered behind the exchange -- through the
+    // trigger page's second word (bumped on the exchange stream, polled by a one-wave kernel on the compute stream), or an event
+    if (c->trig) {
+        c->done_count += 1;
+        hipLaunchKernelGGL(k_comm_signal, dim3(1), dim3(64), 0, c->stream, c->trig + 1, c->done_count);
+        hipLaunchKernelGGL(k_comm_wait, dim3(1), dim3(64), 0, c->ctx->stream, c->trig + 1, c->done_count);
+        c->pending = 0;
+        return vbnn_check_launch("vbnn_comm_finish");
+    }
     VBNN_CHECK_HIP(hipEventRecord(c->done, c->stream));
     VBNN_CHECK_HIP(hipStreamWaitEvent(c->ctx->stream, c->done, 0));
     c->pending = 0;

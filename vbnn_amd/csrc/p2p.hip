@@ -47,6 +47,9 @@ constexpr int P2P_STATUS_WORD = P2P_MAX_WORLD, P2P_DEAD_WORD0 = 16;
 // word 24: this rank's TRIGGER count -- written by a one-thread kernel on the COMPUTE stream behind the launch that fills a bucket,
 // polled by the first barrier of that bucket's exchange (see p2p_trigger)
 constexpr int P2P_TRIGGER_WORD = 24;
+constexpr int P2P_DONE_WORD = 25;      // ... and the way back: bumped on the EXCHANGE stream behind the step's exit barrier, polled by a one-wave
+                                       // kernel on the compute stream (vbnn_p2p_finish) -- the compute stream resumes within a microsecond of the
+                                       // exchange's end instead of a marker packet's ~10 us later
 
 // what a barrier needs, by value in a kernel's arguments
 struct P2PSync {
@@ -57,6 +60,10 @@ struct P2PSync {
 
 __global__ __launch_bounds__(64) void k_p2p_signal(unsigned* word, unsigned value) {
     if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// (unbounded on purpose: what it waits for sits on the exchange stream behind kernels already enqueued, every one of them bounded)
+__global__ __launch_bounds__(64) void k_p2p_wait(const unsigned* word, unsigned value) {
+    while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) __builtin_amdgcn_s_sleep(8);
 }
 
 // One wave's worth of barrier: lane p < world signals peer p (when `signal`) and polls slot p of this rank's own page. Called by a
@@ -248,6 +255,7 @@ struct vbnn_p2p {
     bool have_stream, have_ready, have_done;
     bool flag_trigger;               // buckets are handed to the exchange stream through the trigger word (p2p_trigger) instead of an event
     unsigned trig_count, trig_pending;   // triggers issued so far; the count the NEXT entry barrier must wait for (0: none)
+    unsigned done_count;             // finishes handed back through P2P_DONE_WORD
     bool need_final;                 // data kernels were enqueued since the last barrier launch: vbnn_p2p_finish owes the step's ONE barrier
     int n_regions; size_t reg_off[16]; int64_t reg_n[16];    // arena regions exchanged since then (an overlapping one forces that barrier early)
     int rs_blocks, ag_blocks;        // grids of the data kernels (vbnn_p2p_set_grid): workgroups of the reduce-scatter, of the all-gather PER PEER
@@ -373,7 +381,7 @@ extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_
     p->arena = nullptr; p->flags = nullptr; p->have_stream = p->have_ready = p->have_done = false;
     p->rs_blocks = P2P_DEFAULT_RS_BLOCKS; p->ag_blocks = P2P_DEFAULT_AG_BLOCKS; p->sim_world = 0; p->sim_GBps = 0.0;
     p->need_final = false; p->n_regions = 0;
-    p->flag_trigger = P2P_DEFAULT_FLAG_TRIGGER; p->trig_count = 0; p->trig_pending = 0;
+    p->flag_trigger = P2P_DEFAULT_FLAG_TRIGGER; p->trig_count = 0; p->trig_pending = 0; p->done_count = 0;
     if (const char* e = getenv("VBNN_P2P_FLAG_TRIGGER")) p->flag_trigger = e[0] == '1';
     if (const char* e = getenv("VBNN_P2P_RS_BLOCKS")) { const int v = atoi(e); if (v > 0 && v <= 4096) p->rs_blocks = v; }
     if (const char* e = getenv("VBNN_P2P_AG_BLOCKS")) { const int v = atoi(e); if (v > 0 && v <= 4096) p->ag_blocks = v; }
@@ -544,6 +552,13 @@ extern "C" int vbnn_p2p_finish(vbnn_p2p* p) {
     if (p->need_final) {                     // the step's one barrier launch: every rank has finished every phase -- the arena may be overwritten
         const int st = p2p_barrier(p);
         if (st != VBNN_OK) return st;
+    }
+    if (p->flag_trigger && !(p->world == 1 && p->sim_world <= 1)) {
+        p->done_count += 1;
+        hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, p->stream, p->flags + P2P_DONE_WORD, p->done_count);
+        hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, p->ctx->stream, p->flags + P2P_DONE_WORD, p->done_count);
+        p->pending = 0;
+        return vbnn_check_launch("vbnn_p2p_finish");
     }
     VBNN_CHECK_HIP(hipEventRecord(p->done, p->stream));
     VBNN_CHECK_HIP(hipStreamWaitEvent(p->ctx->stream, p->done, 0));
