@@ -92,6 +92,15 @@ __global__ __launch_bounds__(64) void k_comm_wait(const unsigned* word, unsigned
     // is lost; the sleep keeps the wave off the SIMD's issue slots)
     while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) __builtin_amdgcn_s_sleep(8);
 }
+// signal on one stream, poll on the other -- the poll goes out only behind a signal that was accepted: a wait without its signal
+// would hold its stream for ever
+static int comm_signal_wait(hipStream_t from, hipStream_t to, unsigned* word, unsigned value, const char* what) {
+    hipLaunchKernelGGL(k_comm_signal, dim3(1), dim3(64), 0, from, word, value);
+    const int st = vbnn_check_launch(what);
+    if (st != VBNN_OK) return st;
+    hipLaunchKernelGGL(k_comm_wait, dim3(1), dim3(64), 0, to, word, value);
+    return vbnn_check_launch(what);
+}
 static int comm_handoff(vbnn_comm* c) {
     if (!c->trig) {
         VBNN_CHECK_HIP(hipEventRecord(c->ready, c->ctx->stream));
@@ -99,9 +108,7 @@ static int comm_handoff(vbnn_comm* c) {
         return VBNN_OK;
     }
     c->trig_count += 1;
-    hipLaunchKernelGGL(k_comm_signal, dim3(1), dim3(64), 0, c->ctx->stream, c->trig, c->trig_count);
-    hipLaunchKernelGGL(k_comm_wait, dim3(1), dim3(64), 0, c->stream, c->trig, c->trig_count);
-    return vbnn_check_launch("comm hand-off");
+    return comm_signal_wait(c->ctx->stream, c->stream, c->trig, c->trig_count, "comm hand-off");
 }
 
 extern "C" int vbnn_comm_unique_id(void* id_out) {
@@ -211,10 +218,8 @@ extern "C" int vbnn_comm_finish(vbnn_comm* c) {
     // trigger page's second word (bumped on the exchange stream, polled by a one-wave kernel on the compute stream), or an event
     if (c->trig) {
         c->done_count += 1;
-        hipLaunchKernelGGL(k_comm_signal, dim3(1), dim3(64), 0, c->stream, c->trig + 1, c->done_count);
-        hipLaunchKernelGGL(k_comm_wait, dim3(1), dim3(64), 0, c->ctx->stream, c->trig + 1, c->done_count);
         c->pending = 0;
-        return vbnn_check_launch("vbnn_comm_finish");
+        return comm_signal_wait(c->stream, c->ctx->stream, c->trig + 1, c->done_count, "vbnn_comm_finish");
     }
     VBNN_CHECK_HIP(hipEventRecord(c->done, c->stream));
     VBNN_CHECK_HIP(hipStreamWaitEvent(c->ctx->stream, c->done, 0));

@@ -296,8 +296,9 @@ static int p2p_trigger(vbnn_p2p* p) {
     }
     p->trig_count += 1;
     hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, p->ctx->stream, p->flags + P2P_TRIGGER_WORD, p->trig_count);
-    p->trig_pending = p->trig_count;
-    return vbnn_check_launch("k_p2p_signal");
+    const int st = vbnn_check_launch("k_p2p_signal");
+    if (st == VBNN_OK) p->trig_pending = p->trig_count;       // (the entry barrier's wait for it is bounded either way)
+    return st;
 }
 // a phase's ENTRY barrier: a one-workgroup launch in front of its data kernel
 static void p2p_entry_barrier(vbnn_p2p* p) {
@@ -555,9 +556,11 @@ extern "C" int vbnn_p2p_finish(vbnn_p2p* p) {
     }
     if (p->flag_trigger && !(p->world == 1 && p->sim_world <= 1)) {
         p->done_count += 1;
-        hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, p->stream, p->flags + P2P_DONE_WORD, p->done_count);
-        hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, p->ctx->stream, p->flags + P2P_DONE_WORD, p->done_count);
         p->pending = 0;
+        hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, p->stream, p->flags + P2P_DONE_WORD, p->done_count);
+        const int st = vbnn_check_launch("vbnn_p2p_finish");
+        if (st != VBNN_OK) return st;       // no poll without its signal: it would hold the context's stream for ever
+        hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, p->ctx->stream, p->flags + P2P_DONE_WORD, p->done_count);
         return vbnn_check_launch("vbnn_p2p_finish");
     }
     VBNN_CHECK_HIP(hipEventRecord(p->done, p->stream));
