@@ -147,8 +147,11 @@ extern "C" int vbnn_comm_create(vbnn_ctx* ctx, int rank, int world, const void* 
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
     {
+        // (the polled hand-offs need the two streams on different hardware queues, i.e. of different priority: p2p.hip)
         const char* ev = getenv("VBNN_COMM_FLAG_TRIGGER");
-        if (e == hipSuccess && !(ev && ev[0] == '0')) {
+        int prio = least;
+        const bool same_prio = (ctx->stream && hipStreamGetPriority(ctx->stream, &prio) == hipSuccess && prio == greatest) || greatest == least;
+        if (e == hipSuccess && !(ev && ev[0] == '0') && !same_prio) {
             e = hipExtMallocWithFlags((void**)&c->trig, 4096, hipDeviceMallocUncached);
             if (e == hipSuccess) e = hipMemset(c->trig, 0, 4096);
         }

@@ -413,6 +413,14 @@ extern "C" int vbnn_p2p_create(vbnn_ctx* ctx, int rank, int world, size_t arena_
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (e == hipSuccess) { e = hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, greatest); p->have_stream = e == hipSuccess; }
+    {
+        // The polled hand-offs need the two streams to make progress INDEPENDENTLY: a kernel polling at the head of a hardware queue
+        // that also carries the stream it waits for would wait for ever. Streams of different priority never share a queue; a
+        // context whose own stream already has the highest priority keeps the event hand-offs.
+        int prio = least;
+        if (ctx->stream && hipStreamGetPriority(ctx->stream, &prio) == hipSuccess && prio == greatest) p->flag_trigger = false;
+        if (greatest == least) p->flag_trigger = false;              // no priorities on this device: no such guarantee
+    }
     if (e == hipSuccess) { e = hipEventCreateWithFlags(&p->ready, hipEventDisableTiming); p->have_ready = e == hipSuccess; }
     if (e == hipSuccess) { e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming); p->have_done = e == hipSuccess; }
     if (e != hipSuccess) {
