@@ -41,6 +41,20 @@ __global__ __launch_bounds__(512, 2) void k_k_bigregs(float* p) {               
     for (int i = 0; i < 160; ++i) s += v[i] * v[(i + 7) % 160];
     if (p && s == 12345.f) p[0] = s;
 }
+// a whole chip's stores in the launch's LAST microseconds: every workgroup spins, then stores 384 KB (what a two-pass GEMM's epilogue does)
+template <int MODE>
+__global__ __launch_bounds__(512) void k_l_endburst(float* p) {
+    spin(3000);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* q = reinterpret_cast<f4*>(p) + (size_t)blockIdx.x * (384 * 1024 / 16);
+    const f4 v = {1.f, 2.f, 3.f, 4.f};
+    for (int i = threadIdx.x; i < 384 * 1024 / 16; i += 512) {
+        if (MODE == 0) q[i] = v;
+        else if (MODE == 1) __builtin_nontemporal_store(v, q + i);
+        else { __hip_atomic_store(reinterpret_cast<unsigned long long*>(q + i), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+               __hip_atomic_store(reinterpret_cast<unsigned long long*>(q + i) + 1, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+}
 int main() {
     float* buf; unsigned* cnt;
     const size_t n = 32u << 20;
@@ -59,6 +73,9 @@ int main() {
         hipLaunchKernelGGL(k_i_fence, dim3(1024), dim3(256), 0, s, (float*)nullptr); hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, (float*)nullptr);
         hipLaunchKernelGGL(k_j_atomic, dim3(1024), dim3(256), 0, s, cnt); hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, (float*)nullptr);
         hipLaunchKernelGGL(k_k_bigregs, dim3(256), dim3(512), 0, s, (float*)nullptr); hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, (float*)nullptr);
+        hipLaunchKernelGGL(k_l_endburst<0>, dim3(256), dim3(512), 0, s, buf); hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, (float*)nullptr);
+        hipLaunchKernelGGL(k_l_endburst<1>, dim3(256), dim3(512), 0, s, buf); hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, (float*)nullptr);
+        hipLaunchKernelGGL(k_l_endburst<2>, dim3(256), dim3(512), 0, s, buf); hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, (float*)nullptr);
         CK(hipStreamSynchronize(s));
     }
     printf("done\n");
